@@ -1,0 +1,102 @@
+"""ctypes front-ends for the CPU checkers under oracle/ (TEST INFRASTRUCTURE ONLY).
+
+  * ``restated``  -> oracle/_build/libctcoracle.so  (this repo's CPU restatement, oracle/ctc_oracle.cpp)
+  * ``reference`` -> oracle/_ref/libctcref.so       (the reference's own sources, built by oracle/Makefile)
+
+Both expose the marshalling contract of ctcdecode/src/binding.cpp:55-99 behind a C ABI.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RESTATED_SO = os.path.join(ROOT, "oracle", "_build", "libctcoracle.so")
+REFERENCE_SO = os.path.join(ROOT, "oracle", "_ref", "libctcref.so")
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def have_reference():
+    return os.path.exists(REFERENCE_SO)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def decode(probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, log_input=True,
+           threads=None, which="restated", want_stats=False):
+    """Returns dict(tokens[B,K,T], timesteps[B,K,T], scores[B,K], lens[B,K], nres[B]) as numpy arrays.
+
+    Unwritten positions are zero (the reference leaves them uninitialised, ctcdecode/__init__.py:83-86).
+    """
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    B, T, V = probs.shape
+    if seq_lens is not None:
+        seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    threads = threads or os.cpu_count() or 1
+    tok = np.zeros((B, beam, T), np.int32)
+    ts = np.zeros((B, beam, T), np.int32)
+    sc = np.zeros((B, beam), np.float32)
+    ln = np.zeros((B, beam), np.int32)
+    nres = np.zeros((B,), np.int32)
+    if which == "restated":
+        lib = ctypes.CDLL(RESTATED_SO)
+        stats = np.zeros((B, 5), np.int64) if want_stats else None
+        rc = lib.ctcoracle_decode_f32(_ptr(probs, _f32p), _ptr(seq_lens, _i32p), B, T, V, beam, threads,
+                                      ctypes.c_double(cutoff_prob), cutoff_top_n, blank_id, int(bool(log_input)),
+                                      _ptr(tok, _i32p), _ptr(ts, _i32p), _ptr(sc, _f32p), _ptr(ln, _i32p),
+                                      _ptr(nres, _i32p), _ptr(stats, _i64p))
+    elif which == "reference":
+        lib = ctypes.CDLL(REFERENCE_SO)
+        stats = None
+        rc = lib.ctcref_decode_f32(_ptr(probs, _f32p), _ptr(seq_lens, _i32p), B, T, V, beam, threads,
+                                   ctypes.c_double(cutoff_prob), cutoff_top_n, blank_id, int(bool(log_input)),
+                                   _ptr(tok, _i32p), _ptr(ts, _i32p), _ptr(sc, _f32p), _ptr(ln, _i32p),
+                                   _ptr(nres, _i32p))
+    else:
+        raise ValueError(which)
+    if rc != 1:
+        raise RuntimeError("checker returned %d" % rc)
+    out = dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)
+    if want_stats:
+        out["stats"] = stats
+    return out
+
+
+def assert_same(a, b, what=""):
+    """Bit-exact comparison of two result dicts on the region the reference defines."""
+    assert np.array_equal(a["nres"], b["nres"]), what + " n_results differ"
+    B, K = a["lens"].shape
+    for bi in range(B):
+        n = int(a["nres"][bi])
+        assert np.array_equal(a["lens"][bi, :n], b["lens"][bi, :n]), "%s lens differ (item %d)" % (what, bi)
+        sa = a["scores"][bi, :n].view(np.uint32)
+        sb = b["scores"][bi, :n].view(np.uint32)
+        assert np.array_equal(sa, sb), "%s scores differ bitwise (item %d): %s vs %s" % (
+            what, bi, a["scores"][bi, :n][sa != sb][:4], b["scores"][bi, :n][sa != sb][:4])
+        for p in range(n):
+            L = int(a["lens"][bi, p])
+            assert np.array_equal(a["tokens"][bi, p, :L], b["tokens"][bi, p, :L]), "%s tokens differ (item %d beam %d)" % (what, bi, p)
+            assert np.array_equal(a["timesteps"][bi, p, :L], b["timesteps"][bi, p, :L]), "%s timesteps differ (item %d beam %d)" % (what, bi, p)
+
+
+def synth_logprobs(B, T, V, seed, kind="randn", quant=None, blank_bias=0.0, blank_id=0):
+    """Synthetic log-softmax inputs (numpy only, so fixtures are reproducible without torch).
+
+    kind="randn": log_softmax of N(0,1) logits.  ``quant`` rounds the
+    log-probs to multiples of ``quant`` -- this manufactures exact score ties, the hard case
+    for parity.  ``blank_bias`` adds to the blank logit (blank-dominated posteriors).
+    """
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, T, V)).astype(np.float32)
+    x[:, :, blank_id] += np.float32(blank_bias)
+    m = x.max(axis=-1, keepdims=True)
+    lse = m + np.log(np.exp(x - m).sum(axis=-1, keepdims=True, dtype=np.float32), dtype=np.float32)
+    lp = (x - lse).astype(np.float32)
+    if quant:
+        lp = (np.round(lp / np.float32(quant)) * np.float32(quant)).astype(np.float32)
+    return lp
