@@ -1,0 +1,239 @@
+// stl_emul.h -- the selection / sorting algorithms the reference inherits from its toolchain,
+// restated so that a GPU lane can run them and obtain the SAME permutation.
+//
+// Why this exists: the reference prunes the beam with std::nth_element
+// (ctcdecode/src/ctc_beam_search_decoder.cpp:150-154) and orders the final beams with two
+// std::sort calls (ctc_beam_search_decoder.cpp:188-190, decoder_utils.cpp:59) under a
+// comparator (decoder_utils.cpp:122-132) for which exact ties are structural at long T
+// (SURVEY.md 7.3-H2).  Which of several comparator-equivalent prefixes survives, and in which
+// order equal beams are returned, is therefore decided by the algorithm inside libstdc++
+// (GCC 11: introselect / introsort with median-of-three pivots, Hoare partition, heap fallback
+// after 2*floor(lg n) levels, insertion-sort finish with threshold 16).  These are textbook
+// algorithms; this header is an independent array-index formulation of them (no iterators, no
+// recursion), validated element-for-element against the real std::nth_element / std::sort /
+// std::partial_sort by tests/native/stl_emul_check.cpp (random inputs with heavy ties plus
+// adversarial "quicksort killer" inputs that force the heap fallbacks).
+//
+// All functions work on v[first, last) of some trivially copyable T with a strict-weak
+// "goes before" predicate `before(a, b)`.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define STLEMU_HD __host__ __device__ inline
+#else
+#define STLEMU_HD inline
+#endif
+
+namespace stlemu {
+
+STLEMU_HD int floor_lg(int n) {  // n >= 1
+  int k = 0;
+  while (n > 1) {
+    n >>= 1;
+    ++k;
+  }
+  return k;
+}
+
+template <class T>
+STLEMU_HD void exch(T *v, int a, int b) {
+  T t = v[a];
+  v[a] = v[b];
+  v[b] = t;
+}
+
+// Put the median of v[a], v[b], v[c] into v[res].
+template <class T, class C>
+STLEMU_HD void median_to(T *v, int res, int a, int b, int c, C before) {
+  if (before(v[a], v[b])) {
+    if (before(v[b], v[c]))
+      exch(v, res, b);
+    else if (before(v[a], v[c]))
+      exch(v, res, c);
+    else
+      exch(v, res, a);
+  } else if (before(v[a], v[c])) {
+    exch(v, res, a);
+  } else if (before(v[b], v[c])) {
+    exch(v, res, c);
+  } else {
+    exch(v, res, b);
+  }
+}
+
+// Hoare partition of v[lo, hi) around the value at v[piv] (piv outside [lo, hi)); no bounds checks:
+// the caller guarantees sentinels exist (median-of-three does).
+template <class T, class C>
+STLEMU_HD int hoare_split(T *v, int lo, int hi, int piv, C before) {
+  for (;;) {
+    while (before(v[lo], v[piv])) ++lo;
+    --hi;
+    while (before(v[piv], v[hi])) --hi;
+    if (!(lo < hi)) return lo;
+    exch(v, lo, hi);
+    ++lo;
+  }
+}
+
+template <class T, class C>
+STLEMU_HD int split_with_median_pivot(T *v, int first, int last, C before) {
+  int mid = first + (last - first) / 2;
+  median_to(v, first, first + 1, mid, last - 1, before);
+  return hoare_split(v, first + 1, last, first, before);
+}
+
+// Binary max-heap (w.r.t. `before` as "less") helpers on v[base, base+len).
+template <class T, class C>
+STLEMU_HD void sift(T *v, int base, int hole, int len, T value, C before) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (before(v[base + child], v[base + child - 1])) --child;
+    v[base + hole] = v[base + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    v[base + hole] = v[base + child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && before(v[base + parent], value)) {
+    v[base + hole] = v[base + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  v[base + hole] = value;
+}
+
+template <class T, class C>
+STLEMU_HD void heapify(T *v, int first, int last, C before) {
+  const int len = last - first;
+  if (len < 2) return;
+  int parent = (len - 2) / 2;
+  for (;;) {
+    T value = v[first + parent];
+    sift(v, first, parent, len, value, before);
+    if (parent == 0) return;
+    --parent;
+  }
+}
+
+// Heap on [first, middle); replace the top by v[at] (which receives the old top).
+template <class T, class C>
+STLEMU_HD void pop_to(T *v, int first, int middle, int at, C before) {
+  T value = v[at];
+  v[at] = v[first];
+  sift(v, first, 0, middle - first, value, before);
+}
+
+template <class T, class C>
+STLEMU_HD void heap_select(T *v, int first, int middle, int last, C before) {
+  heapify(v, first, middle, before);
+  for (int i = middle; i < last; ++i)
+    if (before(v[i], v[first])) pop_to(v, first, middle, i, before);
+}
+
+template <class T, class C>
+STLEMU_HD void heap_sort_down(T *v, int first, int last, C before) {
+  while (last - first > 1) {
+    --last;
+    pop_to(v, first, last, last, before);
+  }
+}
+
+template <class T, class C>
+STLEMU_HD void linear_insert_unguarded(T *v, int at, C before) {
+  T value = v[at];
+  int prev = at - 1;
+  while (before(value, v[prev])) {
+    v[at] = v[prev];
+    at = prev;
+    --prev;
+  }
+  v[at] = value;
+}
+
+template <class T, class C>
+STLEMU_HD void insertion_sort(T *v, int first, int last, C before) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (before(v[i], v[first])) {
+      T value = v[i];
+      for (int j = i; j > first; --j) v[j] = v[j - 1];
+      v[first] = value;
+    } else {
+      linear_insert_unguarded(v, i, before);
+    }
+  }
+}
+
+// == std::nth_element(v+first, v+nth, v+last, before)
+template <class T, class C>
+STLEMU_HD void nth_element(T *v, int first, int nth, int last, C before) {
+  if (first == last || nth == last) return;
+  int depth = 2 * floor_lg(last - first);
+  while (last - first > 3) {
+    if (depth == 0) {
+      heap_select(v, first, nth + 1, last, before);
+      exch(v, first, nth);
+      return;
+    }
+    --depth;
+    int cut = split_with_median_pivot(v, first, last, before);
+    if (cut <= nth)
+      first = cut;
+    else
+      last = cut;
+  }
+  insertion_sort(v, first, last, before);
+}
+
+// == std::sort(v+first, v+last, before).  `stack` needs 3 * (2*floor_lg(n) + 2) ints.
+template <class T, class C>
+STLEMU_HD void sort(T *v, int first, int last, C before, int *stack) {
+  if (first == last) return;
+  const int lo0 = first, hi0 = last;
+  int sp = 0;
+  int depth = 2 * floor_lg(last - first);
+  // Each pending range carries the depth budget it was created with.  Sub-ranges are disjoint, so the
+  // order in which they are finished does not change the result.
+  for (;;) {
+    while (last - first > 16) {
+      if (depth == 0) {
+        heap_select(v, first, last, last, before);
+        heap_sort_down(v, first, last, before);
+        break;
+      }
+      --depth;
+      int cut = split_with_median_pivot(v, first, last, before);
+      stack[sp++] = cut;  // right part [cut, last) postponed
+      stack[sp++] = last;
+      stack[sp++] = depth;
+      last = cut;
+    }
+    if (sp == 0) break;
+    depth = stack[--sp];
+    last = stack[--sp];
+    first = stack[--sp];
+  }
+  first = lo0;
+  last = hi0;
+  if (last - first > 16) {
+    insertion_sort(v, first, first + 16, before);
+    for (int i = first + 16; i != last; ++i) linear_insert_unguarded(v, i, before);
+  } else {
+    insertion_sort(v, first, last, before);
+  }
+}
+
+// == std::partial_sort(v+first, v+middle, v+last, before)   (used by the tests to reach the heap code directly)
+template <class T, class C>
+STLEMU_HD void partial_sort(T *v, int first, int middle, int last, C before) {
+  heap_select(v, first, middle, last, before);
+  heap_sort_down(v, first, middle, before);
+}
+
+}  // namespace stlemu

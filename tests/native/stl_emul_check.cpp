@@ -1,0 +1,125 @@
+// Element-for-element check of ctcdecode_amd/csrc/stl_emul.h against the real libstdc++ algorithms the
+// reference calls (std::nth_element: ctc_beam_search_decoder.cpp:151; std::sort: :76,:189, decoder_utils.cpp:23,59).
+// Inputs: index arrays ordered by a key array with heavy ties (the comparator sees ties as equivalent, so the
+// resulting permutation of the INDICES exposes every internal decision), plus adversarial inputs built with
+// McIlroy's "killer adversary" against the live std::sort so that the depth-limit / heap fallbacks execute.
+#include "../../ctcdecode_amd/csrc/stl_emul.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <random>
+#include <vector>
+
+static long long g_checked = 0, g_bad = 0;
+
+struct ByKey {
+  const int *key;
+  bool operator()(uint32_t a, uint32_t b) const { return key[a] > key[b]; }  // "better first", like prefix_compare
+};
+
+static void check_all(const std::vector<int> &key, std::mt19937 &g) {
+  const int n = (int)key.size();
+  ByKey cmp{key.data()};
+  std::vector<uint32_t> base(n);
+  std::iota(base.begin(), base.end(), 0u);
+  // sort
+  {
+    std::vector<uint32_t> a = base, b = base;
+    std::vector<int> stack(3 * (2 * stlemu::floor_lg(n > 0 ? n : 1) + 4));
+    std::sort(a.begin(), a.end(), cmp);
+    stlemu::sort(b.data(), 0, n, cmp, stack.data());
+    ++g_checked;
+    if (a != b) { ++g_bad; fprintf(stderr, "sort mismatch n=%d\n", n); }
+    // second sort of an already-sorted array (the reference sorts twice)
+    std::sort(a.begin(), a.end(), cmp);
+    stlemu::sort(b.data(), 0, n, cmp, stack.data());
+    ++g_checked;
+    if (a != b) { ++g_bad; fprintf(stderr, "re-sort mismatch n=%d\n", n); }
+  }
+  // nth_element at a few positions
+  for (int rep = 0; rep < 4 && n > 0; ++rep) {
+    int nth = rep == 0 ? n / 2 : rep == 1 ? std::min(n, 100) % (n + 1) : (int)(g() % (n + 1));
+    std::vector<uint32_t> a = base, b = base;
+    std::nth_element(a.begin(), a.begin() + nth, a.end(), cmp);
+    stlemu::nth_element(b.data(), 0, nth, n, cmp);
+    ++g_checked;
+    if (a != b) { ++g_bad; fprintf(stderr, "nth_element mismatch n=%d nth=%d\n", n, nth); }
+  }
+  // partial_sort (reaches heap_select / sift directly)
+  if (n > 0) {
+    int mid = (int)(g() % (n + 1));
+    std::vector<uint32_t> a = base, b = base;
+    std::partial_sort(a.begin(), a.begin() + mid, a.end(), cmp);
+    stlemu::partial_sort(b.data(), 0, mid, n, cmp);
+    ++g_checked;
+    if (a != b) { ++g_bad; fprintf(stderr, "partial_sort mismatch n=%d mid=%d\n", n, mid); }
+  }
+}
+
+// McIlroy, "A Killer Adversary for Quicksort" (1999): decide values lazily while the real algorithm runs.
+struct Adversary {
+  std::vector<int> val;
+  int gas, nsolid = 0, candidate = 0;
+  explicit Adversary(int n) : val(n, n), gas(n) {}
+  bool less(int x, int y) {
+    if (val[x] == gas && val[y] == gas) {
+      if (x == candidate) val[x] = nsolid++; else val[y] = nsolid++;
+    }
+    if (val[x] == gas) candidate = x; else if (val[y] == gas) candidate = y;
+    return val[x] < val[y];
+  }
+};
+
+static std::vector<int> killer_for_sort(int n, bool descending) {
+  Adversary adv(n);
+  std::vector<int> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return descending ? adv.less(b, a) : adv.less(a, b); });
+  for (int &v : adv.val) if (v == adv.gas) v = adv.nsolid++;
+  return adv.val;
+}
+
+static std::vector<int> killer_for_nth(int n, int nth) {
+  Adversary adv(n);
+  std::vector<int> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::nth_element(idx.begin(), idx.begin() + nth, idx.end(), [&](int a, int b) { return adv.less(b, a); });
+  for (int &v : adv.val) if (v == adv.gas) v = adv.nsolid++;
+  return adv.val;
+}
+
+int main(int argc, char **argv) {
+  int rounds = argc > 1 ? atoi(argv[1]) : 3000;
+  std::mt19937 g(12345);
+  for (int r = 0; r < rounds; ++r) {
+    int n = r < 70 ? r : (int)(g() % 3200);
+    int distinct = 1 + (int)(g() % (r % 3 == 0 ? 4 : r % 3 == 1 ? 64 : 100000));
+    std::vector<int> key(n);
+    for (int &k : key) k = (int)(g() % distinct);
+    if (r % 5 == 0) std::sort(key.begin(), key.end());
+    if (r % 7 == 0) std::sort(key.begin(), key.end(), std::greater<int>());
+    check_all(key, g);
+  }
+  for (int n : {17, 33, 100, 257, 1000, 2900, 5000}) {
+    check_all(killer_for_sort(n, false), g);
+    check_all(killer_for_sort(n, true), g);
+    check_all(killer_for_nth(n, std::min(100, n / 2)), g);
+    // killers with ties folded in
+    std::vector<int> k = killer_for_sort(n, true);
+    for (int &v : k) v /= 3;
+    check_all(k, g);
+  }
+  // make sure the adversarial inputs really exercised the fallbacks: count comparisons of the real sort
+  {
+    std::vector<int> k = killer_for_sort(5000, true);
+    long long ncmp = 0;
+    std::vector<int> idx(5000);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { ++ncmp; return k[a] > k[b]; });
+    printf("killer comparisons at n=5000: %lld (n lg n = %d)\n", ncmp, 5000 * 12);
+  }
+  printf("mismatches=%lld checked=%lld\n", g_bad, g_checked);
+  return g_bad ? 1 : 0;
+}
