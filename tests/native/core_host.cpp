@@ -1,0 +1,110 @@
+// TEST INFRASTRUCTURE ONLY: the GPU decoder's per-utterance core (ctcdecode_amd/csrc/beam_core.h) instantiated with a
+// single sequential "thread", behind the same C signature as the oracle, so that the algorithm (DFS-ordered beam +
+// LCP array, Euler-tour slots, exact tie handling) is differential-tested on the CPU before it ever runs on a GPU.
+// The product never links this file.
+#define CTC_EXACT_MATH_HOST_TABLES
+#include "../../ctcdecode_amd/csrc/beam_core.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct HostX {
+  int tid() const { return 0; }
+  int nt() const { return 1; }
+  void sync() {}
+  int reduce_add(int v) { return v; }
+  uint32_t scan_excl(uint32_t *a, int n) {
+    uint32_t run = 0;
+    for (int i = 0; i < n; ++i) {
+      uint32_t v = a[i];
+      a[i] = run;
+      run += v;
+    }
+    return run;
+  }
+  void atomic_min(int *p, int v) { *p = std::min(*p, v); }
+};
+
+// Vocabulary pruning exactly as the reference does it (decoder_utils.cpp:10-45) -- host stand-in for the GPU prune pass.
+template <class T>
+T log_add(T a, T b) {
+  const T floor_v = -std::numeric_limits<T>::max();
+  if (a <= floor_v) return b;
+  if (b <= floor_v) return a;
+  T top = std::max(a, b);
+  return std::log(std::exp(a - top) + std::exp(b - top)) + top;
+}
+
+void prune_row(const float *row, int V, double cutoff_prob, int top_n, int *cnt, int *ch, float *lp) {
+  std::vector<std::pair<int, double>> pv;
+  for (int i = 0; i < V; ++i) pv.emplace_back(i, (double)row[i]);
+  size_t keep = (size_t)V;
+  std::sort(pv.begin(), pv.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.second > b.second; });
+  if (std::log(cutoff_prob) < 0.0) {
+    double cum = 0.0;
+    keep = 0;
+    for (size_t i = 0; i < pv.size(); ++i) {
+      cum = log_add(cum, pv[i].second);
+      ++keep;
+      if (cum >= cutoff_prob || keep >= (size_t)top_n) break;
+    }
+  } else {
+    keep = (size_t)top_n;
+  }
+  *cnt = (int)keep;
+  for (size_t i = 0; i < keep; ++i) {
+    ch[i] = pv[i].first;
+    lp[i] = (float)pv[i].second;
+  }
+}
+
+}  // namespace
+
+// log-probability input only (the prob->log conversion is a separate, elementwise stage of the product).
+extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, int num_threads,
+                                  double cutoff_prob, int cutoff_top_n, int blank_id, int32_t *out_tokens,
+                                  int32_t *out_timesteps, float *out_scores, int32_t *out_lens, int32_t *n_results) {
+  using namespace ctcbeam;
+  const bool pruned = std::log(cutoff_prob) < 0.0 || cutoff_top_n < V;
+  Dims d;
+  d.K = beam;
+  d.V = V;
+  d.Vc_max = pruned ? std::min(V, cutoff_top_n) : V;
+  d.use_rank_table = pruned ? 1 : 0;
+  std::atomic<int> next{0}, bad{0};
+  auto work = [&] {
+    Work w;
+    std::vector<char> mem(carve(w, nullptr, d) + 64);
+    std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
+    std::vector<int> pcnt(T), pch((size_t)T * d.Vc_max);
+    std::vector<float> plp((size_t)T * d.Vc_max);
+    for (;;) {
+      int b = next.fetch_add(1);
+      if (b >= B) return;
+      int len = seq_lens ? seq_lens[b] : T;
+      len = std::max(0, std::min(len, T));
+      carve(w, mem.data(), d);
+      HostX x;
+      const float *rows = probs + (size_t)b * T * V;
+      PrunedRows pr{pcnt.data(), pch.data(), plp.data(), d.Vc_max};
+      if (pruned)
+        for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
+      int st = decode_utterance(x, w, d, blank_id, pruned ? nullptr : rows, pruned ? &pr : nullptr, len, pool.data(), (int)pool.size(),
+                                ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T, out_timesteps + (size_t)b * beam * T,
+                                out_scores + (size_t)b * beam, out_lens + (size_t)b * beam, n_results + b);
+      if (st != ST_OK) bad = st;
+    }
+  };
+  std::vector<std::thread> pool_threads;
+  for (int i = 1; i < std::min(num_threads, B); ++i) pool_threads.emplace_back(work);
+  work();
+  for (auto &t : pool_threads) t.join();
+  return bad ? -bad : 1;
+}

@@ -100,3 +100,38 @@ def synth_logprobs(B, T, V, seed, kind="randn", quant=None, blank_bias=0.0, blan
     if quant:
         lp = (np.round(lp / np.float32(quant)) * np.float32(quant)).astype(np.float32)
     return lp
+
+
+CORE_HOST_SO = os.path.join(ROOT, "oracle", "_build", "libctccore_host.so")
+
+
+def build_core_host():
+    """Compile the GPU decoder's per-utterance core for the host (sequential policy) -- test infrastructure only."""
+    import subprocess
+
+    src = os.path.join(ROOT, "tests", "native", "core_host.cpp")
+    deps = [src] + [os.path.join(ROOT, "ctcdecode_amd", "csrc", f) for f in ("beam_core.h", "stl_emul.h", "exact_math.h")]
+    if os.path.exists(CORE_HOST_SO) and all(os.path.getmtime(CORE_HOST_SO) >= os.path.getmtime(p) for p in deps):
+        return CORE_HOST_SO
+    os.makedirs(os.path.dirname(CORE_HOST_SO), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", src, "-o", CORE_HOST_SO, "-lpthread"], check=True)
+    return CORE_HOST_SO
+
+
+def decode_core_host(probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, threads=None):
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    B, T, V = probs.shape
+    if seq_lens is not None:
+        seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    threads = threads or os.cpu_count() or 1
+    tok = np.zeros((B, beam, T), np.int32)
+    ts = np.zeros((B, beam, T), np.int32)
+    sc = np.zeros((B, beam), np.float32)
+    ln = np.zeros((B, beam), np.int32)
+    nres = np.zeros((B,), np.int32)
+    lib = ctypes.CDLL(build_core_host())
+    rc = lib.ctccore_decode_f32(_ptr(probs, _f32p), _ptr(seq_lens, _i32p), B, T, V, beam, threads, ctypes.c_double(cutoff_prob),
+                                cutoff_top_n, blank_id, _ptr(tok, _i32p), _ptr(ts, _i32p), _ptr(sc, _f32p), _ptr(ln, _i32p), _ptr(nres, _i32p))
+    if rc != 1:
+        raise RuntimeError("core returned %d" % rc)
+    return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)

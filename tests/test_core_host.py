@@ -1,0 +1,42 @@
+"""The GPU decoder's per-utterance core (ctcdecode_amd/csrc/beam_core.h) compiled for the host with a sequential
+execution policy, against the oracle and the committed reference fixtures.  This validates the ALGORITHM the HIP kernel
+runs (DFS-ordered beam + LCP array, Euler-tour candidate slots, exact tie replay) without a GPU; the -m gpu tests then
+check the same source running as a workgroup."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_util as ou
+
+
+@pytest.mark.parametrize("name", [n for n in gu.names() if "prob" not in n])
+def test_core_matches_reference_fixtures(name):
+    args, want = gu.load(name)
+    assert args.pop("log_input")
+    ou.assert_same(ou.decode_core_host(**args), want, name)
+
+
+def test_core_randomized_against_oracle():
+    rng = np.random.default_rng(7)
+    stats = np.zeros(5, np.int64)
+    for it in range(120):
+        V = int(rng.choice([3, 5, 9, 29, 29, 64]))
+        K = int(rng.choice([1, 2, 5, 16, 50, 100, 128]))
+        T = int(rng.integers(1, 200))
+        quant = [None, None, 0.5, 1.0, 0.25, 2.0][int(rng.integers(0, 6))]
+        bias = float(rng.choice([0, 0, 3, 6, -2]))
+        blank = int(rng.integers(0, V))
+        top_n = int(rng.choice([40, 40, 40, max(1, V // 2), 3]))
+        lp = ou.synth_logprobs(2, T, V, 5000 + it, quant=quant, blank_bias=bias, blank_id=blank)
+        sl = rng.integers(0, T + 5, size=2).astype(np.int32) if it % 4 == 0 else None
+        kw = dict(beam=K, blank_id=blank, cutoff_top_n=top_n)
+        a = ou.decode(lp, sl, which="restated", want_stats=True, **kw)
+        ou.assert_same(a, ou.decode_core_host(lp, sl, **kw), "case %d V=%d K=%d T=%d q=%s" % (it, V, K, T, quant))
+        stats += a["stats"].sum(0)
+    # the sweep must actually exercise the hard paths: tie splits at the K boundary, revived dead-interior nodes
+    assert stats[1] > 100 and stats[2] > 1000, stats
+
+
+def test_core_north_star_shape():
+    lp = ou.synth_logprobs(2, 1000, 29, 5)
+    ou.assert_same(ou.decode(lp, beam=100), ou.decode_core_host(lp, beam=100))
