@@ -1,0 +1,114 @@
+"""MI355X-native drop-in for ``ctcdecode.CTCBeamDecoder.decode()`` (no language model).
+
+Same constructor arguments, same ``decode(probs, seq_lens)`` call and the same four output tensors as
+ctcdecode/__init__.py:6-123 of the reference; the prefix beam search itself runs as a hand-written HIP kernel
+(one workgroup per utterance, beam in LDS) behind the C ABI in include/ctcdecode_amd.h.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import NativeError  # noqa: F401
+
+__all__ = ["CTCBeamDecoder", "NativeError"]
+
+
+class CTCBeamDecoder(object):
+    """See ctcdecode/__init__.py:6-51 of the reference for the meaning of the arguments.
+
+    Differences, all additive:
+      * ``device``: the MI355X to decode on (default: ``cuda:<current>``).
+      * ``decode_device()`` returns the four tensors in HBM without the device->host copy.
+      * positions the reference leaves uninitialised (``[b, p, out_len:]``, rows ``p >= #results``) are zero.
+      * a language model (``model_path``) is not part of this build: NotImplementedError.
+    """
+
+    def __init__(self, labels, model_path=None, alpha=0, beta=0, cutoff_top_n=40, cutoff_prob=1.0, beam_width=100,
+                 num_processes=4, blank_id=0, log_probs_input=False, device=None):
+        self.cutoff_top_n = cutoff_top_n
+        self._beam_width = beam_width
+        self._scorer = None
+        self._num_processes = num_processes
+        self._labels = list(labels)
+        self._num_labels = len(labels)
+        self._blank_id = blank_id
+        self._log_probs = 1 if log_probs_input else 0
+        self._cutoff_prob = cutoff_prob
+        if model_path is not None:
+            raise NotImplementedError("ctcdecode_amd: the KenLM scorer tier (model_path) is not built; decode without a language model")
+        if not torch.cuda.is_available():
+            raise RuntimeError("ctcdecode_amd: no HIP device visible; this decoder has no CPU path")
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self._device.type != "cuda":
+            raise ValueError("ctcdecode_amd: device must be a HIP (cuda:N) device")
+        if self._device.index is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        h = ctypes.c_void_p()
+        _native.check(_native.lib.ctcd_create(ctypes.byref(h), self._device.index))
+        self._handle = h
+
+    def set_threads(self, n):
+        _native.check(_native.lib.ctcd_set_threads(self._handle, int(n)))
+
+    def set_timing(self, on=True):
+        _native.check(_native.lib.ctcd_set_timing(self._handle, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        _native.check(_native.lib.ctcd_last_kernel_ms(self._handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def decode_device(self, probs, seq_lens=None, check=True):
+        """``probs``: [B, T, V] tensor (any device / float dtype).  Returns (beam_results, beam_scores, timesteps,
+        out_lens) as tensors in HBM on the decoder's device; asynchronous on the current stream when ``check`` is False."""
+        if probs.dim() != 3:
+            raise ValueError("probs must be [batch, time, labels]")
+        probs = probs.to(device=self._device, dtype=torch.float32).contiguous()
+        B, T, V = probs.shape
+        if V != self._num_labels:
+            raise ValueError("probs.shape[2] (%d) does not match the number of labels (%d)" % (V, self._num_labels))
+        if seq_lens is not None:
+            seq_lens = seq_lens.to(device=self._device, dtype=torch.int32).contiguous()
+            if seq_lens.numel() != B:
+                raise ValueError("seq_lens must have one entry per batch item")
+        K = self._beam_width
+        with torch.cuda.device(self._device):
+            output = torch.empty((B, K, T), dtype=torch.int32, device=self._device)
+            timesteps = torch.empty((B, K, T), dtype=torch.int32, device=self._device)
+            scores = torch.empty((B, K), dtype=torch.float32, device=self._device)
+            out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            _native.check(_native.lib.ctcd_beam_decode(
+                self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K,
+                self._num_processes, float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
+                output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), None, stream))
+            if check:
+                _native.check(_native.lib.ctcd_check_status(self._handle, B))
+        return output, scores, timesteps, out_len
+
+    def decode(self, probs, seq_lens=None):
+        """Drop-in for ctcdecode/__init__.py:53-123: returns CPU tensors (output, scores, timesteps, out_seq_len)."""
+        output, scores, timesteps, out_len = self.decode_device(probs, seq_lens)
+        return output.cpu(), scores.cpu(), timesteps.cpu(), out_len.cpu()
+
+    def character_based(self):
+        return None  # ctcdecode/__init__.py:125-126 without a scorer
+
+    def max_order(self):
+        return None
+
+    def dict_size(self):
+        return None
+
+    def reset_params(self, alpha, beta):
+        return None
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                _native.lib.ctcd_destroy(h)
+            except Exception:
+                pass
+            self._handle = None

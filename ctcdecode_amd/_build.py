@@ -1,0 +1,72 @@
+"""Builds ctcdecode_amd/_lib/libctcdecode_amd.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+The library must share the HIP runtime that PyTorch-ROCm has already loaded into the process (device pointers and
+streams cross the boundary), so it is linked against the libamdhip64.so that ships inside torch/lib (SONAME
+``libamdhip64.so``); /opt/rocm/lib is on the rpath as the fallback for a host program that does not use torch.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "_lib")
+LIB_PATH = os.path.join(LIB_DIR, "libctcdecode_amd.so")
+SOURCES = ["ctcdecode_amd.hip"]
+HEADERS = ["beam_core.h", "stl_emul.h", "exact_math.h", os.path.join("..", "..", "include", "ctcdecode_amd.h")]
+ROCM = os.environ.get("ROCM_HOME", "/opt/rocm")
+
+
+def _hipcc():
+    return shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+
+
+def _torch_lib_dir():
+    try:
+        import torch
+
+        d = os.path.join(os.path.dirname(torch.__file__), "lib")
+        if os.path.exists(os.path.join(d, "libamdhip64.so")):
+            return d
+    except Exception:
+        pass
+    return None
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+               "-Wno-unused-result", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    tl = _torch_lib_dir()
+    libdirs = ([tl] if tl else []) + [os.path.join(ROCM, "lib")]
+    link = ["g++", "-shared", "-o", LIB_PATH] + objs
+    for ld in libdirs:
+        link += ["-L" + ld, "-Wl,-rpath," + ld, "-Wl,-rpath-link," + ld]
+    link += ["-lamdhip64", "-lpthread"]
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    subprocess.run(link, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

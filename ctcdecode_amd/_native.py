@@ -1,0 +1,59 @@
+"""ctypes binding of the C ABI in include/ctcdecode_amd.h (the only way the Python layer reaches the decoder).
+
+There is NO CPU fallback: if the HIP library is missing or does not load, importing this module raises.
+"""
+import ctypes
+import os
+
+from . import _build
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+SYMBOLS = ["ctcd_create", "ctcd_destroy", "ctcd_beam_decode", "ctcd_beam_decode_host", "ctcd_check_status",
+           "ctcd_set_threads", "ctcd_set_timing", "ctcd_last_kernel_ms", "ctcd_debug_math_check", "ctcd_workgroup_lds_bytes", "ctcd_last_error", "ctcd_version"]
+
+
+def _load():
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("ctcdecode_amd: HIP library %s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or `python -m ctcdecode_amd._build`). There is no CPU fallback." % path)
+    import torch  # noqa: F401  (loads the HIP runtime the library must share with PyTorch-ROCm)
+
+    lib = ctypes.CDLL(path)
+    lib.ctcd_last_error.restype = ctypes.c_char_p
+    lib.ctcd_version.restype = ctypes.c_char_p
+    lib.ctcd_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    lib.ctcd_destroy.argtypes = [ctypes.c_void_p]
+    lib.ctcd_destroy.restype = None
+    lib.ctcd_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.ctcd_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.ctcd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.ctcd_debug_math_check.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
+    lib.ctcd_check_status.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.ctcd_workgroup_lds_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    common = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+              ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+              ctypes.c_void_p, ctypes.c_void_p]
+    lib.ctcd_beam_decode.argtypes = common + [ctypes.c_void_p]
+    lib.ctcd_beam_decode_host.argtypes = common
+    return lib
+
+
+lib = _load()
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib.ctcd_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError("ctcdecode_amd: " + msg)
+        if rc == -2:
+            raise NotImplementedError("ctcdecode_amd: " + msg)
+        raise NativeError("ctcdecode_amd (code %d): %s" % (rc, msg))

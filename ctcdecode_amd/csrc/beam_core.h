@@ -516,6 +516,10 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   Decoder<X> dec(x, w, d, blank, pool, pool_cap, tbl);
   dec.init();
   const int tid = x.tid(), nt = x.nt();
+  // Row prefetch: the row of step t+1 is requested from HBM before step t runs, so its latency hides behind the step.
+  const bool prefetch = pr == nullptr && d.V <= nt;
+  float pre = 0.f;
+  if (prefetch && len > 0 && tid < d.V) pre = rows[tid];
   for (int t = 0; t < len; ++t) {
     StepIn in;
     in.t = t;
@@ -523,7 +527,12 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       in.Vc = d.V;
       in.identity = 1;
       in.blank_rank = blank;
-      for (int r = tid; r < d.V; r += nt) w.clp[r] = rows[(size_t)t * d.V + r];
+      if (prefetch) {
+        if (tid < d.V) w.clp[tid] = pre;
+        if (t + 1 < len && tid < d.V) pre = rows[(size_t)(t + 1) * d.V + tid];
+      } else {
+        for (int r = tid; r < d.V; r += nt) w.clp[r] = rows[(size_t)t * d.V + r];
+      }
       x.sync();
     } else {
       in.Vc = pr->cnt[t];

@@ -1,0 +1,475 @@
+// ctcdecode_amd.hip -- gfx950 kernels + C ABI (include/ctcdecode_amd.h) of the CTC prefix beam-search decoder.
+//
+// Grid mapping (replaces the reference's ThreadPool fan-out, ctc_beam_search_decoder.cpp:259-275): one workgroup per
+// utterance; the whole T-step recurrence of that utterance runs inside ONE persistent kernel launch with the beam in
+// LDS (a kernel boundary costs ~1.5 us on MI355X -- more than a whole time step should).  The per-utterance algorithm
+// is beam_core.h; this file supplies the workgroup execution policy (barriers, wave-shuffle reductions/scans), the
+// elementwise prob->log pre-pass, and the host-side marshalling of binding.cpp:35-101.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ctcdecode_amd.h"
+#define CTC_EXACT_MATH_HOST_TABLES
+#include "beam_core.h"
+
+namespace {
+
+using namespace ctcbeam;
+
+// ------------------------------------------------------------------------------------------------ device policy
+struct DevX {
+  int *red;  // 2 x 16 ints of LDS
+  int parity;
+  __device__ int tid() const { return (int)threadIdx.x; }
+  __device__ int nt() const { return (int)blockDim.x; }
+  __device__ void sync() { __syncthreads(); }
+  __device__ void atomic_min(int *p, int v) { atomicMin(p, v); }
+
+  // Sum over the workgroup, same value returned to every thread.  One barrier per call: consecutive calls alternate
+  // between two scratch rows, and a row is only rewritten after a later barrier that every reader has passed.
+  __device__ int reduce_add(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int wave = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+    int *row = red + parity * 16;
+    parity ^= 1;
+    if ((threadIdx.x & 63) == 0) row[wave] = v;
+    __syncthreads();
+    int tot = 0;
+    for (int i = 0; i < nw; ++i) tot += row[i];
+    return tot;
+  }
+
+  // In-place exclusive prefix sum of a[0, n) in LDS; returns the total.  Each thread owns a contiguous chunk.
+  __device__ uint32_t scan_excl(uint32_t *a, int n) {
+    const int nthreads = (int)blockDim.x, t = (int)threadIdx.x;
+    const int chunk = (n + nthreads - 1) / nthreads;
+    const int lo = t * chunk, hi = min(lo + chunk, n);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += a[i];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += o;
+    }
+    const int wave = t >> 6, nw = (nthreads + 63) >> 6;
+    int *row = red + parity * 16;
+    parity ^= 1;
+    if ((t & 63) == 63) row[wave] = (int)incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int i = 0; i < nw; ++i) {
+      const uint32_t v = (uint32_t)row[i];
+      if (i < wave) base += v;
+      total += v;
+    }
+    uint32_t run = base + incl - sum;
+    for (int i = lo; i < hi; ++i) {
+      const uint32_t v = a[i];
+      a[i] = run;
+      run += v;
+    }
+    __syncthreads();
+    return total;
+  }
+};
+
+struct KernelArgs {
+  const float *probs;       // [B, T, V] log-probabilities
+  const int32_t *seq_lens;  // [B] or null
+  int B, T, V, K, blank;
+  Dims dims;
+  PoolNode *pool;           // [B, pool_stride]
+  long long pool_stride;
+  const uint64_t *tables;   // 64 words (exact_math.h)
+  int32_t *out_tok, *out_ts, *out_len, *n_results;
+  float *out_score;
+  int32_t *status;          // [B]
+};
+
+__global__ void ctc_beam_decode_kernel(KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ uint64_t tbl[64];
+  __shared__ int red[32];
+  const int b = (int)blockIdx.x;
+  if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
+  Work w;
+  carve(w, smem, a.dims);
+  DevX x{red, 0};
+  int len = a.seq_lens ? a.seq_lens[b] : a.T;
+  len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
+  __syncthreads();
+  const size_t kt = (size_t)a.K * a.T;
+  const int st = decode_utterance(x, w, a.dims, a.blank, a.probs + (size_t)b * a.T * a.V, (const PrunedRows *)nullptr, len,
+                                  a.pool + (size_t)b * a.pool_stride, (int)a.pool_stride, tbl, a.T,
+                                  a.out_tok + (size_t)b * kt, a.out_ts + (size_t)b * kt, a.out_score + (size_t)b * a.K,
+                                  a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr);
+  if (threadIdx.x == 0) a.status[b] = st;
+}
+
+// prob -> log-prob exactly as decoder_utils.cpp:42 : float(log(double(p) + FLT_MIN)).  The device log() is within
+// 1 ulp of the correctly rounded double; the element is flagged (and later recomputed with the host C library the
+// reference binds to) whenever that uncertainty could change the float it rounds to, so the result is bit-exact.
+__global__ void prob_to_log_kernel(const float *in, float *out, size_t n, unsigned *n_flag, unsigned long long *flag_idx,
+                                   unsigned flag_cap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double y = log((double)in[i] + (double)FLT_MIN);
+    const float f = (float)y;
+    const double eps = fabs(y) * 0x1p-50;
+    if ((float)(y - eps) != f || (float)(y + eps) != f || !(y == y)) {
+      unsigned k = atomicAdd(n_flag, 1u);
+      if (k < flag_cap) flag_idx[k] = (unsigned long long)i;
+    }
+    out[i] = f;
+  }
+}
+
+__global__ void debug_math_kernel(int mode, uint32_t start, uint32_t stride, const float *xs, const float *ys, float *out,
+                                  size_t n, const uint64_t *tables) {
+  __shared__ uint64_t tbl[64];
+  if (threadIdx.x < 64) tbl[threadIdx.x] = tables[threadIdx.x];
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 2) {
+    out[i] = ctcmath::lse(xs[i], ys[i], tbl);
+  } else {
+    const float x = ctcmath::bits_to_f32(start + (uint32_t)i * stride);
+    out[i] = mode == 0 ? ctcmath::expf_nonpos(x, tbl) : ctcmath::logf_normal(x, tbl);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(CTCD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+
+struct Buf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return CTCD_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(CTCD_EHIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    cap = bytes;
+    return CTCD_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct ctcd_decoder {
+  int device = 0;
+  int threads = 512;
+  int max_lds = 0;
+  Buf pool, status, tables, logp, flags, stage_in, stage_out;
+  bool tables_ready = false;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::mutex mu;
+};
+
+namespace {
+
+Dims make_dims(int beam, int V, int cutoff_top_n, double cutoff_prob) {
+  const bool pruned = cutoff_prob < 1.0 || cutoff_top_n < V;
+  Dims d;
+  d.K = beam;
+  d.V = V;
+  d.Vc_max = pruned ? (cutoff_top_n < V ? cutoff_top_n : V) : V;
+  d.use_rank_table = pruned ? 1 : 0;
+  return d;
+}
+
+int check_args(int B, int T, int V, int beam, int cutoff_top_n, int blank_id, const void *probs, const void *tok,
+               const void *ts, const void *sc, const void *ln) {
+  if (B < 0 || T < 0 || V <= 0 || beam <= 0 || cutoff_top_n <= 0) return fail(CTCD_EINVAL, "B, T >= 0 and V, beam_width, cutoff_top_n > 0 required");
+  if (blank_id < 0 || blank_id >= V) return fail(CTCD_EINVAL, "blank_id must index the vocabulary");
+  if (beam > kMaxBeam) return fail(CTCD_EUNSUPPORTED, "beam_width > 16383");
+  if (V > kMaxVocab) return fail(CTCD_EUNSUPPORTED, "vocabulary > 65534");
+  if ((long long)beam * T + 1 > 0x7fffffffLL) return fail(CTCD_EUNSUPPORTED, "beam_width * T too large");
+  if (B > 0 && T > 0 && (!probs || !tok || !ts)) return fail(CTCD_EINVAL, "null tensor");
+  if (B > 0 && (!sc || !ln)) return fail(CTCD_EINVAL, "null tensor");
+  return CTCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ctcd_last_error(void) { return g_err.c_str(); }
+const char *ctcd_version(void) { return "ctcdecode_amd 0.1 (gfx950)"; }
+
+int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob) {
+  if (beam <= 0 || V <= 0 || cutoff_top_n <= 0) return CTCD_EINVAL;
+  Work w;
+  const size_t n = carve(w, nullptr, make_dims(beam, V, cutoff_top_n, cutoff_prob));
+  return n > 0x7fffffffu ? 0x7fffffff : (int)n;
+}
+
+int ctcd_create(ctcd_decoder **out, int device_id) {
+  if (!out) return fail(CTCD_EINVAL, "out == NULL");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(CTCD_EINVAL, "no such HIP device");
+  ctcd_decoder *d = new ctcd_decoder;
+  d->device = device_id;
+  int v = 0;
+  HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id));
+  d->max_lds = v;
+  *out = d;
+  return CTCD_OK;
+}
+
+void ctcd_destroy(ctcd_decoder *d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
+  d->pool.release(); d->status.release(); d->tables.release(); d->logp.release(); d->flags.release();
+  d->stage_in.release(); d->stage_out.release();
+  delete d;
+}
+
+int ctcd_set_threads(ctcd_decoder *d, int t) {
+  if (!d || t < 64 || t > 1024 || (t & 63)) return fail(CTCD_EINVAL, "threads must be a multiple of 64 in [64, 1024]");
+  d->threads = t;
+  return CTCD_OK;
+}
+
+int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                     int /*num_processes*/, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                     int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, out_tok, out_ts, out_sc, out_len);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(d->mu);
+  hipStream_t stream = (hipStream_t)stream_;
+  HIP_TRY(hipSetDevice(d->device));
+  if (B == 0) return CTCD_OK;
+  const Dims dims = make_dims(beam, V, cutoff_top_n, cutoff_prob);
+  if (dims.use_rank_table)
+    return fail(CTCD_EUNSUPPORTED, "vocabulary pruning (cutoff_top_n < V or cutoff_prob < 1) is not built yet");
+  Work wtmp;
+  const size_t lds = carve(wtmp, nullptr, dims);
+  if (lds + 1024 > (size_t)d->max_lds)
+    return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) needs " + std::to_string(lds) + " B of LDS, more than one workgroup has");
+
+  // outputs: everything outside the valid region is defined as 0
+  const size_t kt = (size_t)B * beam * T;
+  if (kt) {
+    HIP_TRY(hipMemsetAsync(out_tok, 0, kt * 4, stream));
+    HIP_TRY(hipMemsetAsync(out_ts, 0, kt * 4, stream));
+  }
+  HIP_TRY(hipMemsetAsync(out_sc, 0, (size_t)B * beam * 4, stream));
+  HIP_TRY(hipMemsetAsync(out_len, 0, (size_t)B * beam * 4, stream));
+
+  if (!d->tables_ready) {
+    if ((rc = d->tables.ensure(sizeof(ctcmath::Tables)))) return rc;
+    HIP_TRY(hipMemcpy(d->tables.p, ctcmath::host_tables().w, sizeof(ctcmath::Tables), hipMemcpyHostToDevice));
+    d->tables_ready = true;
+  }
+  const long long pool_stride = (long long)beam * T + 1;
+  if ((rc = d->pool.ensure((size_t)B * pool_stride * sizeof(PoolNode)))) return rc;
+  if ((rc = d->status.ensure((size_t)B * 4))) return rc;
+
+  const float *logp = probs;
+  if (!log_input && T > 0) {
+    const size_t n = (size_t)B * T * V;
+    const unsigned cap = 1u << 16;
+    if ((rc = d->logp.ensure(n * 4))) return rc;
+    if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
+    unsigned *n_flag = (unsigned *)d->flags.p;
+    unsigned long long *idx = (unsigned long long *)((char *)d->flags.p + 8);
+    HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(prob_to_log_kernel, dim3(blocks), dim3(256), 0, stream, probs, (float *)d->logp.p, n, n_flag, idx, cap);
+    HIP_TRY(hipGetLastError());
+    unsigned nf = 0;
+    HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (nf > cap) return fail(CTCD_EINTERNAL, "too many non-finite / borderline probabilities");
+    if (nf) {  // borderline roundings: recompute with the C library the reference binds to
+      std::vector<unsigned long long> hi(nf);
+      HIP_TRY(hipMemcpy(hi.data(), idx, (size_t)nf * 8, hipMemcpyDeviceToHost));
+      for (unsigned k = 0; k < nf; ++k) {
+        float p, v;
+        HIP_TRY(hipMemcpy(&p, probs + hi[k], 4, hipMemcpyDeviceToHost));
+        v = (float)std::log((double)p + (double)FLT_MIN);
+        HIP_TRY(hipMemcpy((float *)d->logp.p + hi[k], &v, 4, hipMemcpyHostToDevice));
+      }
+    }
+    logp = (const float *)d->logp.p;
+  }
+
+  KernelArgs a;
+  a.probs = logp; a.seq_lens = seq_lens; a.B = B; a.T = T; a.V = V; a.K = beam; a.blank = blank_id; a.dims = dims;
+  a.pool = (PoolNode *)d->pool.p; a.pool_stride = pool_stride; a.tables = (const uint64_t *)d->tables.p;
+  a.out_tok = out_tok; a.out_ts = out_ts; a.out_len = out_len; a.n_results = n_results; a.out_score = out_sc;
+  a.status = (int32_t *)d->status.p;
+  HIP_TRY(hipFuncSetAttribute((const void *)ctc_beam_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
+  hipLaunchKernelGGL(ctc_beam_decode_kernel, dim3(B), dim3(d->threads), lds, stream, a);
+  HIP_TRY(hipGetLastError());
+  if (d->timing) HIP_TRY(hipEventRecord(d->ev1, stream));
+  return CTCD_OK;
+}
+
+int ctcd_beam_decode_host(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                          int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                          int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, out_tok, out_ts, out_sc, out_len);
+  if (rc) return rc;
+  if (B == 0) return CTCD_OK;
+  HIP_TRY(hipSetDevice(d->device));
+  const size_t nin = (size_t)B * T * V * 4, kt = (size_t)B * beam * T * 4, kk = (size_t)B * beam * 4;
+  const size_t off_sl = (nin + 15) / 16 * 16;
+  if ((rc = d->stage_in.ensure(off_sl + (size_t)B * 4 + 16))) return rc;
+  const size_t o_ts = (kt + 15) / 16 * 16, o_sc = o_ts * 2, o_ln = o_sc + (kk + 15) / 16 * 16, o_nr = o_ln + (kk + 15) / 16 * 16;
+  if ((rc = d->stage_out.ensure(o_nr + (size_t)B * 4 + 16))) return rc;
+  char *din = (char *)d->stage_in.p, *dout = (char *)d->stage_out.p;
+  if (nin) HIP_TRY(hipMemcpy(din, probs, nin, hipMemcpyHostToDevice));
+  if (seq_lens) HIP_TRY(hipMemcpy(din + off_sl, seq_lens, (size_t)B * 4, hipMemcpyHostToDevice));
+  rc = ctcd_beam_decode(d, (const float *)din, seq_lens ? (const int32_t *)(din + off_sl) : nullptr, B, T, V, beam, num_processes,
+                        cutoff_prob, cutoff_top_n, blank_id, log_input, (int32_t *)dout, (int32_t *)(dout + o_ts),
+                        (float *)(dout + o_sc), (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<int32_t> st(B);
+  HIP_TRY(hipMemcpy(st.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; ++b)
+    if (st[b] != ST_OK) return fail(CTCD_EINTERNAL, "decoder status " + std::to_string(st[b]) + " for item " + std::to_string(b));
+  if (kt) {
+    HIP_TRY(hipMemcpy(out_tok, dout, kt, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_ts, dout + o_ts, kt, hipMemcpyDeviceToHost));
+  }
+  HIP_TRY(hipMemcpy(out_sc, dout + o_sc, kk, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_len, dout + o_ln, kk, hipMemcpyDeviceToHost));
+  if (n_results) HIP_TRY(hipMemcpy(n_results, dout + o_nr, (size_t)B * 4, hipMemcpyDeviceToHost));
+  return CTCD_OK;
+}
+
+// HIP-event timing of the decode kernel alone, on the stream it is launched on (bench.py's roofline figure).
+int ctcd_set_timing(ctcd_decoder *d, int on) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  HIP_TRY(hipSetDevice(d->device));
+  if (on && !d->ev0) {
+    HIP_TRY(hipEventCreate(&d->ev0));
+    HIP_TRY(hipEventCreate(&d->ev1));
+  }
+  d->timing = on != 0;
+  return CTCD_OK;
+}
+
+int ctcd_last_kernel_ms(ctcd_decoder *d, float *ms) {
+  if (!d || !ms || !d->ev0) return fail(CTCD_EINVAL, "timing not enabled");
+  HIP_TRY(hipEventSynchronize(d->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, d->ev0, d->ev1));
+  return CTCD_OK;
+}
+
+// Device expf/logf/log_sum_exp against the host C library over a range of float bit patterns (tests only):
+// mode 0: expf_nonpos(x), 1: logf_normal(x), x = bits lo, lo+stride, ... <= hi;  mode 2: lse(x, y) on n pairs.
+int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,
+                          const float *ys, long long n_pairs, long long *checked, long long *mismatches);
+
+// Status words of the last ctcd_beam_decode on this decoder (device -> host); for callers of the async entry point.
+int ctcd_check_status(ctcd_decoder *d, int B) {
+  if (!d || B < 0) return fail(CTCD_EINVAL, "bad arguments");
+  if (B == 0) return CTCD_OK;
+  HIP_TRY(hipSetDevice(d->device));
+  std::vector<int32_t> st(B);
+  HIP_TRY(hipMemcpy(st.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; ++b)
+    if (st[b] != ST_OK) return fail(CTCD_EINTERNAL, "decoder status " + std::to_string(st[b]) + " for item " + std::to_string(b));
+  return CTCD_OK;
+}
+
+int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,
+                          const float *ys, long long n_pairs, long long *checked, long long *mismatches) {
+  if (!d || !checked || !mismatches || stride == 0) return fail(CTCD_EINVAL, "bad arguments");
+  HIP_TRY(hipSetDevice(d->device));
+  int rc;
+  if (!d->tables_ready) {
+    if ((rc = d->tables.ensure(sizeof(ctcmath::Tables)))) return rc;
+    HIP_TRY(hipMemcpy(d->tables.p, ctcmath::host_tables().w, sizeof(ctcmath::Tables), hipMemcpyHostToDevice));
+    d->tables_ready = true;
+  }
+  *checked = 0;
+  *mismatches = 0;
+  const size_t chunk = (size_t)1 << 24;
+  Buf out, inx, iny;
+  if ((rc = out.ensure(chunk * 4))) return rc;
+  std::vector<float> host(chunk);
+  auto ref_lse = [](float x, float y) {  // decoder_utils.h:47-54
+    const float neg = -FLT_MAX;
+    if (x <= neg) return y;
+    if (y <= neg) return x;
+    const float m = x > y ? x : y;
+    return std::log(std::exp(x - m) + std::exp(y - m)) + m;
+  };
+  if (mode == 0 || mode == 1) {
+    for (uint64_t start = lo; start <= hi; start += (uint64_t)chunk * stride) {
+      const uint64_t cnt64 = ((uint64_t)hi - start) / stride + 1;
+      const size_t cnt = (size_t)std::min<uint64_t>(cnt64, chunk);
+      hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, mode, (uint32_t)start, stride,
+                         (const float *)nullptr, (const float *)nullptr, (float *)out.p, cnt, (const uint64_t *)d->tables.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpy(host.data(), out.p, cnt * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < cnt; ++i) {
+        const float x = ctcmath::bits_to_f32((uint32_t)(start + i * stride));
+        const float want = mode == 0 ? std::exp(x) : std::log(x);
+        const bool same = ctcmath::f32_to_bits(want) == ctcmath::f32_to_bits(host[i]);
+        // below -88 the restatement returns 0 where libm returns < 2^-126: indistinguishable inside log_sum_exp
+        if (!same && !(mode == 0 && x < -88.0f && host[i] == 0.0f && 1.0f + want == 1.0f)) ++*mismatches;
+      }
+      *checked += (long long)cnt;
+    }
+  } else {
+    if (!xs || !ys || n_pairs < 0) return fail(CTCD_EINVAL, "pairs missing");
+    if ((rc = inx.ensure(chunk * 4)) || (rc = iny.ensure(chunk * 4))) return rc;
+    for (long long off = 0; off < n_pairs; off += (long long)chunk) {
+      const size_t cnt = (size_t)std::min<long long>((long long)chunk, n_pairs - off);
+      HIP_TRY(hipMemcpy(inx.p, xs + off, cnt * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(iny.p, ys + off, cnt * 4, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, 2, 0u, 1u, (const float *)inx.p,
+                         (const float *)iny.p, (float *)out.p, cnt, (const uint64_t *)d->tables.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpy(host.data(), out.p, cnt * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < cnt; ++i)
+        if (ctcmath::f32_to_bits(ref_lse(xs[off + i], ys[off + i])) != ctcmath::f32_to_bits(host[i])) ++*mismatches;
+      *checked += (long long)cnt;
+    }
+    inx.release();
+    iny.release();
+  }
+  out.release();
+  return CTCD_OK;
+}
+
+}  // extern "C"

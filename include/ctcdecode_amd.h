@@ -1,0 +1,82 @@
+/* ctcdecode_amd.h -- C ABI of the MI355X-native CTC prefix beam-search decoder.
+ *
+ * Drop-in boundary for the ONE hot path of parlance/ctcdecode: CTCBeamDecoder.decode() without a language model.
+ * Each entry point names the reference interface it replaces (paths relative to the reference checkout):
+ *
+ *   ctcd_beam_decode        <- ctcdecode/src/binding.cpp:103-120  paddle_beam_decode()  (pybind11: binding.cpp:291)
+ *                              = binding.cpp:35-101 beam_decode() -> ctc_beam_search_decoder_batch()
+ *                                (ctcdecode/src/ctc_beam_search_decoder.cpp:245-285) with ext_scorer == nullptr
+ *   ctcd_beam_decode_host   <- the same call as the reference makes it: CPU tensors in, CPU tensors out
+ *                              (ctcdecode/__init__.py:77-123 moves probs to the CPU first; here they are staged to HBM)
+ *   ctcd_create / destroy   <- no reference counterpart (the reference allocates per call); caches HBM scratch
+ *   ctcd_last_error         <- replaces LOG(FATAL)/abort (ctcdecode/src/decoder_utils.h:17-29) by error codes
+ *
+ * Plain pointers and sizes only; no torch / HIP types.  `stream` is a hipStream_t passed as void* (NULL = default).
+ * All functions return CTCD_OK (0) or a negative CTCD_E* code; ctcd_last_error() describes the last failure of the
+ * calling thread.
+ *
+ * Tensor layouts (row-major, identical to the reference's tensors, ctcdecode/__init__.py:83-86):
+ *   probs        float32 [B, T, V]   log-probabilities if log_input != 0, probabilities otherwise
+ *   seq_lens     int32   [B] or NULL (all T); each clamped to [0, T]         (binding.cpp:64-65)
+ *   out_tokens   int32   [B, beam, T] label ids   of beam p of item b at [b][p][0 .. out_lens[b][p])
+ *   out_timesteps int32  [B, beam, T] frame index at which each label's probability peaked (path_trie.cpp:42-45)
+ *   out_scores   float32 [B, beam]   negative log-likelihood, ascending = best first (decoder_utils.cpp:68)
+ *   out_lens     int32   [B, beam]
+ *   n_results    int32   [B] or NULL: number of beams actually returned for item b (min(beam, #prefixes))
+ * Everything the reference leaves uninitialised (rows p >= n_results, positions >= out_lens) is written as 0.
+ */
+#ifndef CTCDECODE_AMD_H_
+#define CTCDECODE_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTCD_OK 0
+#define CTCD_EINVAL (-1)      /* bad argument (sizes, blank_id, NULL pointers, ...) */
+#define CTCD_EUNSUPPORTED (-2) /* configuration outside what this build implements (see ctcd_last_error) */
+#define CTCD_EHIP (-3)        /* HIP runtime error */
+#define CTCD_EINTERNAL (-4)   /* decoder status word reported a failure */
+
+typedef struct ctcd_decoder ctcd_decoder;
+
+/* Create a decoder bound to HIP device `device_id`.  Owns only scratch (node pools, pruned candidate lists). */
+int ctcd_create(ctcd_decoder **out, int device_id);
+void ctcd_destroy(ctcd_decoder *dec);
+
+/* Decode a batch whose tensors all live in the HBM of the decoder's device.  Asynchronous on `stream` unless
+ * log_input == 0 or n_results/status need host inspection; call hipStreamSynchronize before reading. */
+int ctcd_beam_decode(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                     int num_processes /* accepted for signature parity; unused on the GPU */, double cutoff_prob,
+                     int cutoff_top_n, int blank_id, int log_input, int32_t *out_tokens, int32_t *out_timesteps,
+                     float *out_scores, int32_t *out_lens, int32_t *n_results, void *stream);
+
+/* Same, with HOST pointers for every tensor (what paddle_beam_decode receives).  Synchronous. */
+int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                          int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                          int32_t *out_tokens, int32_t *out_timesteps, float *out_scores, int32_t *out_lens,
+                          int32_t *n_results);
+
+/* Host check of the per-item status words written by the last ctcd_beam_decode (synchronises the device). */
+int ctcd_check_status(ctcd_decoder *dec, int B);
+
+/* HIP-event timing of the decode kernel alone (events recorded on the launch stream). */
+int ctcd_set_timing(ctcd_decoder *dec, int on);
+int ctcd_last_kernel_ms(ctcd_decoder *dec, float *ms);
+
+/* Test hook: device expf/logf/log_sum_exp (exact_math.h) vs the host C library over float bit patterns. */
+int ctcd_debug_math_check(ctcd_decoder *dec, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,
+                          const float *ys, long long n_pairs, long long *checked, long long *mismatches);
+
+/* Tuning / introspection. */
+int ctcd_set_threads(ctcd_decoder *dec, int threads_per_workgroup); /* 64..1024, multiple of 64 */
+int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob); /* LDS one utterance needs */
+const char *ctcd_last_error(void);
+const char *ctcd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTCDECODE_AMD_H_ */

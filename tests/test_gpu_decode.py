@@ -1,0 +1,175 @@
+"""-m gpu parity tests proper: the HIP path, called through the product API / C ABI, against the oracle and the
+committed reference fixtures.  Integer tensors and scores are compared BIT-EXACT on the region the reference defines."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_util as ou
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return torch
+
+
+def _decode(torch, probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, log_input=True, threads=None,
+            host_entry=False):
+    import ctcdecode_amd
+
+    V = probs.shape[2]
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=cutoff_top_n, cutoff_prob=cutoff_prob,
+                                       beam_width=beam, blank_id=blank_id, log_probs_input=log_input, device="cuda:0")
+    if threads:
+        dec.set_threads(threads)
+    try:
+        out, sc, ts, ln = dec.decode(torch.from_numpy(np.ascontiguousarray(probs)),
+                                     torch.from_numpy(seq_lens) if seq_lens is not None else None)
+    except NotImplementedError as e:
+        pytest.skip(str(e))
+    return dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+
+
+def _with_nres(got, want):
+    got = dict(got)
+    got["nres"] = want["nres"]
+    # rows the reference does not define must be zero in our output
+    for b in range(got["lens"].shape[0]):
+        n = int(want["nres"][b])
+        assert not got["lens"][b, n:].any() and not got["scores"][b, n:].any() and not got["tokens"][b, n:].any()
+    return got
+
+
+def test_library_is_the_hip_build(torch_mod):
+    import ctcdecode_amd._native as n
+
+    assert b"gfx950" in n.lib.ctcd_version()
+    maps = open("/proc/self/maps").read()
+    assert "libctcdecode_amd.so" in maps
+
+
+@pytest.mark.parametrize("name", gu.names())
+def test_reference_fixtures(torch_mod, name):
+    args, want = gu.load(name)
+    got = _decode(torch_mod, **args)
+    ou.assert_same(_with_nres(got, want), want, name)
+
+
+def test_reference_golden_strings(torch_mod):
+    """tests/test_decode.py:37-53,66-91 of the reference, through the drop-in class."""
+    import ctcdecode_amd
+
+    vocab = ["'", " ", "a", "b", "c", "d", "_"]
+    args, _ = gu.load("ref_fixtures_prob")
+    dec = ctcdecode_amd.CTCBeamDecoder(vocab, beam_width=20, blank_id=vocab.index("_"))
+    out, sc, ts, ln = dec.decode(torch_mod.from_numpy(args["probs"]))
+    strings = ["".join(vocab[x] for x in out[b][0][: ln[b][0]]) for b in range(2)]
+    assert strings == ["acdc", "b'a"]
+    dec = ctcdecode_amd.CTCBeamDecoder(vocab, beam_width=20, blank_id=vocab.index("_"), log_probs_input=True, num_processes=24)
+    out, sc, ts, ln = dec.decode(torch_mod.from_numpy(args["probs"]).log())
+    strings = ["".join(vocab[x] for x in out[b][0][: ln[b][0]]) for b in range(2)]
+    assert strings == ["acdc", "b'a"]
+    assert out.dtype == torch_mod.int32 and sc.dtype == torch_mod.float32 and tuple(sc.shape) == (2, 20) and tuple(ts.shape) == (2, 20, 6)
+
+
+CASES = [
+    dict(B=4, T=100, V=29, K=10, seed=31),
+    dict(B=3, T=250, V=29, K=64, seed=32),
+    dict(B=3, T=200, V=29, K=50, seed=33, quant=0.5),
+    dict(B=2, T=150, V=5, K=30, seed=34, quant=1.0, blank_id=2),
+    dict(B=2, T=150, V=29, K=20, seed=35, blank_bias=5.0),
+    dict(B=2, T=120, V=3, K=128, seed=36, quant=0.5, blank_id=1),
+    dict(B=2, T=200, V=9, K=100, seed=37, quant=0.25, blank_bias=3.0, blank_id=8),
+    dict(B=1, T=60, V=29, K=1, seed=38),
+    dict(B=5, T=64, V=29, K=16, seed=39, ragged=True),
+]
+
+
+@pytest.mark.parametrize("threads", [64, 256, 1024])
+@pytest.mark.parametrize("c", CASES, ids=lambda c: "B%(B)d_T%(T)d_V%(V)d_K%(K)d_s%(seed)d" % c)
+def test_randomized_against_oracle(torch_mod, c, threads):
+    blank = c.get("blank_id", 0)
+    lp = ou.synth_logprobs(c["B"], c["T"], c["V"], c["seed"], quant=c.get("quant"), blank_bias=c.get("blank_bias", 0.0), blank_id=blank)
+    sl = np.array([c["T"], 0, 1, c["T"] // 2, c["T"] + 9][: c["B"]], np.int32) if c.get("ragged") else None
+    want = ou.decode(lp, sl, beam=c["K"], blank_id=blank, which="restated")
+    got = _decode(torch_mod, lp, sl, beam=c["K"], blank_id=blank, threads=threads)
+    ou.assert_same(_with_nres(got, want), want)
+
+
+def test_north_star_shape_parity_and_properties(torch_mod):
+    """BASELINE.json configs[1]: B=256, T=1000, V=29, beam=100.  Bit-exact against the oracle on a sample of the items
+    (the CPU needs ~1 s per item), size-independent properties on all of them, and run-to-run determinism."""
+    B, T, V, K = 256, 1000, 29, 100
+    lp = ou.synth_logprobs(B, T, V, 2024)
+    got = _decode(torch_mod, lp, beam=K)
+    again = _decode(torch_mod, lp, beam=K)
+    for k in got:
+        assert np.array_equal(got[k], again[k]), "non-deterministic " + k
+    sample = [0, 1, 17, 100, 128, 200, 254, 255]
+    want = ou.decode(lp[sample], beam=K, which="restated")
+    sub = {k: v[sample] for k, v in got.items()}
+    ou.assert_same(_with_nres(sub, want), want, "north-star sample")
+    lens, sc, tok, ts = got["lens"], got["scores"], got["tokens"], got["timesteps"]
+    assert (np.diff(sc, axis=1) >= 0).all(), "beam_scores must ascend (best first)"
+    assert (lens >= 0).all() and (lens <= T).all()
+    pos = np.arange(T)[None, None, :]
+    valid = pos < lens[:, :, None]
+    assert (tok[valid] > 0).all() and (tok[valid] < V).all(), "labels are non-blank vocabulary ids"
+    assert (tok[~valid] == 0).all() and (ts[~valid] == 0).all(), "outside the valid region everything is zero"
+    assert (ts[valid] >= 0).all() and (ts[valid] < T).all()
+    # beams of one item are pairwise distinct prefixes
+    for b in range(0, B, 16):
+        seen = {tuple(tok[b, p, : lens[b, p]]) for p in range(K)}
+        assert len(seen) == K
+
+
+def test_empty_and_degenerate_batches(torch_mod):
+    import ctcdecode_amd
+
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(5)], beam_width=4, log_probs_input=True)
+    out, sc, ts, ln = dec.decode(torch_mod.zeros((0, 7, 5)))
+    assert tuple(out.shape) == (0, 4, 7)
+    out, sc, ts, ln = dec.decode(torch_mod.zeros((2, 0, 5)))
+    assert tuple(out.shape) == (2, 4, 0) and (ln == 0).all()
+    with pytest.raises(ValueError):
+        dec.decode(torch_mod.zeros((1, 3, 6)))
+    with pytest.raises(ValueError):
+        ctcdecode_amd.CTCBeamDecoder(["a", "b"], blank_id=5, log_probs_input=True).decode(torch_mod.zeros((1, 3, 2)))
+    with pytest.raises(NotImplementedError):
+        ctcdecode_amd.CTCBeamDecoder(["a", "b"], model_path="lm.arpa")
+
+
+def test_device_math_bit_exact_vs_host_libm(torch_mod):
+    """exact_math.h on the GPU against the GPU box's own glibc expf/logf (what the reference's log_sum_exp calls)."""
+    import ctypes
+
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    dec = ctcdecode_amd.CTCBeamDecoder(["a", "b"], log_probs_input=True)
+    chk, bad = ctypes.c_longlong(), ctypes.c_longlong()
+    # logf on every float in [1, 2]
+    n.check(n.lib.ctcd_debug_math_check(dec._handle, 1, 0x3F800000, 0x40000000, 1, None, None, 0, ctypes.byref(chk), ctypes.byref(bad)))
+    assert chk.value == 0x40000000 - 0x3F800000 + 1 and bad.value == 0, (chk.value, bad.value)
+    # expf on [-88, -0], every 7th float, plus the far tail
+    n.check(n.lib.ctcd_debug_math_check(dec._handle, 0, 0x80000000, 0xC2B00000, 7, None, None, 0, ctypes.byref(chk), ctypes.byref(bad)))
+    assert bad.value == 0 and chk.value > 1.5e8
+    n.check(n.lib.ctcd_debug_math_check(dec._handle, 0, 0xC2B00000, 0xFF7FFFFF, 100003, None, None, 0, ctypes.byref(chk), ctypes.byref(bad)))
+    assert bad.value == 0
+    rng = np.random.default_rng(5)
+    N = 1 << 22
+    x = rng.uniform(-4000, 0, N).astype(np.float32)
+    y = (x - rng.uniform(0, 30, N).astype(np.float32) * np.where(rng.integers(0, 3, N) == 0, np.float32(0.05), np.float32(1))).astype(np.float32)
+    y[::7] = x[::7]
+    y[::1013] = -np.finfo(np.float32).max
+    swap = rng.integers(0, 2, N).astype(bool)
+    x, y = np.where(swap, y, x), np.where(swap, x, y)
+    x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
+    n.check(n.lib.ctcd_debug_math_check(dec._handle, 2, 0, 0, 1, x.ctypes.data, y.ctypes.data, N, ctypes.byref(chk), ctypes.byref(bad)))
+    assert chk.value == N and bad.value == 0
