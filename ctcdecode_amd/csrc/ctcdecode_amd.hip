@@ -24,19 +24,143 @@ namespace {
 using namespace ctcbeam;
 
 // ------------------------------------------------------------------------------------------------ device policy
+// Cross-lane data movement uses DPP (row shifts + row broadcasts, a few cycles each) instead of ds_bpermute-based
+// shuffles (~100 cycles each on the critical path): every block primitive below is a wave-level scan.
+#define CTC_DPP(old, v, ctrl, rowmask) __builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rowmask), 0xf, false)
+
+// Inclusive scan over the 64 lanes of a wave; op(left, mine); `ident` is op's left identity.
+template <class Op>
+__device__ __forceinline__ int wave_scan(int v, const int ident, Op op) {
+  v = op(CTC_DPP(ident, v, 0x111, 0xf), v);  // row_shr:1
+  v = op(CTC_DPP(ident, v, 0x112, 0xf), v);  // row_shr:2
+  v = op(CTC_DPP(ident, v, 0x114, 0xf), v);  // row_shr:4
+  v = op(CTC_DPP(ident, v, 0x118, 0xf), v);  // row_shr:8
+  v = op(CTC_DPP(ident, v, 0x142, 0xa), v);  // row_bcast:15 -> rows 1, 3
+  v = op(CTC_DPP(ident, v, 0x143, 0xc), v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+  return __builtin_amdgcn_readlane(wave_scan(v, 0, [](int a, int b) { return a + b; }), 63);
+}
+__device__ __forceinline__ int wave_min(int v) {
+  return __builtin_amdgcn_readlane(wave_scan(v, ctcbeam::kIntMax, [](int a, int b) { return a < b ? a : b; }), 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane(
+      wave_scan((int)v, 0, [](int a, int b) { return (uint32_t)a > (uint32_t)b ? a : b; }), 63);
+}
+
+template <bool PROF>
 struct DevX {
   int *red;  // 2 x 16 ints of LDS
   int parity;
+  int *seg;  // 2 x 80 ints of LDS (seg_scan)
+  int segpar;
+  long long *prof;   // PROF: per-phase cycle accumulators (LDS), written by thread 0
+  long long last;
+  __device__ void mark(int id) {
+    if (PROF && threadIdx.x == 0) {
+      const long long now = (long long)wall_clock64();
+      prof[id] += now - last;
+      last = now;
+    }
+  }
   __device__ int tid() const { return (int)threadIdx.x; }
   __device__ int nt() const { return (int)blockDim.x; }
   __device__ void sync() { __syncthreads(); }
-  __device__ void atomic_min(int *p, int v) { atomicMin(p, v); }
+  __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+  __device__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+  // one LDS atomic per wave
+  __device__ void wave_add(int *p, int v) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
+  }
+
+  // bins[0, 256) complete (caller synced).  Wave 0 finds the bucket holding the need-th largest key; everyone gets
+  // out[0..3] = {bucket or -1, #keys above it, #keys total, #keys in it} after the closing barrier; bins re-zeroed.
+  __device__ void find_bucket(int *bins, int nb, int need, int *out) {
+    if (threadIdx.x < 64) {
+      const int lane = (int)threadIdx.x;
+      const int per = nb >> 6;            // 4 for 256 bins
+      const int base = (63 - lane) * per;  // lane 0 owns the TOP bins: a prefix scan over lanes is a suffix sum over bins
+      int v[4] = {0, 0, 0, 0};
+      int sum = 0;
+      for (int k = 0; k < per; ++k) {
+        v[k] = bins[base + k];
+        bins[base + k] = 0;
+        sum += v[k];
+      }
+      const int incl = wave_scan(sum, 0, [](int a, int b) { return a + b; });
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      const unsigned long long m = __ballot(incl >= need);
+      if (m == 0ull) {
+        if (lane == 0) { out[0] = -1; out[1] = 0; out[2] = total; out[3] = 0; }
+      } else if (lane == __ffsll((long long)m) - 1) {
+        int run = incl - sum;  // keys in bins above this lane's
+        for (int k = per - 1; k >= 0; --k) {
+          if (run + v[k] >= need) { out[0] = base + k; out[1] = run; out[2] = total; out[3] = v[k]; break; }
+          run += v[k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // Fused compaction scan (beam_core.h step E): exclusive counts, the min-LCP carried in from the slots since the last
+  // survivor in the preceding threads' chunks, and workgroup totals / min depth / max key.  One barrier.
+  __device__ void seg_scan(int cnt, int cntc, bool has, int tailmin, int dloc, uint32_t kmax, ctcbeam::SegOut &o) {
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+    int ci = (int)((uint32_t)cnt | ((uint32_t)cntc << 16));
+    int h = has ? 1 : 0, mn = tailmin;
+    // inclusive segmented scan of (count, has-survivor, min since last survivor): combine(left, mine)
+#define CTC_SEG_STEP(ctrl, rowmask)                                \
+    {                                                                \
+      const int co = CTC_DPP(0, ci, ctrl, rowmask);                  \
+      const int ho = CTC_DPP(0, h, ctrl, rowmask);                   \
+      const int mo = CTC_DPP(ctcbeam::kIntMax, mn, ctrl, rowmask);   \
+      ci += co;                                                      \
+      if (!h) { mn = mo < mn ? mo : mn; h = ho; }                    \
+    }
+    CTC_SEG_STEP(0x111, 0xf) CTC_SEG_STEP(0x112, 0xf) CTC_SEG_STEP(0x114, 0xf) CTC_SEG_STEP(0x118, 0xf)
+    CTC_SEG_STEP(0x142, 0xa) CTC_SEG_STEP(0x143, 0xc)
+#undef CTC_SEG_STEP
+    const int dm = wave_min(dloc);
+    const uint32_t km = wave_max_u32(kmax);
+    // exclusive values: shift the whole wave right by one lane (wave_shr:1)
+    const int ce = CTC_DPP(0, ci, 0x138, 0xf);
+    const int he = CTC_DPP(0, h, 0x138, 0xf);
+    const int me = CTC_DPP(ctcbeam::kIntMax, mn, 0x138, 0xf);
+    int *row = seg + segpar * 80;
+    segpar ^= 1;
+    if (lane == 63) {
+      row[wave * 5 + 0] = ci; row[wave * 5 + 1] = h; row[wave * 5 + 2] = mn; row[wave * 5 + 3] = dm; row[wave * 5 + 4] = (int)km;
+    }
+    __syncthreads();
+    uint32_t cb = 0, tot = 0, kmx = 0;
+    int mb = ctcbeam::kIntMax, dmin = ctcbeam::kIntMax;
+    for (int i = 0; i < nw; ++i) {
+      const uint32_t cw = (uint32_t)row[i * 5];
+      const int hw = row[i * 5 + 1], mw = row[i * 5 + 2], dw = row[i * 5 + 3];
+      const uint32_t kw = (uint32_t)row[i * 5 + 4];
+      if (i < wave) {
+        cb += cw;
+        if (hw) mb = mw; else mb = mw < mb ? mw : mb;
+      }
+      tot += cw;
+      dmin = dw < dmin ? dw : dmin;
+      kmx = kw > kmx ? kw : kmx;
+    }
+    const uint32_t ex = cb + (uint32_t)ce;
+    o.excl = (int)(ex & 0xFFFFu); o.exclc = (int)(ex >> 16);
+    o.total = (int)(tot & 0xFFFFu); o.totalc = (int)(tot >> 16);
+    o.carry = he ? me : (mb < me ? mb : me);
+    o.dmin = dmin; o.maxkey = kmx;
+  }
 
   // Sum over the workgroup, same value returned to every thread.  One barrier per call: consecutive calls alternate
   // between two scratch rows, and a row is only rewritten after a later barrier that every reader has passed.
   __device__ int reduce_add(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = wave_sum(v);
     const int wave = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
     int *row = red + parity * 16;
     parity ^= 1;
@@ -50,16 +174,11 @@ struct DevX {
   // In-place exclusive prefix sum of a[0, n) in LDS; returns the total.  Each thread owns a contiguous chunk.
   __device__ uint32_t scan_excl(uint32_t *a, int n) {
     const int nthreads = (int)blockDim.x, t = (int)threadIdx.x;
-    const int chunk = (n + nthreads - 1) / nthreads;
-    const int lo = t * chunk, hi = min(lo + chunk, n);
+    const int chunk = ((n + nthreads - 1) / nthreads) | 1;  // odd stride: no LDS bank conflicts across lanes
+    const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
     uint32_t sum = 0;
     for (int i = lo; i < hi; ++i) sum += a[i];
-    uint32_t incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t o = __shfl_up(incl, off, 64);
-      if ((t & 63) >= off) incl += o;
-    }
+    const uint32_t incl = (uint32_t)wave_scan((int)sum, 0, [](int x, int y) { return x + y; });
     const int wave = t >> 6, nw = (nthreads + 63) >> 6;
     int *row = red + parity * 16;
     parity ^= 1;
@@ -93,8 +212,10 @@ struct KernelArgs {
   int32_t *out_tok, *out_ts, *out_len, *n_results;
   float *out_score;
   int32_t *status;          // [B]
+  long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
 };
 
+template <bool PROF>
 __global__ void ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -103,16 +224,21 @@ __global__ void ctc_beam_decode_kernel(KernelArgs a) {
   if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
   Work w;
   carve(w, smem, a.dims);
-  DevX x{red, 0};
+  __shared__ long long prof[16];
+  if (PROF && threadIdx.x < 16) prof[threadIdx.x] = 0;
+  __shared__ int seg[160];
+  DevX<PROF> x{red, 0, seg, 0, prof, 0};
   int len = a.seq_lens ? a.seq_lens[b] : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();
+  if (PROF) x.last = (long long)wall_clock64();
   const size_t kt = (size_t)a.K * a.T;
   const int st = decode_utterance(x, w, a.dims, a.blank, a.probs + (size_t)b * a.T * a.V, (const PrunedRows *)nullptr, len,
                                   a.pool + (size_t)b * a.pool_stride, (int)a.pool_stride, tbl, a.T,
                                   a.out_tok + (size_t)b * kt, a.out_ts + (size_t)b * kt, a.out_score + (size_t)b * a.K,
                                   a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr);
   if (threadIdx.x == 0) a.status[b] = st;
+  if (PROF && threadIdx.x < 16) a.prof[(size_t)b * 16 + threadIdx.x] = prof[threadIdx.x];
 }
 
 // prob -> log-prob exactly as decoder_utils.cpp:42 : float(log(double(p) + FLT_MIN)).  The device log() is within
@@ -190,6 +316,8 @@ struct ctcd_decoder {
   Buf pool, status, tables, logp, flags, stage_in, stage_out;
   bool tables_ready = false;
   bool timing = false;
+  bool profile = false;
+  Buf prof;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
 };
@@ -250,7 +378,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
-  d->pool.release(); d->status.release(); d->tables.release(); d->logp.release(); d->flags.release();
+  d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release();
   delete d;
 }
@@ -331,9 +459,18 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
   a.pool = (PoolNode *)d->pool.p; a.pool_stride = pool_stride; a.tables = (const uint64_t *)d->tables.p;
   a.out_tok = out_tok; a.out_ts = out_ts; a.out_len = out_len; a.n_results = n_results; a.out_score = out_sc;
   a.status = (int32_t *)d->status.p;
-  HIP_TRY(hipFuncSetAttribute((const void *)ctc_beam_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  a.prof = nullptr;
+  if (d->profile) {
+    if ((rc = d->prof.ensure((size_t)B * 16 * 8))) return rc;
+    a.prof = (long long *)d->prof.p;
+  }
+  const void *fn = d->profile ? (const void *)ctc_beam_decode_kernel<true> : (const void *)ctc_beam_decode_kernel<false>;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
-  hipLaunchKernelGGL(ctc_beam_decode_kernel, dim3(B), dim3(d->threads), lds, stream, a);
+  if (d->profile)
+    hipLaunchKernelGGL(ctc_beam_decode_kernel<true>, dim3(B), dim3(d->threads), lds, stream, a);
+  else
+    hipLaunchKernelGGL(ctc_beam_decode_kernel<false>, dim3(B), dim3(d->threads), lds, stream, a);
   HIP_TRY(hipGetLastError());
   if (d->timing) HIP_TRY(hipEventRecord(d->ev1, stream));
   return CTCD_OK;
@@ -390,6 +527,22 @@ int ctcd_last_kernel_ms(ctcd_decoder *d, float *ms) {
   if (!d || !ms || !d->ev0) return fail(CTCD_EINVAL, "timing not enabled");
   HIP_TRY(hipEventSynchronize(d->ev1));
   HIP_TRY(hipEventElapsedTime(ms, d->ev0, d->ev1));
+  return CTCD_OK;
+}
+
+// Phase profile (tools/phase_profile.py): run the instrumented build of the kernel and read its per-utterance timers
+// (wall_clock64 ticks of a 100 MHz clock, accumulated per phase by thread 0 of each workgroup).
+int ctcd_debug_set_profile(ctcd_decoder *d, int on) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  d->profile = on != 0;
+  return CTCD_OK;
+}
+
+int ctcd_debug_get_profile(ctcd_decoder *d, long long *out, int B) {
+  if (!d || !out || B <= 0 || !d->prof.p) return fail(CTCD_EINVAL, "no profile recorded");
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d->prof.p, (size_t)B * 16 * 8, hipMemcpyDeviceToHost));
   return CTCD_OK;
 }
 

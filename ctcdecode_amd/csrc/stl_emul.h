@@ -170,11 +170,11 @@ STLEMU_HD void insertion_sort(T *v, int first, int last, C before) {
   }
 }
 
-// == std::nth_element(v+first, v+nth, v+last, before)
+// The introselect loop of std::nth_element, resumable: `depth` is the remaining partition budget
+// (2*floor_lg(n) at the start).  beam_core.h runs the first, large partitions workgroup-parallel and hands the
+// remainder to this serial form.
 template <class T, class C>
-STLEMU_HD void nth_element(T *v, int first, int nth, int last, C before) {
-  if (first == last || nth == last) return;
-  int depth = 2 * floor_lg(last - first);
+STLEMU_HD void introselect(T *v, int first, int nth, int last, int depth, C before) {
   while (last - first > 3) {
     if (depth == 0) {
       heap_select(v, first, nth + 1, last, before);
@@ -189,6 +189,13 @@ STLEMU_HD void nth_element(T *v, int first, int nth, int last, C before) {
       last = cut;
   }
   insertion_sort(v, first, last, before);
+}
+
+// == std::nth_element(v+first, v+nth, v+last, before)
+template <class T, class C>
+STLEMU_HD void nth_element(T *v, int first, int nth, int last, C before) {
+  if (first == last || nth == last) return;
+  introselect(v, first, nth, last, 2 * floor_lg(last - first), before);
 }
 
 // == std::sort(v+first, v+last, before).  `stack` needs 3 * (2*floor_lg(n) + 2) ints.

@@ -70,6 +70,10 @@ int ctcd_last_kernel_ms(ctcd_decoder *dec, float *ms);
 int ctcd_debug_math_check(ctcd_decoder *dec, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,
                           const float *ys, long long n_pairs, long long *checked, long long *mismatches);
 
+/* Test/tuning hook: instrumented build of the kernel; out = int64 [B][16] per-phase timer ticks. */
+int ctcd_debug_set_profile(ctcd_decoder *dec, int on);
+int ctcd_debug_get_profile(ctcd_decoder *dec, long long *out, int B);
+
 /* Tuning / introspection. */
 int ctcd_set_threads(ctcd_decoder *dec, int threads_per_workgroup); /* 64..1024, multiple of 64 */
 int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob); /* LDS one utterance needs */
