@@ -21,8 +21,9 @@
 //     EQUAL keys -- structural at long T, SURVEY.md 7.3-H2 -- or on the last step (whose permutation feeds the final
 //     sorts), the workgroup replays libstdc++'s std::nth_element on the DFS-ordered candidate list (Hoare partitions
 //     done in parallel, the small tail by one lane with stl_emul.h), so the same prefixes survive as in the
-//     reference.  Survivors are compacted in slot order by one fused scan that also produces the new LCP array,
-//     which keeps the DFS-order invariant.
+//     reference.  The <= K survivors are gathered, ranked by slot index (= DFS order) and emitted one per thread;
+//     the new LCP array comes from range-minima over the old one (the LCA depth of two candidates is determined by
+//     their parents' entries), which keeps the DFS-order invariant without ever scanning the dropped candidates.
 //   * Trie nodes that survive a step are appended to a per-utterance pool in HBM {parent, char, timestep,
 //     log_prob_c}; nothing transient is ever materialised (the reference news/deletes ~2.8k nodes per step).
 //     The pool is read back only for (rare) dead-interior lookups and for the final back-trace.
@@ -87,36 +88,28 @@ struct Dims {
 
 enum {
   VAR_N = 0, VAR_POOL, VAR_DMIN, VAR_STATUS, VAR_MAXKEY, VAR_WLOG,          // persistent across steps
-  VAR_VALID, VAR_LCOUNT, VAR_FB0, VAR_FB1, VAR_FB2, VAR_FB3, VAR_CUT,      // scratch within a step
-  VAR_TAU_LO, VAR_TAU_HI, VAR_G, VAR_E, VAR_COUNT = 24
+  VAR_NPIN, VAR_LCOUNT, VAR_FB0, VAR_FB1, VAR_FB2, VAR_FB3, VAR_CUT,       // scratch within a step
+  VAR_TAU, VAR_TAUC, VAR_G, VAR_E, VAR_SCOUNT, VAR_NDMIN, VAR_NMAXKEY, VAR_COUNT = 24
 };
-constexpr int kBins = 256;      // histogram buckets of the select
+constexpr int kBins = 1024;     // histogram buckets of the select
+constexpr int kBinsLog = 10;
 constexpr int kListCap = 128;   // exact-rank list (one bucket's keys)
 constexpr int kSerialCut = 96;  // introselect ranges at most this long are finished by one lane
-
-// What the fused compaction scan returns to every thread (see X::seg_scan).
-struct SegOut {
-  int excl, exclc;    // survivors / surviving new children in the chunks before this thread's
-  int total, totalc;  // workgroup totals
-  int carry;          // min LCP value since the last survivor before this thread's chunk
-  int dmin;           // min depth over all survivors
-  uint32_t maxkey;    // max score key over all survivors
-};
 
 struct Work {
   Beam cur, nxt;
   int *e, *anc, *ostart, *cstart, *hasvia, *pinr, *revr;  // per beam entry, this step
   uint32_t *hit;   // 2 words per entry: ranks (non-blank numbering) of the children that already exist
-  float *b_new, *nb_new, *sc_new;
+  float *b_new, *nb_new, *sc_new, *rev_lpc;
   int *cch;        // candidate characters of this step (unused in identity mode)
   float *clp;      // their log-probs
   int *rank_of;    // V entries, -1 = not a candidate (only when Dims::use_rank_table)
   uint32_t *skey, *sinfo, *pos;  // S_max (+1 for pos): score key, info word, scratch
-  int *slcp;       // S_max: LCP depth of the slot with its predecessor slot
+  int *surv;       // 3K: slots of the survivors | their rank in slot (= DFS) order | inverse of that ranking
   uint64_t *ek;    // S_max: (key48 << 16 | slot) in DFS order, for the exact replay
   uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition
   int *bins;       // kBins
-  uint64_t *list;  // kListCap
+  uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
   int *fin, *sstack;
   int *vars;
 };
@@ -144,14 +137,14 @@ CTC_HD size_t carve(Work &w, char *base, const Dims &d) {
   w.e = carve_ptr<int>(p, K); w.anc = carve_ptr<int>(p, K); w.ostart = carve_ptr<int>(p, K);
   w.cstart = carve_ptr<int>(p, K); w.hasvia = carve_ptr<int>(p, K); w.pinr = carve_ptr<int>(p, K);
   w.revr = carve_ptr<int>(p, K); w.hit = carve_ptr<uint32_t>(p, 2 * K);
-  w.b_new = carve_ptr<float>(p, K); w.nb_new = carve_ptr<float>(p, K); w.sc_new = carve_ptr<float>(p, K);
+  w.b_new = carve_ptr<float>(p, K); w.nb_new = carve_ptr<float>(p, K); w.sc_new = carve_ptr<float>(p, K); w.rev_lpc = carve_ptr<float>(p, K);
   w.cch = carve_ptr<int>(p, (size_t)d.Vc_max);
   w.clp = carve_ptr<float>(p, (size_t)d.Vc_max);
   w.rank_of = carve_ptr<int>(p, d.use_rank_table ? (size_t)d.V : 0);
   w.skey = carve_ptr<uint32_t>(p, S); w.sinfo = carve_ptr<uint32_t>(p, S);
-  w.pos = carve_ptr<uint32_t>(p, S + 2); w.slcp = carve_ptr<int>(p, S);
+  w.pos = carve_ptr<uint32_t>(p, S + 2); w.surv = carve_ptr<int>(p, 3 * K + 4);
   w.ek = carve_ptr<uint64_t>(p, S); w.lr = carve_ptr<uint16_t>(p, 2 * S + 2);
-  w.bins = carve_ptr<int>(p, kBins); w.list = carve_ptr<uint64_t>(p, kListCap);
+  w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
   w.fin = carve_ptr<int>(p, K);
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
@@ -164,6 +157,10 @@ struct StepIn {
   int blank_rank;  // rank of the blank among the candidates, -1 if it was pruned away
   int identity;    // 1: candidate r is character r (no pruning)
 };
+
+// histogram bins are stored with one pad word per 16 so that the 64 lanes of find_bucket (16 consecutive bins each)
+// hit distinct LDS banks
+CTC_HD int bin_index(int b) { return b + (b >> 4); }
 
 CTC_HD int ceil_log2_u64(uint64_t v) {  // smallest s with (1 << s) >= v, v >= 1
   int s = 0;
@@ -220,43 +217,36 @@ struct Decoder {
   CTC_HD uint64_t slot_key48(int s) const { return key48(w.skey[s], w.sinfo[s]); }
 
   // ------------------------------------------------------------------------------------------------------ select
-  // K-th largest 48-bit key among the S slots (holes have key 0).  Leaves tau (VAR_TAU_*), G = #keys > tau,
-  // E = #keys == tau and VAR_VALID = #candidates in vars.  Precondition: bins[] and VAR_VALID/VAR_LCOUNT zeroed.
+  // K-th largest SCORE key (32 bit) among the S slots (holes have key 0): histogram over a window below the previous
+  // best key, then an exact rank inside the one bucket that holds it.  Leaves tau (VAR_TAU), G = #keys > tau and
+  // E = #keys == tau in vars.  Precondition: bins[] zeroed, VAR_LCOUNT == 0.
   CTC_HD void select_kth(int S, int K) {
     const int tid = x.tid(), nt = x.nt();
-    // first window: [maxkey - 2^wlog, +inf) in score-key units, 256 buckets
     const uint32_t maxkey = (uint32_t)w.vars[VAR_MAXKEY];
     const int wlog = w.vars[VAR_WLOG];
-    uint64_t lo, hi = (uint64_t)1 << 48;
-    if (wlog >= 32 || ((uint64_t)1 << wlog) > (uint64_t)maxkey) lo = 1;
-    else lo = ((uint64_t)maxkey - ((uint64_t)1 << wlog) + 1) << 16;
-    if (lo < 1) lo = 1;
+    uint64_t lo = 1, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
+    if (wlog < 32 && ((uint64_t)1 << wlog) <= (uint64_t)maxkey) lo = (uint64_t)maxkey - ((uint64_t)1 << wlog) + 1;
     int need = K, gbase = 0;
     bool first = true;
     for (;;) {
       uint64_t width = hi - lo;
-      if (first && wlog < 32) width = (uint64_t)1 << (wlog + 16);  // buckets sized for the window, top bucket open-ended
-      const int shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - 8;
-      int valid = 0;
+      if (first && wlog < 32) width = (uint64_t)1 << wlog;  // buckets sized for the window; the top bucket is open-ended
+      const int shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
+      const uint32_t lo32 = (uint32_t)lo, span = (uint32_t)(hi - lo - 1);  // key in range <=> key - lo32 <= span
       for (int s = tid; s < S; s += nt) {
-        const uint32_t inf = w.sinfo[s];
-        valid += info_type(inf) != T_HOLE;
-        const uint64_t k = key48(w.skey[s], inf);
-        if (k >= lo && k < hi) {
-          uint64_t bk = (k - lo) >> shift;
-          x.atomic_add(&w.bins[bk < (uint64_t)(kBins - 1) ? (int)bk : kBins - 1], 1);
+        const uint32_t dk = w.skey[s] - lo32;
+        if (w.skey[s] >= lo32 && dk <= span) {
+          const uint32_t bk = dk >> shift;
+          x.atomic_add(&w.bins[bin_index(bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1)], 1);
         }
       }
-      if (first) x.wave_add(&w.vars[VAR_VALID], valid);
       x.sync();
       x.mark(12);
       // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
       //    [2] #keys in the window, [3] #keys in b*.  Also re-zeroes bins[] and ends with a barrier.
-      x.find_bucket(w.bins, kBins, need, &w.vars[VAR_FB0]);
+      x.find_bucket(w.bins, need, &w.vars[VAR_FB0]);
       const int bstar = w.vars[VAR_FB0], above = w.vars[VAR_FB1], total = w.vars[VAR_FB2], inb = w.vars[VAR_FB3];
-      const int N = w.vars[VAR_VALID];
       x.mark(13);
-      if (first && N <= K) return;  // nothing to prune (ctc_beam_search_decoder.cpp:150)
       first = false;
       if (bstar < 0) {  // the K-th key lies below the window: look at everything under it
         gbase += total; need -= total; hi = lo; lo = 1;
@@ -266,32 +256,30 @@ struct Decoder {
       uint64_t bhi = (bstar == kBins - 1) ? hi : blo + ((uint64_t)1 << shift);
       if (bhi > hi) bhi = hi;  // keys at or above hi are already counted in gbase
       if (shift == 0 && bstar < kBins - 1) {  // the bucket is a single key value
-        if (tid == 0) {
-          w.vars[VAR_TAU_LO] = (int)(uint32_t)blo; w.vars[VAR_TAU_HI] = (int)(uint32_t)(blo >> 32);
-          w.vars[VAR_G] = gbase + above; w.vars[VAR_E] = inb;
-        }
+        if (tid == 0) { w.vars[VAR_TAU] = (int)(uint32_t)blo; w.vars[VAR_G] = gbase + above; w.vars[VAR_E] = inb; }
         x.sync();
         return;
       }
-      if (inb <= kListCap) {  // exact rank inside the bucket
+      if (inb <= kListCap) {  // exact rank inside the bucket, on offsets from its base
+        const uint32_t b32 = (uint32_t)blo, bspan = (uint32_t)(bhi - blo - 1);
         for (int s = tid; s < S; s += nt) {
-          const uint64_t k = slot_key48(s);
-          if (k >= blo && k < bhi) w.list[x.atomic_add(&w.vars[VAR_LCOUNT], 1)] = k;
+          const uint32_t k = w.skey[s], dk = k - b32;
+          if (k >= b32 && dk <= bspan) w.list[x.atomic_add(&w.vars[VAR_LCOUNT], 1)] = dk + 1u;
         }
+        for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
         x.sync();
         x.mark(14);
         const int want = need - above;  // rank (1-based, descending) of tau inside the bucket
         for (int q = tid; q < inb; q += nt) {
-          const uint64_t mine = w.list[q];
+          const uint32_t mine = w.list[q];
           int g = 0, e = 0;
-          for (int r = 0; r < inb; ++r) {
-            const uint64_t o = w.list[r];
-            g += o > mine;
-            e += o == mine;
+          for (int r = 0; r < inb; r += 4) {
+            const uint32_t o0 = w.list[r], o1 = w.list[r + 1], o2 = w.list[r + 2], o3 = w.list[r + 3];
+            g += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
+            e += (o0 == mine) + (o1 == mine) + (o2 == mine) + (o3 == mine);
           }
           if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
-            w.vars[VAR_TAU_LO] = (int)(uint32_t)mine; w.vars[VAR_TAU_HI] = (int)(uint32_t)(mine >> 32);
-            w.vars[VAR_G] = gbase + above + g; w.vars[VAR_E] = e;
+            w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gbase + above + g; w.vars[VAR_E] = e;
           }
         }
         x.sync();
@@ -299,6 +287,52 @@ struct Decoder {
       }
       gbase += above; need -= above; lo = blo; hi = bhi;  // too crowded: histogram the bucket itself
     }
+  }
+
+  // Several candidates share the K-th score: order them by character (prefix_compare, decoder_utils.cpp:126-131).
+  // m of the E candidates with score key tau must survive.  Sets VAR_TAUC (smallest surviving inverted-character
+  // code) and returns true when that cut is unambiguous; false when it would split a group of equivalent prefixes
+  // (or the group is too large to rank here): the caller then replays std::nth_element.
+  CTC_HD bool resolve_by_character(int S, uint32_t tau, int m, int E) {
+    const int tid = x.tid(), nt = x.nt();
+    if (E > kListCap) return false;
+    if (tid == 0) { w.vars[VAR_LCOUNT] = 0; w.vars[VAR_CUT] = 0; }
+    x.sync();
+    for (int s = tid; s < S; s += nt)
+      if (w.skey[s] == tau) w.list[x.atomic_add(&w.vars[VAR_LCOUNT], 1)] = (w.sinfo[s] >> 16) + 1u;
+    x.sync();
+    for (int q = tid; q < E; q += nt) {
+      const uint32_t mine = w.list[q];
+      int g = 0, e = 0;
+      for (int r = 0; r < E; ++r) {
+        const uint32_t o = w.list[r];
+        g += o > mine;
+        e += o == mine;
+      }
+      if (g < m && m <= g + e) { w.vars[VAR_TAUC] = (int)(mine - 1u); w.vars[VAR_CUT] = (g + e == m) ? 1 : 2; }
+    }
+    x.sync();
+    return w.vars[VAR_CUT] == 1;
+  }
+
+  // min of lcp[] over (lo, hi] of the CURRENT beam (depth of the lowest common ancestor of entries lo and hi)
+  CTC_HD int lca_depth(int ja, int jb) const {
+    const Beam &b = w.cur;
+    if (ja == jb) return b.dep[ja];
+    const int lo = ja < jb ? ja : jb, hi = ja < jb ? jb : ja;
+    int m = kIntMax;
+    int i = lo + 1;
+    for (; i + 3 <= hi; i += 4) {  // four independent loads per trip
+      const int l0 = b.lcp[i], l1 = b.lcp[i + 1], l2 = b.lcp[i + 2], l3 = b.lcp[i + 3];
+      const int m01 = l0 < l1 ? l0 : l1, m23 = l2 < l3 ? l2 : l3;
+      const int mm = m01 < m23 ? m01 : m23;
+      m = mm < m ? mm : m;
+    }
+    for (; i <= hi; ++i) {
+      const int l = b.lcp[i];
+      m = l < m ? l : m;
+    }
+    return m;
   }
 
   // ------------------------------------------------------------------------------------------------ exact replay
@@ -389,12 +423,16 @@ struct Decoder {
       w.hit[2 * j] = 0;
       w.hit[2 * j + 1] = 0;
     }
-    for (int i = tid; i < kBins; i += nt) w.bins[i] = 0;
-    if (tid == 0) { w.vars[VAR_VALID] = 0; w.vars[VAR_LCOUNT] = 0; }
+    for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
+    if (tid == 0) {
+      w.vars[VAR_NPIN] = 0; w.vars[VAR_LCOUNT] = 0; w.vars[VAR_SCOUNT] = 0;
+      w.vars[VAR_NDMIN] = kIntMax; w.vars[VAR_NMAXKEY] = 0;
+    }
     x.sync();
     x.mark(0);
 
     // ---- A2: slot offsets; which children of in-beam parents already exist (in the beam, or dead-interior)
+    int npin = 0;
     for (int j = tid; j < n; j += nt) {
       int a = 0;
       for (int i = w.anc[j]; i >= 0; i = w.anc[i]) ++a;
@@ -428,7 +466,9 @@ struct Decoder {
       w.hasvia[j] = hv;
       w.pinr[j] = pr;
       w.revr[j] = rr;
+      npin += pr >= 0;
     }
+    x.wave_add(&w.vars[VAR_NPIN], npin);
     x.sync();
     x.mark(1);
 
@@ -462,23 +502,23 @@ struct Decoder {
         w.sc_new[j] = ns;
         const int s0 = w.ostart[j];
         uint32_t k0 = 0, i0 = kHoleInfo;
-        int l0 = kIntMax, l1 = b.lcp[j];
         const int rx = w.revr[j];
         if (rx >= 0) {                                                      // path_trie.cpp:40-57: hit + revive
           const int cx = b.viach[j];
           const float lp = w.clp[rx];
           const int xn = b.via[j];
-          if (pool[xn].lpc < lp) {
+          float xl = pool[xn].lpc;
+          if (xl < lp) {
+            xl = lp;
             pool[xn].tstep = in.t;
             pool[xn].lpc = lp;
           }
+          w.rev_lpc[j] = xl;  // read back by whoever compacts the revived node (same step, other thread)
           k0 = ord_f32(child_logp(P, cx, lp));
           i0 = mk_info(cx, T_REVIVED, j);
-          l0 = b.lcp[j];
-          l1 = b.dep[P] + 1;
         }
-        w.skey[s0] = k0; w.sinfo[s0] = i0; w.slcp[s0] = l0;
-        w.skey[s0 + 1] = ord_f32(ns); w.sinfo[s0 + 1] = mk_info(c, T_SELF, j); w.slcp[s0 + 1] = l1;
+        w.skey[s0] = k0; w.sinfo[s0] = i0;
+        w.skey[s0 + 1] = ord_f32(ns); w.sinfo[s0 + 1] = mk_info(c, T_SELF, j);
       }
     }
     if (!split || tid >= n1) {
@@ -498,7 +538,6 @@ struct Decoder {
             const bool exists = (w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u;
             w.skey[s] = exists ? 0u : ord_f32(child_logp(i, c, lp));
             w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
-            w.slcp[s] = exists ? kIntMax : b.dep[i];
           }
         }
       } else {
@@ -510,7 +549,6 @@ struct Decoder {
           const bool exists = small_vocab && ((w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u);
           w.skey[s] = exists ? 0u : ord_f32(child_logp(i, c, w.clp[r]));
           w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
-          w.slcp[s] = exists ? kIntMax : b.dep[i];
         }
       }
     }
@@ -520,26 +558,31 @@ struct Decoder {
         const int r = w.pinr[j] >= 0 ? w.pinr[j] : w.revr[j];
         if (r >= 0) {
           const int s = w.cstart[w.anc[j]] + r - ((brank >= 0 && r > brank) ? 1 : 0);
-          w.skey[s] = 0; w.sinfo[s] = kHoleInfo; w.slcp[s] = kIntMax;
+          w.skey[s] = 0; w.sinfo[s] = kHoleInfo;
         }
       }
       x.sync();
     }
     x.mark(2);
 
-    // ---- C: the K-th best key
-    select_kth(S, K);
-    const int N = w.vars[VAR_VALID];
-    uint64_t tau = 0;
-    bool exact = false, tie = false;
-    if (N > K) {
-      tau = ((uint64_t)(uint32_t)w.vars[VAR_TAU_HI] << 32) | (uint32_t)w.vars[VAR_TAU_LO];
-      tie = w.vars[VAR_E] > K - w.vars[VAR_G];  // the boundary splits a group of equivalent prefixes
-      exact = tie || last;                      // decode() sorts the array exactly as nth_element left it (:164-190)
+    // ---- C: the K-th best key.  #candidates = beam entries + new children - children that already exist as entries
+    const int N = n * (1 + Vnb) - w.vars[VAR_NPIN];
+    uint32_t tau = 0, tauc = 0;
+    bool exact = false;
+    if (N > K) {  // ctc_beam_search_decoder.cpp:150
+      select_kth(S, K);
+      tau = (uint32_t)w.vars[VAR_TAU];
+      const int E = w.vars[VAR_E], m = K - w.vars[VAR_G];
+      if (E > m) {
+        if (resolve_by_character(S, tau, m, E)) tauc = (uint32_t)w.vars[VAR_TAUC];
+        else exact = true;  // the boundary splits a group of equivalent prefixes
+      }
+      if (last) exact = true;  // decode() sorts the array exactly as nth_element left it (:164-190)
     }
     x.mark(5);
 
-    // ---- D: exact replay of std::nth_element when the outcome depends on it
+    // ---- D: who survives.  Normally a flag pass; when the outcome depends on it, an exact replay of std::nth_element.
+    int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
     if (exact) {
       for (int s = tid; s <= S; s += nt) w.pos[s] = (s < S && info_type(w.sinfo[s]) != T_HOLE) ? 1u : 0u;
       x.sync();
@@ -548,122 +591,130 @@ struct Decoder {
         if (w.pos[s + 1] != w.pos[s]) w.ek[w.pos[s]] = (slot_key48(s) << 16) | (uint64_t)s;
       x.sync();
       replay_nth_element(N, K);
-      for (int s = tid; s < S; s += nt) w.pos[s] = 0;
-      x.sync();
-      for (int k = tid; k < K; k += nt) w.pos[(int)(w.ek[k] & 0xFFFFu)] = 1u;
+      for (int k = tid; k < K; k += nt) surv[k] = (int)(w.ek[k] & 0xFFFFu);
       x.sync();
       x.mark(6);
+    } else {
+      for (int s0 = 0; s0 < S; s0 += nt) {  // every thread takes part in every round (wave-aggregated append)
+        const int s = s0 + tid;
+        bool keep = false;
+        if (s < S) {
+          const uint32_t k = w.skey[s], inf = w.sinfo[s];
+          keep = (N <= K) ? (info_type(inf) != T_HOLE) : (k > tau || (k == tau && (inf >> 16) >= tauc));
+        }
+        const int idx = x.append(&w.vars[VAR_SCOUNT], keep);
+        if (keep) surv[idx] = s;
+      }
+      x.sync();
+      x.mark(3);
     }
+    const int n_new = N < K ? N : K;
 
-    // ---- E: fused compaction.  Each thread owns a contiguous chunk of slots; one workgroup scan yields the new beam
-    // index of every survivor, the id of every surviving new node, and the LCP carried across chunk boundaries.
-    const int chunk = ((S + nt - 1) / nt) | 1;  // odd stride: conflict-free LDS access across lanes
-    const int c_lo = tid * chunk < S ? tid * chunk : S, c_hi = c_lo + chunk < S ? c_lo + chunk : S;
-    auto survives = [&](int s, uint32_t inf) -> bool {
-      if (exact) return w.pos[s] != 0;
-      if (info_type(inf) == T_HOLE) return false;
-      if (N <= K) return true;
-      const uint64_t k = key48(w.skey[s], inf);
-      return k > tau || (k == tau && !tie);
-    };
-    int cnt = 0, cntc = 0, tailmin = kIntMax, dloc = kIntMax;
-    uint32_t kmax = 0;
-    bool has = false;
-    for (int s = c_lo; s < c_hi; ++s) {
-      const uint32_t inf = w.sinfo[s];
-      const int l = w.slcp[s];
-      tailmin = l < tailmin ? l : tailmin;
-      if (survives(s, inf)) {
-        ++cnt;
-        cntc += info_type(inf) == T_CHILD;
-        has = true;
-        tailmin = kIntMax;
-        const int j = info_entry(inf);
-        const int dd = info_type(inf) == T_SELF ? b.dep[j] : (info_type(inf) == T_CHILD ? b.dep[j] + 1 : b.dep[w.anc[j]] + 1);
-        dloc = dd < dloc ? dd : dloc;
-        const uint32_t sk = w.skey[s];
-        kmax = sk > kmax ? sk : kmax;
+    // ---- E: rank the survivors by slot (= DFS order), then one thread per survivor builds the next beam entry.
+    {
+      const int parts = nt / n_new > 0 ? (nt / n_new < 16 ? nt / n_new : 16) : 1;  // threads per survivor
+      if (parts > 1) {
+        for (int q = tid; q < n_new; q += nt) rk[q] = 0;
+        x.sync();
+        if (tid < parts * n_new) {
+          const int q = tid % n_new, part = tid / n_new;
+          const int mine = surv[q];
+          int r = 0;
+          for (int o = part; o < n_new; o += parts) r += surv[o] < mine;
+          x.atomic_add(&rk[q], r);
+        }
+        x.sync();
+        for (int q = tid; q < n_new; q += nt) ord[rk[q]] = q;
+      } else {
+        for (int q = tid; q < n_new; q += nt) {
+          const int mine = surv[q];
+          int r = 0;
+          for (int o = 0; o < n_new; ++o) r += surv[o] < mine;
+          rk[q] = r;
+          ord[r] = q;
+        }
       }
     }
-    x.mark(3);
-    SegOut so;
-    x.seg_scan(cnt, cntc, has, tailmin, dloc, kmax, so);
+    x.sync();
     x.mark(4);
-    const int n_new = so.total, n_child = so.totalc;
-    if (pool_count + n_child > pool_cap) {  // cannot happen when the pool is sized 1 + K*T
+    if (pool_count + n_new > pool_cap) {  // cannot happen when the pool is sized 1 + K*T
       if (tid == 0) w.vars[VAR_STATUS] = ST_POOL_OVERFLOW;
       x.sync();
       return;
     }
-    {
-      int k = so.excl, cid = so.exclc, run = so.carry;
-      for (int s = c_lo; s < c_hi; ++s) {
-        const uint32_t inf = w.sinfo[s];
-        const int l = w.slcp[s];
-        run = l < run ? l : run;
-        if (!survives(s, inf)) continue;
-        const uint32_t type = info_type(inf);
-        const int j = info_entry(inf);
-        nb.lcp[k] = k == 0 ? -1 : run;
-        run = kIntMax;
-        if (last && exact) w.pos[s] = 0x80000000u | (uint32_t)k;
-        if (type == T_SELF) {
-          nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = b.dep[j];
-          nb.via[k] = b.via[j]; nb.viaanc[k] = b.viaanc[j]; nb.viach[k] = b.viach[j];
-          nb.bprev[k] = w.b_new[j]; nb.nbprev[k] = w.nb_new[j]; nb.score[k] = w.sc_new[j]; nb.lpc[k] = b.lpc[j];
-        } else {
-          const int c = info_ch(inf);
-          const int P = (type == T_CHILD) ? j : w.anc[j];
-          const float lp = w.clp[rank_of_char(in, c)];
-          const float logp = child_logp(P, c, lp);
-          int id;
-          float lpc;
-          if (type == T_CHILD) {  // path_trie.cpp:97-105
-            id = pool_count + cid;
-            ++cid;
-            PoolNode pn; pn.parent = b.node[P]; pn.ch = c; pn.tstep = in.t; pn.lpc = lp;
-            pool[id] = pn;
-            lpc = lp;
-          } else {                // path_trie.cpp:50-56 : revived, probabilities reset
-            id = b.via[j];
-            lpc = pool[id].lpc;
-          }
-          nb.node[k] = id; nb.par[k] = b.node[P]; nb.ch[k] = c; nb.dep[k] = b.dep[P] + 1;
-          nb.via[k] = -1; nb.viaanc[k] = -1; nb.viach[k] = -1;
-          nb.bprev[k] = CTC_NEG_MAX; nb.nbprev[k] = logp; nb.score[k] = logp; nb.lpc[k] = lpc;
-        }
-        ++k;
+    int dloc = kIntMax;
+    uint32_t kloc = 0;
+    for (int q = tid; q < n_new; q += nt) {
+      const int k = rk[q], s = surv[q];
+      const uint32_t inf = w.sinfo[s];
+      const uint32_t type = info_type(inf);
+      const int j = info_entry(inf);
+      // LCP with the previous survivor: the LCA depth of two candidates is the LCA depth of the entries they hang
+      // off (a brand-new child never lies on an existing path), capped by the depth of a revived interior node.
+      int l = -1;
+      if (k > 0) {
+        const uint32_t pinf = w.sinfo[surv[ord[k - 1]]];
+        const int pj = info_entry(pinf);
+        l = lca_depth(pj, j);
+        if (type == T_REVIVED) { const int dx = b.dep[w.anc[j]] + 1; l = dx < l ? dx : l; }
+        if (info_type(pinf) == T_REVIVED) { const int dx = b.dep[w.anc[pj]] + 1; l = dx < l ? dx : l; }
       }
+      nb.lcp[k] = l;
+      if (last && exact) w.fin[q] = k;
+      int dd;
+      if (type == T_SELF) {
+        nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = dd = b.dep[j];
+        nb.via[k] = b.via[j]; nb.viaanc[k] = b.viaanc[j]; nb.viach[k] = b.viach[j];
+        nb.bprev[k] = w.b_new[j]; nb.nbprev[k] = w.nb_new[j]; nb.score[k] = w.sc_new[j]; nb.lpc[k] = b.lpc[j];
+      } else {
+        const int c = info_ch(inf);
+        const int P = (type == T_CHILD) ? j : w.anc[j];
+        const float lp = w.clp[rank_of_char(in, c)];
+        const float logp = child_logp(P, c, lp);
+        int id;
+        float lpc;
+        if (type == T_CHILD) {  // path_trie.cpp:97-105; ids are handed out by beam position (gaps are harmless)
+          id = pool_count + k;
+          PoolNode pn; pn.parent = b.node[P]; pn.ch = c; pn.tstep = in.t; pn.lpc = lp;
+          pool[id] = pn;
+          lpc = lp;
+        } else {                // path_trie.cpp:50-56 : revived, probabilities reset
+          id = b.via[j];
+          lpc = w.rev_lpc[j];
+        }
+        nb.node[k] = id; nb.par[k] = b.node[P]; nb.ch[k] = c; nb.dep[k] = dd = b.dep[P] + 1;
+        nb.viaanc[k] = -1;
+        nb.bprev[k] = CTC_NEG_MAX; nb.nbprev[k] = logp; nb.score[k] = logp; nb.lpc[k] = lpc;
+      }
+      dloc = dd < dloc ? dd : dloc;
+      kloc = w.skey[s] > kloc ? w.skey[s] : kloc;
     }
+    x.wave_min_to(&w.vars[VAR_NDMIN], dloc);
+    x.wave_max_to(&w.vars[VAR_NMAXKEY], kloc);
+    if (last && !exact)
+      for (int k = tid; k < n_new; k += nt) w.fin[k] = k;
+    // un-register this step's candidates from the rank table
+    if (!in.identity)
+      for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
+    x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
     if (tid == 0) {
       w.vars[VAR_N] = n_new;
-      w.vars[VAR_POOL] = pool_count + n_child;
-      w.vars[VAR_DMIN] = so.dmin;
+      w.vars[VAR_POOL] = pool_count + n_new;
+      w.vars[VAR_DMIN] = w.vars[VAR_NDMIN];
       // next select window.  It is anchored at this step's best key (an upper bound for the next step's keys when
       // log-probabilities are <= 0) and must reach down to the next K-th key: twice the distance from THIS step's
       // anchor (the previous best key) to this step's K-th key, rounded up to a power of two.
       int wl = 32;
       if (N > K) {
         const uint32_t anchor = (uint32_t)w.vars[VAR_MAXKEY];
-        const uint32_t t32 = (uint32_t)(tau >> 16);
-        const uint32_t gap = anchor > t32 ? anchor - t32 : 0;
+        const uint32_t gap = anchor > tau ? anchor - tau : 0;
         wl = ceil_log2_u64((uint64_t)gap + 1) + 1;
         wl = wl < 10 ? 10 : (wl > 32 ? 32 : wl);
       }
       w.vars[VAR_WLOG] = wl;
-      w.vars[VAR_MAXKEY] = (int)so.maxkey;
+      w.vars[VAR_MAXKEY] = w.vars[VAR_NMAXKEY];
     }
-    // un-register this step's candidates from the rank table
-    if (!in.identity)
-      for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
     x.sync();
-    if (last) {
-      if (exact)
-        for (int k = tid; k < K; k += nt) w.fin[k] = (int)(w.pos[(int)(w.ek[k] & 0xFFFFu)] & 0x7FFFFFFFu);
-      else
-        for (int k = tid; k < n_new; k += nt) w.fin[k] = k;
-      x.sync();
-    }
     x.mark(8);
     Beam t = w.cur; w.cur = w.nxt; w.nxt = t;
   }

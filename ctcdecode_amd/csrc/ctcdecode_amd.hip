@@ -54,8 +54,6 @@ template <bool PROF>
 struct DevX {
   int *red;  // 2 x 16 ints of LDS
   int parity;
-  int *seg;  // 2 x 80 ints of LDS (seg_scan)
-  int segpar;
   long long *prof;   // PROF: per-phase cycle accumulators (LDS), written by thread 0
   long long last;
   __device__ void mark(int id) {
@@ -67,7 +65,10 @@ struct DevX {
   }
   __device__ int tid() const { return (int)threadIdx.x; }
   __device__ int nt() const { return (int)blockDim.x; }
-  __device__ void sync() { __syncthreads(); }
+  // LDS-only barrier: waits for this wave's LDS traffic, not for outstanding global loads/stores (the row prefetch
+  // and the pool appends stay in flight across phases).  sync_full() is the fence that also drains global memory.
+  __device__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  __device__ void sync_full() { __syncthreads(); }
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
   // one LDS atomic per wave
@@ -76,18 +77,42 @@ struct DevX {
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
   }
 
-  // bins[0, 256) complete (caller synced).  Wave 0 finds the bucket holding the need-th largest key; everyone gets
-  // out[0..3] = {bucket or -1, #keys above it, #keys total, #keys in it} after the closing barrier; bins re-zeroed.
-  __device__ void find_bucket(int *bins, int nb, int need, int *out) {
+  // Wave-aggregated append: lanes with `pred` get consecutive indices from *counter (one LDS atomic per wave).
+  // Must be called by every lane of the wave.
+  __device__ int append(int *counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return -1;
+    const int lane = (int)threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __builtin_amdgcn_readlane(base, leader);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+  }
+  __device__ void wave_min_to(int *p, int v) {
+    v = wave_min(v);
+    if ((threadIdx.x & 63) == 0 && v != ctcbeam::kIntMax) atomicMin(p, v);
+  }
+  __device__ void wave_max_to(int *p, uint32_t v) {
+    v = wave_max_u32(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
+  }
+
+  // bins complete (caller synced), padded layout ctcbeam::bin_index.  Wave 0 finds the bucket holding the need-th
+  // largest key; everyone gets out[0..3] = {bucket or -1, #keys above it, #keys total, #keys in it} after the closing
+  // barrier; bins are re-zeroed.
+  __device__ void find_bucket(int *bins, int need, int *out) {
     if (threadIdx.x < 64) {
       const int lane = (int)threadIdx.x;
-      const int per = nb >> 6;            // 4 for 256 bins
-      const int base = (63 - lane) * per;  // lane 0 owns the TOP bins: a prefix scan over lanes is a suffix sum over bins
-      int v[4] = {0, 0, 0, 0};
+      constexpr int per = ctcbeam::kBins / 64;  // 16
+      const int owner = 63 - lane;  // lane 0 owns the TOP bins: a prefix scan over lanes is a suffix sum over bins
+      int *mine = bins + owner * (per + 1);
+      int v[per];
       int sum = 0;
+#pragma unroll
       for (int k = 0; k < per; ++k) {
-        v[k] = bins[base + k];
-        bins[base + k] = 0;
+        v[k] = mine[k];
+        mine[k] = 0;
         sum += v[k];
       }
       const int incl = wave_scan(sum, 0, [](int a, int b) { return a + b; });
@@ -97,64 +122,15 @@ struct DevX {
         if (lane == 0) { out[0] = -1; out[1] = 0; out[2] = total; out[3] = 0; }
       } else if (lane == __ffsll((long long)m) - 1) {
         int run = incl - sum;  // keys in bins above this lane's
+        bool done = false;
+#pragma unroll
         for (int k = per - 1; k >= 0; --k) {
-          if (run + v[k] >= need) { out[0] = base + k; out[1] = run; out[2] = total; out[3] = v[k]; break; }
-          run += v[k];
+          if (!done && run + v[k] >= need) { out[0] = owner * per + k; out[1] = run; out[2] = total; out[3] = v[k]; done = true; }
+          if (!done) run += v[k];
         }
       }
     }
-    __syncthreads();
-  }
-
-  // Fused compaction scan (beam_core.h step E): exclusive counts, the min-LCP carried in from the slots since the last
-  // survivor in the preceding threads' chunks, and workgroup totals / min depth / max key.  One barrier.
-  __device__ void seg_scan(int cnt, int cntc, bool has, int tailmin, int dloc, uint32_t kmax, ctcbeam::SegOut &o) {
-    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
-    int ci = (int)((uint32_t)cnt | ((uint32_t)cntc << 16));
-    int h = has ? 1 : 0, mn = tailmin;
-    // inclusive segmented scan of (count, has-survivor, min since last survivor): combine(left, mine)
-#define CTC_SEG_STEP(ctrl, rowmask)                                \
-    {                                                                \
-      const int co = CTC_DPP(0, ci, ctrl, rowmask);                  \
-      const int ho = CTC_DPP(0, h, ctrl, rowmask);                   \
-      const int mo = CTC_DPP(ctcbeam::kIntMax, mn, ctrl, rowmask);   \
-      ci += co;                                                      \
-      if (!h) { mn = mo < mn ? mo : mn; h = ho; }                    \
-    }
-    CTC_SEG_STEP(0x111, 0xf) CTC_SEG_STEP(0x112, 0xf) CTC_SEG_STEP(0x114, 0xf) CTC_SEG_STEP(0x118, 0xf)
-    CTC_SEG_STEP(0x142, 0xa) CTC_SEG_STEP(0x143, 0xc)
-#undef CTC_SEG_STEP
-    const int dm = wave_min(dloc);
-    const uint32_t km = wave_max_u32(kmax);
-    // exclusive values: shift the whole wave right by one lane (wave_shr:1)
-    const int ce = CTC_DPP(0, ci, 0x138, 0xf);
-    const int he = CTC_DPP(0, h, 0x138, 0xf);
-    const int me = CTC_DPP(ctcbeam::kIntMax, mn, 0x138, 0xf);
-    int *row = seg + segpar * 80;
-    segpar ^= 1;
-    if (lane == 63) {
-      row[wave * 5 + 0] = ci; row[wave * 5 + 1] = h; row[wave * 5 + 2] = mn; row[wave * 5 + 3] = dm; row[wave * 5 + 4] = (int)km;
-    }
-    __syncthreads();
-    uint32_t cb = 0, tot = 0, kmx = 0;
-    int mb = ctcbeam::kIntMax, dmin = ctcbeam::kIntMax;
-    for (int i = 0; i < nw; ++i) {
-      const uint32_t cw = (uint32_t)row[i * 5];
-      const int hw = row[i * 5 + 1], mw = row[i * 5 + 2], dw = row[i * 5 + 3];
-      const uint32_t kw = (uint32_t)row[i * 5 + 4];
-      if (i < wave) {
-        cb += cw;
-        if (hw) mb = mw; else mb = mw < mb ? mw : mb;
-      }
-      tot += cw;
-      dmin = dw < dmin ? dw : dmin;
-      kmx = kw > kmx ? kw : kmx;
-    }
-    const uint32_t ex = cb + (uint32_t)ce;
-    o.excl = (int)(ex & 0xFFFFu); o.exclc = (int)(ex >> 16);
-    o.total = (int)(tot & 0xFFFFu); o.totalc = (int)(tot >> 16);
-    o.carry = he ? me : (mb < me ? mb : me);
-    o.dmin = dmin; o.maxkey = kmx;
+    sync();
   }
 
   // Sum over the workgroup, same value returned to every thread.  One barrier per call: consecutive calls alternate
@@ -165,7 +141,7 @@ struct DevX {
     int *row = red + parity * 16;
     parity ^= 1;
     if ((threadIdx.x & 63) == 0) row[wave] = v;
-    __syncthreads();
+    sync();
     int tot = 0;
     for (int i = 0; i < nw; ++i) tot += row[i];
     return tot;
@@ -183,7 +159,7 @@ struct DevX {
     int *row = red + parity * 16;
     parity ^= 1;
     if ((t & 63) == 63) row[wave] = (int)incl;
-    __syncthreads();
+    sync();
     uint32_t base = 0, total = 0;
     for (int i = 0; i < nw; ++i) {
       const uint32_t v = (uint32_t)row[i];
@@ -196,7 +172,7 @@ struct DevX {
       a[i] = run;
       run += v;
     }
-    __syncthreads();
+    sync();
     return total;
   }
 };
@@ -226,8 +202,7 @@ __global__ void ctc_beam_decode_kernel(KernelArgs a) {
   carve(w, smem, a.dims);
   __shared__ long long prof[16];
   if (PROF && threadIdx.x < 16) prof[threadIdx.x] = 0;
-  __shared__ int seg[160];
-  DevX<PROF> x{red, 0, seg, 0, prof, 0};
+  DevX<PROF> x{red, 0, prof, 0};
   int len = a.seq_lens ? a.seq_lens[b] : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();

@@ -19,6 +19,7 @@ struct HostX {
   int tid() const { return 0; }
   int nt() const { return 1; }
   void sync() {}
+  void sync_full() {}
   void mark(int) {}
   int reduce_add(int v) { return v; }
   uint32_t scan_excl(uint32_t *a, int n) {
@@ -33,19 +34,22 @@ struct HostX {
   int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
   void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
   void wave_add(int *p, int v) { *p += v; }
-  void find_bucket(int *bins, int nb, int need, int *out) {
+  void find_bucket(int *bins, int need, int *out) {
+    using ctcbeam::bin_index;
+    using ctcbeam::kBins;
     int run = 0, bstar = -1, above = 0, inb = 0, total = 0;
-    for (int b = 0; b < nb; ++b) total += bins[b];
-    for (int b = nb - 1; b >= 0; --b) {
-      if (run + bins[b] >= need) { bstar = b; above = run; inb = bins[b]; break; }
-      run += bins[b];
+    for (int b = 0; b < kBins; ++b) total += bins[bin_index(b)];
+    for (int b = kBins - 1; b >= 0; --b) {
+      const int v = bins[bin_index(b)];
+      if (run + v >= need) { bstar = b; above = run; inb = v; break; }
+      run += v;
     }
     out[0] = bstar; out[1] = above; out[2] = total; out[3] = inb;
-    for (int b = 0; b < nb; ++b) bins[b] = 0;
+    for (int b = 0; b < kBins + kBins / 16; ++b) bins[b] = 0;
   }
-  void seg_scan(int cnt, int cntc, bool, int, int dloc, uint32_t kmax, ctcbeam::SegOut &o) {
-    o.excl = 0; o.exclc = 0; o.total = cnt; o.totalc = cntc; o.carry = ctcbeam::kIntMax; o.dmin = dloc; o.maxkey = kmax;
-  }
+  int append(int *counter, bool pred) { return pred ? (*counter)++ : -1; }
+  void wave_min_to(int *p, int v) { *p = std::min(*p, v); }
+  void wave_max_to(int *p, uint32_t v) { *p = (int)std::max((uint32_t)*p, v); }
 };
 
 // Vocabulary pruning exactly as the reference does it (decoder_utils.cpp:10-45) -- host stand-in for the GPU prune pass.

@@ -9,8 +9,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-NAMES = ["A1 subtree ends / ancestors", "A2 slot offsets / existing children", "B score candidates", "E1 compaction pass 1", "E2 workgroup scan",
-         "C4 select: exact rank in bucket", "D exact nth_element replay", "(unused)", "E3 compaction pass 2 (emit)", "(unused)",
+NAMES = ["A1 subtree ends / ancestors", "A2 slot offsets / existing children", "B score candidates", "D flag survivors", "E1 rank survivors",
+         "C4 select: exact rank in bucket", "D' exact nth_element replay", "(unused)", "E2 emit next beam", "(unused)",
          "row load", "finish (sorts + back-trace)", "C1 select: histogram", "C2 select: find bucket", "C3 select: gather bucket", "(unused)"]
 
 
