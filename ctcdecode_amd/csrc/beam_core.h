@@ -775,10 +775,19 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   Decoder<X> dec(x, w, d, blank, pool, pool_cap, tbl);
   dec.init();
   const int tid = x.tid(), nt = x.nt();
-  // Row prefetch: the row of step t+1 is requested from HBM before step t runs, so its latency hides behind the step.
-  const bool prefetch = pr == nullptr && d.V <= nt;
-  float pre = 0.f;
-  if (prefetch && len > 0 && tid < d.V) pre = rows[tid];
+  // Prefetch: the candidates of step t+1 are requested from HBM before step t runs, so the latency hides behind it.
+  const int width = pr ? pr->stride : d.V;
+  const bool prefetch = width <= nt;
+  float pre_lp = 0.f;
+  int pre_ch = 0, pre_cnt = 0;
+  if (prefetch && len > 0) {
+    if (pr) {
+      pre_cnt = pr->cnt[0];
+      if (tid < width) { pre_ch = pr->ch[tid]; pre_lp = pr->lp[tid]; }
+    } else if (tid < width) {
+      pre_lp = rows[tid];
+    }
+  }
   for (int t = 0; t < len; ++t) {
     StepIn in;
     in.t = t;
@@ -787,20 +796,29 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       in.identity = 1;
       in.blank_rank = blank;
       if (prefetch) {
-        if (tid < d.V) w.clp[tid] = pre;
-        if (t + 1 < len && tid < d.V) pre = rows[(size_t)(t + 1) * d.V + tid];
+        if (tid < d.V) w.clp[tid] = pre_lp;
+        if (t + 1 < len && tid < d.V) pre_lp = rows[(size_t)(t + 1) * d.V + tid];
       } else {
         for (int r = tid; r < d.V; r += nt) w.clp[r] = rows[(size_t)t * d.V + r];
       }
       x.sync();
     } else {
-      in.Vc = pr->cnt[t];
       in.identity = 0;
-      for (int r = tid; r < in.Vc; r += nt) {
-        const int c = pr->ch[(size_t)t * pr->stride + r];
-        w.cch[r] = c;
-        w.clp[r] = pr->lp[(size_t)t * pr->stride + r];
-        w.rank_of[c] = r;
+      if (prefetch) {
+        in.Vc = pre_cnt;
+        if (tid < in.Vc) { w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = tid; }
+        if (t + 1 < len) {
+          pre_cnt = pr->cnt[t + 1];
+          if (tid < width) { pre_ch = pr->ch[(size_t)(t + 1) * width + tid]; pre_lp = pr->lp[(size_t)(t + 1) * width + tid]; }
+        }
+      } else {
+        in.Vc = pr->cnt[t];
+        for (int r = tid; r < in.Vc; r += nt) {
+          const int c = pr->ch[(size_t)t * width + r];
+          w.cch[r] = c;
+          w.clp[r] = pr->lp[(size_t)t * width + r];
+          w.rank_of[c] = r;
+        }
       }
       x.sync();
       in.blank_rank = w.rank_of[blank];

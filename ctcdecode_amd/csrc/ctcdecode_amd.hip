@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -189,6 +191,10 @@ struct KernelArgs {
   float *out_score;
   int32_t *status;          // [B]
   long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
+  const int *pr_cnt;        // pruned mode: [B, T] candidates per frame (null in identity mode)
+  const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
+  const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
+  int pr_stride;
 };
 
 template <bool PROF>
@@ -208,7 +214,15 @@ __global__ void ctc_beam_decode_kernel(KernelArgs a) {
   __syncthreads();
   if (PROF) x.last = (long long)wall_clock64();
   const size_t kt = (size_t)a.K * a.T;
-  const int st = decode_utterance(x, w, a.dims, a.blank, a.probs + (size_t)b * a.T * a.V, (const PrunedRows *)nullptr, len,
+  PrunedRows prow;
+  if (a.pr_cnt) {
+    prow.cnt = a.pr_cnt + (size_t)b * a.T;
+    prow.ch = a.pr_ch + (size_t)b * a.T * a.pr_stride;
+    prow.lp = a.pr_lp + (size_t)b * a.T * a.pr_stride;
+    prow.stride = a.pr_stride;
+  }
+  const int st = decode_utterance(x, w, a.dims, a.blank, a.pr_cnt ? nullptr : a.probs + (size_t)b * a.T * a.V,
+                                  a.pr_cnt ? &prow : (const PrunedRows *)nullptr, len,
                                   a.pool + (size_t)b * a.pool_stride, (int)a.pool_stride, tbl, a.T,
                                   a.out_tok + (size_t)b * kt, a.out_ts + (size_t)b * kt, a.out_score + (size_t)b * a.K,
                                   a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr);
@@ -232,6 +246,141 @@ __global__ void prob_to_log_kernel(const float *in, float *out, size_t n, unsign
       if (k < flag_cap) flag_idx[k] = (unsigned long long)i;
     }
     out[i] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ vocabulary prune
+// get_pruned_log_probs (decoder_utils.cpp:10-45) for every frame, one wave per frame, no barriers: the top
+// min(cutoff_top_n, V) values in descending order (and, with cutoff_prob < 1, the reference's cumulative cut).
+// The order std::sort gives EQUAL values, and double-precision libm roundings, are toolchain behaviour the reference
+// inherits; whenever a frame's result could depend on either (equal values at or above the cut, a cumulative sum
+// within rounding distance of cutoff_prob, a borderline float rounding of log) the frame is flagged and recomputed on
+// the host with the real std::sort / libm (host_prune_row below).  Everything else is decided here, exactly.
+struct PruneArgs {
+  const float *in;          // [B, T, V]
+  const int32_t *seq_lens;  // [B] or null
+  int T, V, top_n, log_input, stride;
+  long long rows;           // B * T
+  double cutoff_prob;
+  int *cnt, *ch;
+  float *lp;
+  unsigned *n_flag, *flag_rows;
+  unsigned flag_cap;
+};
+
+__device__ __forceinline__ uint32_t prune_key(float v) {  // order of the doubles the reference compares; -0 == +0
+  uint32_t u = __float_as_uint(v);
+  if (u == 0x80000000u) u = 0;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ double log_add_f64(double a, double b) {  // decoder_utils.h:47-54 with T = double
+  const double neg = -1.7976931348623157e308;
+  if (a <= neg) return b;
+  if (b <= neg) return a;
+  const double m = a > b ? a : b;
+  return log(exp(a - m) + exp(b - m)) + m;
+}
+
+__global__ void prune_rows_kernel(PruneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char psm[];
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, wpb = (int)blockDim.x >> 6;
+  const int n = a.top_n < a.V ? a.top_n : a.V;
+  uint32_t *lkey = (uint32_t *)psm + (size_t)wave * 3 * a.stride;  // per wave: keys, labels, labels in final order
+  int *lidx = (int *)lkey + a.stride;
+  int *sidx = lidx + a.stride;
+  for (long long r = (long long)blockIdx.x * wpb + wave; r < a.rows; r += (long long)gridDim.x * wpb) {
+    if (a.seq_lens) {  // frames beyond the utterance's length are never read (binding.cpp:64-65)
+      const long long b = r / a.T;
+      int len = a.seq_lens[b];
+      len = len < 0 ? 0 : len;
+      if ((int)(r - b * a.T) >= len) continue;
+    }
+    const float *x = a.in + (size_t)r * a.V;
+    bool flag = false;
+    // n-th largest key, bit by bit
+    uint32_t tau = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t trial = tau | (1u << bit);
+      int c = 0;
+      for (int i = lane; i < a.V; i += 64) c += prune_key(x[i]) >= trial;
+      if (wave_sum(c) >= n) tau = trial;
+    }
+    int g = 0, e = 0;
+    for (int i = lane; i < a.V; i += 64) {
+      const uint32_t k = prune_key(x[i]);
+      g += k > tau;
+      e += k == tau;
+    }
+    g = wave_sum(g);
+    e = wave_sum(e);
+    if (e > n - g) flag = true;  // equal values straddle the cut: std::sort decides which of them are kept
+    // gather the kept values
+    int base = 0;
+    for (int i0 = 0; i0 < a.V; i0 += 64) {
+      const int i = i0 + lane;
+      uint32_t k = 0;
+      bool keep = false;
+      if (i < a.V) {
+        k = prune_key(x[i]);
+        keep = k > tau || (k == tau && !flag);
+      }
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int p = base + __popcll(m & ((1ull << lane) - 1ull));
+        lkey[p] = k;
+        lidx[p] = i;
+      }
+      base += __popcll(m);
+    }
+    const int kept = base;  // == n unless flagged
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
+    // rank (descending); equal kept values -> their order is std::sort's business
+    int *och = a.ch + (size_t)r * a.stride;
+    float *olp = a.lp + (size_t)r * a.stride;
+    for (int q = lane; q < kept; q += 64) {
+      const uint32_t mine = lkey[q];
+      int rank = 0, dup = 0;
+      for (int o = 0; o < kept; ++o) {
+        const uint32_t k = lkey[o];
+        rank += k > mine;
+        dup += k == mine;
+      }
+      if (dup > 1) flag = true;
+      const int idx = lidx[q];
+      float v = x[idx];
+      if (!a.log_input) {  // decoder_utils.cpp:42
+        const double y = log((double)v + (double)FLT_MIN);
+        v = (float)y;
+        const double eps = fabs(y) * 0x1p-50;
+        if ((float)(y - eps) != v || (float)(y + eps) != v || !(y == y)) flag = true;
+      }
+      if (dup <= 1) { och[rank] = idx; olp[rank] = v; sidx[rank] = idx; }
+    }
+    flag = __ballot(flag) != 0ull;
+    int len = kept;
+    if (a.cutoff_prob < 1.0 && !flag) {  // decoder_utils.cpp:25-32: cum starts at 0.0 (sic)
+      if (lane == 0) {
+        double cum = 0.0;
+        len = 0;
+        for (int i = 0; i < kept; ++i) {
+          const double p = (double)x[sidx[i]];
+          cum = log_add_f64(cum, a.log_input ? p : log(p));
+          ++len;
+          if (fabs(cum - a.cutoff_prob) <= 1e-9 * (1.0 + fabs(cum)) || !(cum == cum)) { flag = true; break; }
+          if (cum >= a.cutoff_prob || len >= a.top_n) break;
+        }
+      }
+      len = __builtin_amdgcn_readfirstlane(len);
+      flag = __ballot(flag) != 0ull;
+    }
+    if (lane == 0) {
+      a.cnt[r] = len;
+      if (flag) {
+        const unsigned k = atomicAdd(a.n_flag, 1u);
+        if (k < a.flag_cap) a.flag_rows[k] = (unsigned)r;
+      }
+    }
   }
 }
 
@@ -288,7 +437,8 @@ struct ctcd_decoder {
   int device = 0;
   int threads = 512;
   int max_lds = 0;
-  Buf pool, status, tables, logp, flags, stage_in, stage_out;
+  Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp;
+  long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
   bool tables_ready = false;
   bool timing = false;
   bool profile = false;
@@ -307,6 +457,44 @@ Dims make_dims(int beam, int V, int cutoff_top_n, double cutoff_prob) {
   d.Vc_max = pruned ? (cutoff_top_n < V ? cutoff_top_n : V) : V;
   d.use_rank_table = pruned ? 1 : 0;
   return d;
+}
+
+// One frame of get_pruned_log_probs exactly as the reference computes it (decoder_utils.cpp:10-45): the same
+// std::sort call on (index, double) pairs, the same libm log/exp.  Used only for frames the GPU flagged (equal values
+// at the cut, borderline roundings), so that toolchain-defined behaviour is reproduced by the toolchain itself.
+template <class T>
+T host_log_add(T a, T b) {
+  const T neg = -std::numeric_limits<T>::max();
+  if (a <= neg) return b;
+  if (b <= neg) return a;
+  const T m = std::max(a, b);
+  return std::log(std::exp(a - m) + std::exp(b - m)) + m;
+}
+
+int host_prune_row(const float *row, int V, double cutoff_prob, int top_n, int log_input, int *ch, float *lp) {
+  std::vector<std::pair<int, double>> pv;
+  pv.reserve(V);
+  for (int i = 0; i < V; ++i) pv.emplace_back(i, (double)row[i]);
+  size_t keep = (size_t)V;
+  if (std::log(cutoff_prob) < 0.0 || (size_t)top_n < keep) {
+    std::sort(pv.begin(), pv.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.second > b.second; });
+    if (std::log(cutoff_prob) < 0.0) {
+      double cum = 0.0;
+      keep = 0;
+      for (size_t i = 0; i < pv.size(); ++i) {
+        cum = host_log_add(cum, log_input ? pv[i].second : std::log(pv[i].second));
+        ++keep;
+        if (cum >= cutoff_prob || keep >= (size_t)top_n) break;
+      }
+    } else {
+      keep = (size_t)top_n;
+    }
+  }
+  for (size_t i = 0; i < keep; ++i) {
+    ch[i] = pv[i].first;
+    lp[i] = (float)(log_input ? pv[i].second : std::log(pv[i].second + (double)FLT_MIN));
+  }
+  return (int)keep;
 }
 
 int check_args(int B, int T, int V, int beam, int cutoff_top_n, int blank_id, const void *probs, const void *tok,
@@ -354,7 +542,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   (void)hipSetDevice(d->device);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
-  d->stage_in.release(); d->stage_out.release();
+  d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release();
   delete d;
 }
 
@@ -375,8 +563,8 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
   HIP_TRY(hipSetDevice(d->device));
   if (B == 0) return CTCD_OK;
   const Dims dims = make_dims(beam, V, cutoff_top_n, cutoff_prob);
-  if (dims.use_rank_table)
-    return fail(CTCD_EUNSUPPORTED, "vocabulary pruning (cutoff_top_n < V or cutoff_prob < 1) is not built yet");
+  if (dims.S_max() > 65535)
+    return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) exceeds 65535 candidate slots");
   Work wtmp;
   const size_t lds = carve(wtmp, nullptr, dims);
   if (lds + 1024 > (size_t)d->max_lds)
@@ -401,7 +589,51 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
   if ((rc = d->status.ensure((size_t)B * 4))) return rc;
 
   const float *logp = probs;
-  if (!log_input && T > 0) {
+  d->prune_host_rows = 0;
+  if (dims.use_rank_table && T > 0) {
+    // vocabulary prune pass (also converts the kept probabilities to log space when log_input == 0)
+    const long long rows = (long long)B * T;
+    const int stride = dims.Vc_max;
+    const unsigned cap = 1u << 16;
+    if ((rc = d->pr_cnt.ensure((size_t)rows * 4))) return rc;
+    if ((rc = d->pr_ch.ensure((size_t)rows * stride * 4))) return rc;
+    if ((rc = d->pr_lp.ensure((size_t)rows * stride * 4))) return rc;
+    if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
+    unsigned *n_flag = (unsigned *)d->flags.p;
+    unsigned *flag_rows = (unsigned *)((char *)d->flags.p + 8);
+    HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
+    HIP_TRY(hipMemsetAsync(d->pr_cnt.p, 0, (size_t)rows * 4, stream));
+    PruneArgs pa;
+    pa.in = probs; pa.seq_lens = seq_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
+    pa.stride = stride; pa.rows = rows; pa.cutoff_prob = cutoff_prob; pa.cnt = (int *)d->pr_cnt.p; pa.ch = (int *)d->pr_ch.p;
+    pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
+    const int wpb = 4;
+    const size_t psm = (size_t)wpb * 3 * stride * 4;
+    if (psm > (size_t)d->max_lds) return fail(CTCD_EUNSUPPORTED, "cutoff_top_n too large for the prune pass");
+    const int blocks = (int)std::min<long long>((rows + wpb - 1) / wpb, 256 * 16);
+    HIP_TRY(hipFuncSetAttribute((const void *)prune_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm));
+    hipLaunchKernelGGL(prune_rows_kernel, dim3(blocks), dim3(wpb * 64), psm, stream, pa);
+    HIP_TRY(hipGetLastError());
+    unsigned nf = 0;
+    HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (nf > cap) return fail(CTCD_EUNSUPPORTED, "more than 65536 frames with tied / borderline values in one call");
+    if (nf) {  // toolchain-defined cases: let the toolchain decide (real std::sort, real libm)
+      std::vector<unsigned> fr(nf);
+      HIP_TRY(hipMemcpy(fr.data(), flag_rows, (size_t)nf * 4, hipMemcpyDeviceToHost));
+      std::vector<float> row(V), hlp(stride);
+      std::vector<int> hch(stride);
+      for (unsigned k = 0; k < nf; ++k) {
+        const size_t r = fr[k];
+        HIP_TRY(hipMemcpy(row.data(), probs + r * V, (size_t)V * 4, hipMemcpyDeviceToHost));
+        const int cnt = host_prune_row(row.data(), V, cutoff_prob, cutoff_top_n, log_input, hch.data(), hlp.data());
+        HIP_TRY(hipMemcpy((int *)d->pr_cnt.p + r, &cnt, 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy((int *)d->pr_ch.p + r * stride, hch.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy((float *)d->pr_lp.p + r * stride, hlp.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
+      }
+      d->prune_host_rows = nf;
+    }
+  } else if (!log_input && T > 0) {
     const size_t n = (size_t)B * T * V;
     const unsigned cap = 1u << 16;
     if ((rc = d->logp.ensure(n * 4))) return rc;
@@ -434,6 +666,11 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
   a.pool = (PoolNode *)d->pool.p; a.pool_stride = pool_stride; a.tables = (const uint64_t *)d->tables.p;
   a.out_tok = out_tok; a.out_ts = out_ts; a.out_len = out_len; a.n_results = n_results; a.out_score = out_sc;
   a.status = (int32_t *)d->status.p;
+  a.pr_cnt = nullptr; a.pr_ch = nullptr; a.pr_lp = nullptr; a.pr_stride = 0;
+  if (dims.use_rank_table) {
+    a.pr_cnt = (const int *)d->pr_cnt.p; a.pr_ch = (const int *)d->pr_ch.p; a.pr_lp = (const float *)d->pr_lp.p;
+    a.pr_stride = dims.Vc_max;
+  }
   a.prof = nullptr;
   if (d->profile) {
     if ((rc = d->prof.ensure((size_t)B * 16 * 8))) return rc;
@@ -525,6 +762,9 @@ int ctcd_debug_get_profile(ctcd_decoder *d, long long *out, int B) {
 // mode 0: expf_nonpos(x), 1: logf_normal(x), x = bits lo, lo+stride, ... <= hi;  mode 2: lse(x, y) on n pairs.
 int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,
                           const float *ys, long long n_pairs, long long *checked, long long *mismatches);
+
+// Number of frames of the last ctcd_beam_decode whose vocabulary prune was resolved on the host (ties / borderline).
+long long ctcd_last_prune_host_rows(ctcd_decoder *d) { return d ? d->prune_host_rows : -1; }
 
 // Status words of the last ctcd_beam_decode on this decoder (device -> host); for callers of the async entry point.
 int ctcd_check_status(ctcd_decoder *d, int B) {

@@ -62,6 +62,11 @@ int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *
 /* Host check of the per-item status words written by the last ctcd_beam_decode (synchronises the device). */
 int ctcd_check_status(ctcd_decoder *dec, int B);
 
+/* Frames of the last ctcd_beam_decode whose vocabulary prune had to be decided by the host toolchain (equal values at
+ * the cutoff_top_n boundary or among the kept ones -- the reference's order there is std::sort's -- or borderline
+ * double roundings); 0 for the no-prune configurations. */
+long long ctcd_last_prune_host_rows(ctcd_decoder *dec);
+
 /* HIP-event timing of the decode kernel alone (events recorded on the launch stream). */
 int ctcd_set_timing(ctcd_decoder *dec, int on);
 int ctcd_last_kernel_ms(ctcd_decoder *dec, float *ms);

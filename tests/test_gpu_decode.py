@@ -102,6 +102,41 @@ def test_randomized_against_oracle(torch_mod, c, threads):
     ou.assert_same(_with_nres(got, want), want)
 
 
+PRUNED = [
+    dict(B=3, T=80, V=64, K=20, seed=51, top_n=8),
+    dict(B=2, T=60, V=200, K=16, seed=52, top_n=12),
+    dict(B=2, T=90, V=64, K=24, seed=53, top_n=8, quant=0.5),             # equal values at / above the cut -> host-resolved frames
+    dict(B=2, T=70, V=29, K=16, seed=54, top_n=40, cutoff_prob=0.5),       # the cumulative cut really triggers (exp(0.5)-1 = 0.65)
+    dict(B=2, T=70, V=29, K=16, seed=55, top_n=10, cutoff_prob=0.6),
+    dict(B=2, T=70, V=29, K=16, seed=56, top_n=40, cutoff_prob=0.99),      # BASELINE.json configs[3] setting: never triggers
+    dict(B=2, T=60, V=40, K=12, seed=57, top_n=6, prob_input=True),
+    dict(B=2, T=50, V=40, K=12, seed=58, top_n=40, cutoff_prob=0.55, prob_input=True),
+    dict(B=2, T=40, V=1000, K=10, seed=59, top_n=40, cutoff_prob=0.99, blank_bias=2.0),
+    dict(B=3, T=50, V=64, K=8, seed=60, top_n=1),                          # blank may be pruned away entirely
+]
+
+
+@pytest.mark.parametrize("c", PRUNED, ids=lambda c: "V%(V)d_n%(top_n)d_s%(seed)d" % c)
+def test_vocabulary_pruning_against_oracle(torch_mod, c):
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    lp = ou.synth_logprobs(c["B"], c["T"], c["V"], c["seed"], quant=c.get("quant"), blank_bias=c.get("blank_bias", 0.0))
+    x = np.exp(lp) if c.get("prob_input") else lp
+    kw = dict(beam=c["K"], cutoff_top_n=c["top_n"], cutoff_prob=c.get("cutoff_prob", 1.0), log_input=not c.get("prob_input"))
+    want = ou.decode(x, which="restated", **kw)
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(c["V"])], cutoff_top_n=c["top_n"], cutoff_prob=c.get("cutoff_prob", 1.0),
+                                       beam_width=c["K"], log_probs_input=not c.get("prob_input"))
+    out, sc, ts, ln = dec.decode(torch_mod.from_numpy(np.ascontiguousarray(x)))
+    got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+    ou.assert_same(_with_nres(got, want), want)
+    host_rows = n.lib.ctcd_last_prune_host_rows(dec._handle)
+    if c.get("quant"):
+        assert host_rows > 0, "quantised inputs must exercise the host tie resolution"
+    elif not c.get("prob_input") and c.get("cutoff_prob", 1.0) == 1.0:
+        assert host_rows == 0
+
+
 def test_north_star_shape_parity_and_properties(torch_mod):
     """BASELINE.json configs[1]: B=256, T=1000, V=29, beam=100.  Bit-exact against the oracle on a sample of the items
     (the CPU needs ~1 s per item), size-independent properties on all of them, and run-to-run determinism."""
