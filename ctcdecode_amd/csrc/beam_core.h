@@ -103,7 +103,7 @@ struct Work {
   float *b_new, *nb_new, *sc_new, *rev_lpc;
   int *cch;        // candidate characters of this step (unused in identity mode)
   float *clp;      // their log-probs
-  int *rank_of;    // V entries, -1 = not a candidate (only when Dims::use_rank_table)
+  int16_t *rank_of;  // V entries, -1 = not a candidate (only when Dims::use_rank_table; V <= 32767 then)
   uint32_t *skey, *sinfo, *pos;  // S_max (+1 for pos): score key, info word, scratch
   int *surv;       // 3K: slots of the survivors | their rank in slot (= DFS) order | inverse of that ranking
   uint64_t *ek;    // S_max: (key48 << 16 | slot) in DFS order, for the exact replay
@@ -122,7 +122,10 @@ CTC_HD P *carve_ptr(char *&p, size_t count) {
 }
 
 // Lay the workspace out in `base` (LDS on the GPU).  Returns bytes used; call with base == nullptr to size it.
-CTC_HD size_t carve(Work &w, char *base, const Dims &d) {
+// BIG: the arrays that only the rare paths touch per slot (info words, and the scratch of the exact replay) live in
+// `far` (HBM, per utterance) instead, so that wide beams still fit the 160 KiB of LDS; *far_bytes gets their size.
+template <bool BIG>
+CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_bytes) {
   char *p = base;
   const size_t K = (size_t)d.K, S = (size_t)d.S_max();
   Beam *bs[2] = {&w.cur, &w.nxt};
@@ -140,14 +143,23 @@ CTC_HD size_t carve(Work &w, char *base, const Dims &d) {
   w.b_new = carve_ptr<float>(p, K); w.nb_new = carve_ptr<float>(p, K); w.sc_new = carve_ptr<float>(p, K); w.rev_lpc = carve_ptr<float>(p, K);
   w.cch = carve_ptr<int>(p, (size_t)d.Vc_max);
   w.clp = carve_ptr<float>(p, (size_t)d.Vc_max);
-  w.rank_of = carve_ptr<int>(p, d.use_rank_table ? (size_t)d.V : 0);
-  w.skey = carve_ptr<uint32_t>(p, S); w.sinfo = carve_ptr<uint32_t>(p, S);
-  w.pos = carve_ptr<uint32_t>(p, S + 2); w.surv = carve_ptr<int>(p, 3 * K + 4);
-  w.ek = carve_ptr<uint64_t>(p, S); w.lr = carve_ptr<uint16_t>(p, 2 * S + 2);
+  w.rank_of = carve_ptr<int16_t>(p, d.use_rank_table ? (size_t)d.V : 0);
+  w.skey = carve_ptr<uint32_t>(p, S);
+  w.surv = carve_ptr<int>(p, 3 * K + 4);
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
   w.fin = carve_ptr<int>(p, K);
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
+  char *q = BIG ? far : p;
+  w.sinfo = carve_ptr<uint32_t>(q, S);
+  w.pos = carve_ptr<uint32_t>(q, S + 2);
+  w.ek = carve_ptr<uint64_t>(q, S); w.lr = carve_ptr<uint16_t>(q, 2 * S + 2);
+  if (BIG) {
+    if (far_bytes) *far_bytes = (size_t)(q - far);
+  } else {
+    p = q;
+    if (far_bytes) *far_bytes = 0;
+  }
   return (size_t)(p - base);
 }
 
@@ -806,7 +818,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       in.identity = 0;
       if (prefetch) {
         in.Vc = pre_cnt;
-        if (tid < in.Vc) { w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = tid; }
+        if (tid < in.Vc) { w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid; }
         if (t + 1 < len) {
           pre_cnt = pr->cnt[t + 1];
           if (tid < width) { pre_ch = pr->ch[(size_t)(t + 1) * width + tid]; pre_lp = pr->lp[(size_t)(t + 1) * width + tid]; }
@@ -817,7 +829,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
           const int c = pr->ch[(size_t)t * width + r];
           w.cch[r] = c;
           w.clp[r] = pr->lp[(size_t)t * width + r];
-          w.rank_of[c] = r;
+          w.rank_of[c] = (int16_t)r;
         }
       }
       x.sync();

@@ -191,13 +191,15 @@ struct KernelArgs {
   float *out_score;
   int32_t *status;          // [B]
   long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
+  char *far;                // BIG layout: per-utterance HBM scratch, far_stride bytes each
+  long long far_stride;
   const int *pr_cnt;        // pruned mode: [B, T] candidates per frame (null in identity mode)
   const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
   const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
   int pr_stride;
 };
 
-template <bool PROF>
+template <bool PROF, bool BIG>
 __global__ void ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -205,7 +207,7 @@ __global__ void ctc_beam_decode_kernel(KernelArgs a) {
   const int b = (int)blockIdx.x;
   if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
   Work w;
-  carve(w, smem, a.dims);
+  carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
   __shared__ long long prof[16];
   if (PROF && threadIdx.x < 16) prof[threadIdx.x] = 0;
   DevX<PROF> x{red, 0, prof, 0};
@@ -437,7 +439,7 @@ struct ctcd_decoder {
   int device = 0;
   int threads = 512;
   int max_lds = 0;
-  Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp;
+  Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far;
   long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
   bool tables_ready = false;
   bool timing = false;
@@ -519,7 +521,7 @@ const char *ctcd_version(void) { return "ctcdecode_amd 0.1 (gfx950)"; }
 int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob) {
   if (beam <= 0 || V <= 0 || cutoff_top_n <= 0) return CTCD_EINVAL;
   Work w;
-  const size_t n = carve(w, nullptr, make_dims(beam, V, cutoff_top_n, cutoff_prob));
+  const size_t n = carve<false>(w, nullptr, nullptr, make_dims(beam, V, cutoff_top_n, cutoff_prob), nullptr);
   return n > 0x7fffffffu ? 0x7fffffff : (int)n;
 }
 
@@ -542,7 +544,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   (void)hipSetDevice(d->device);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
-  d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release();
+  d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release();
   delete d;
 }
 
@@ -565,10 +567,19 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
   const Dims dims = make_dims(beam, V, cutoff_top_n, cutoff_prob);
   if (dims.S_max() > 65535)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) exceeds 65535 candidate slots");
+  if (dims.use_rank_table && V > 32767) return fail(CTCD_EUNSUPPORTED, "vocabulary pruning with more than 32767 labels");
   Work wtmp;
-  const size_t lds = carve(wtmp, nullptr, dims);
-  if (lds + 1024 > (size_t)d->max_lds)
+  size_t far_bytes = 0;
+  size_t lds = carve<false>(wtmp, nullptr, nullptr, dims, nullptr);
+  bool big = false;
+  if (lds + 2048 > (size_t)d->max_lds) {  // wide beam: rare-path arrays go to HBM scratch
+    big = true;
+    lds = carve<true>(wtmp, nullptr, nullptr, dims, &far_bytes);
+    far_bytes = (far_bytes + 255) / 256 * 256;
+  }
+  if (lds + 2048 > (size_t)d->max_lds)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) needs " + std::to_string(lds) + " B of LDS, more than one workgroup has");
+  if (big && (rc = d->far.ensure((size_t)B * far_bytes))) return rc;
 
   // outputs: everything outside the valid region is defined as 0
   const size_t kt = (size_t)B * beam * T;
@@ -676,13 +687,13 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
     if ((rc = d->prof.ensure((size_t)B * 16 * 8))) return rc;
     a.prof = (long long *)d->prof.p;
   }
-  const void *fn = d->profile ? (const void *)ctc_beam_decode_kernel<true> : (const void *)ctc_beam_decode_kernel<false>;
+  a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
+  const void *fn = d->profile ? (big ? (const void *)ctc_beam_decode_kernel<true, true> : (const void *)ctc_beam_decode_kernel<true, false>)
+                              : (big ? (const void *)ctc_beam_decode_kernel<false, true> : (const void *)ctc_beam_decode_kernel<false, false>);
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
-  if (d->profile)
-    hipLaunchKernelGGL(ctc_beam_decode_kernel<true>, dim3(B), dim3(d->threads), lds, stream, a);
-  else
-    hipLaunchKernelGGL(ctc_beam_decode_kernel<false>, dim3(B), dim3(d->threads), lds, stream, a);
+  void *kargs[] = {&a};
+  HIP_TRY(hipLaunchKernel(fn, dim3(B), dim3(d->threads), kargs, lds, stream));
   HIP_TRY(hipGetLastError());
   if (d->timing) HIP_TRY(hipEventRecord(d->ev1, stream));
   return CTCD_OK;

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
 #include <thread>
 #include <vector>
@@ -101,7 +102,10 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
   std::atomic<int> next{0}, bad{0};
   auto work = [&] {
     Work w;
-    std::vector<char> mem(carve(w, nullptr, d) + 64);
+    size_t far_bytes = 0;
+    const bool big = getenv("CTC_HOST_BIG") != nullptr;  // exercise the HBM-scratch layout too
+    std::vector<char> mem((big ? carve<true>(w, nullptr, nullptr, d, &far_bytes) : carve<false>(w, nullptr, nullptr, d, &far_bytes)) + 64);
+    std::vector<char> far(far_bytes + 64);
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
     std::vector<int> pcnt(T), pch((size_t)T * d.Vc_max);
     std::vector<float> plp((size_t)T * d.Vc_max);
@@ -110,7 +114,7 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
       if (b >= B) return;
       int len = seq_lens ? seq_lens[b] : T;
       len = std::max(0, std::min(len, T));
-      carve(w, mem.data(), d);
+      if (big) carve<true>(w, mem.data(), far.data(), d, nullptr); else carve<false>(w, mem.data(), nullptr, d, nullptr);
       HostX x;
       const float *rows = probs + (size_t)b * T * V;
       PrunedRows pr{pcnt.data(), pch.data(), plp.data(), d.Vc_max};

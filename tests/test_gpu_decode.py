@@ -164,6 +164,41 @@ def test_north_star_shape_parity_and_properties(torch_mod):
         assert len(seen) == K
 
 
+def test_wide_beam_hbm_scratch_layout(torch_mod):
+    """beam_width=500 (BASELINE.json configs[2] per-utterance shape): the per-slot rare-path arrays move to HBM scratch."""
+    for seed, T, quant in [(71, 150, None), (72, 120, 0.5)]:
+        lp = ou.synth_logprobs(2, T, 29, seed, quant=quant)
+        want = ou.decode(lp, beam=500, which="restated")
+        got = _decode(torch_mod, lp, beam=500)
+        ou.assert_same(_with_nres(got, want), want, "K=500 seed %d" % seed)
+
+
+def test_config3_shape_long_wide(torch_mod):
+    """T=2000, beam_width=500 (configs[2] is B=2048 over 8 GPUs = 256 such utterances per GPU): 6 utterances, all checked."""
+    lp = ou.synth_logprobs(6, 2000, 29, 81)
+    got = _decode(torch_mod, lp, beam=500)
+    want = ou.decode(lp, beam=500, which="restated")
+    ou.assert_same(_with_nres(got, want), want, "configs[2] shape")
+
+
+def test_config4_shape_large_vocab(torch_mod):
+    """BASELINE.json configs[3]: V=10000, beam_width=100, cutoff_top_n=40, cutoff_prob=0.99, B=64, T=500; a sample of the
+    items is checked bit-exact against the oracle (its per-frame std::sort of 10k values makes the CPU side slow)."""
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    B, T, V, K = 64, 500, 10000, 100
+    lp = ou.synth_logprobs(B, T, V, 91)
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=40, cutoff_prob=0.99, beam_width=K, log_probs_input=True)
+    out, sc, ts, ln = dec.decode(torch_mod.from_numpy(lp))
+    got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+    sample = [0, 1, 31, 63]
+    want = ou.decode(lp[sample], beam=K, cutoff_top_n=40, cutoff_prob=0.99, which="restated")
+    ou.assert_same(_with_nres({k: v[sample] for k, v in got.items()}, want), want, "configs[3] sample")
+    assert (np.diff(got["scores"], axis=1) >= 0).all()
+    print("configs[3]: frames resolved on the host:", n.lib.ctcd_last_prune_host_rows(dec._handle), "of", B * T)
+
+
 def test_empty_and_degenerate_batches(torch_mod):
     import ctcdecode_amd
 
