@@ -1,0 +1,91 @@
+"""The N>1 path (ctcdecode_amd/distributed.py) with world_size 2 over gloo on the CPU.  The per-rank decode is stood in
+for by the oracle (there is no GPU here); what is tested is the sharding arithmetic and the gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import oracle_util as ou
+
+    # the module under test has no GPU dependency of its own; import it without the package __init__ (which needs HIP)
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ctcd_distributed", os.path.join(ROOT, "ctcdecode_amd", "distributed.py"))
+    dd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dd)
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, V, K = 40, 9, 6
+    lp = torch.from_numpy(ou.synth_logprobs(B, T, V, 77))
+    sl = torch.tensor([(7 * i) % (T + 3) for i in range(B)], dtype=torch.int32)
+
+    def decode_fn(p, s):
+        r = ou.decode(p.numpy(), s.numpy() if s is not None else None, beam=K, threads=1)
+        return (torch.from_numpy(r["tokens"]), torch.from_numpy(r["scores"]), torch.from_numpy(r["timesteps"]), torch.from_numpy(r["lens"]))
+
+    got = dd.decode_sharded(decode_fn, lp, sl, dst=0)
+    ok = True
+    if rank == 0:
+        want = ou.decode(lp.numpy(), sl.numpy(), beam=K, threads=1)
+        ok = (np.array_equal(got[0].numpy(), want["tokens"]) and np.array_equal(got[1].numpy().view(np.uint32), want["scores"].view(np.uint32))
+              and np.array_equal(got[2].numpy(), want["timesteps"]) and np.array_equal(got[3].numpy(), want["lens"]))
+    else:
+        ok = got is None
+    lo, hi = dd.shard_bounds(B, world, rank)
+    ok = ok and 0 <= lo <= hi <= B
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [5, 4, 1])
+def test_sharded_decode_gloo_world2(B):
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_worker, args=(r, world, port, B, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_bounds_cover_the_batch():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ctcd_distributed", os.path.join(ROOT, "ctcdecode_amd", "distributed.py"))
+    dd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dd)
+    for B in [0, 1, 7, 8, 255, 256, 2048]:
+        for world in [1, 2, 4, 8]:
+            seen = []
+            for r in range(world):
+                lo, hi = dd.shard_bounds(B, world, r)
+                seen += list(range(lo, hi))
+            assert seen == list(range(B))
