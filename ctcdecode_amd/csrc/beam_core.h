@@ -86,10 +86,14 @@ struct Dims {
   CTC_HD int S_max() const { return K * (2 + Vc_max); }
 };
 
+// LDS scalars.  The per-step counters exist twice (index by step parity) so that a step can reset the other set for
+// the step after next without racing with threads that still read this one.
 enum {
-  VAR_N = 0, VAR_POOL, VAR_DMIN, VAR_STATUS, VAR_MAXKEY, VAR_WLOG,          // persistent across steps
-  VAR_NPIN, VAR_LCOUNT, VAR_FB0, VAR_FB1, VAR_FB2, VAR_FB3, VAR_CUT,       // scratch within a step
-  VAR_TAU, VAR_TAUC, VAR_G, VAR_E, VAR_SCOUNT, VAR_NDMIN, VAR_NMAXKEY, VAR_COUNT = 24
+  VAR_STATUS = 0,
+  VAR_FB0, VAR_FB1, VAR_FB2, VAR_FB3, VAR_CUT, VAR_TAU, VAR_TAUC, VAR_G, VAR_E, VAR_TIE,
+  VAR_PAR0 = 12,  // first per-parity set
+  P_NPIN = 0, P_LCOUNT, P_SCOUNT, P_NDMIN, P_NMAXKEY, P_SIZE = 6,
+  VAR_COUNT = VAR_PAR0 + 2 * P_SIZE
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
 constexpr int kBinsLog = 10;
@@ -110,6 +114,7 @@ struct Work {
   uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition
   int *bins;       // kBins
   uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
+  int *lslot;      // kListCap: their slots
   int *fin, *sstack;
   int *vars;
 };
@@ -147,6 +152,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.skey = carve_ptr<uint32_t>(p, S);
   w.surv = carve_ptr<int>(p, 3 * K + 4);
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
+  w.lslot = carve_ptr<int>(p, kListCap + 4);
   w.fin = carve_ptr<int>(p, K);
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
@@ -175,9 +181,7 @@ struct StepIn {
 CTC_HD int bin_index(int b) { return b + (b >> 4); }
 
 CTC_HD int ceil_log2_u64(uint64_t v) {  // smallest s with (1 << s) >= v, v >= 1
-  int s = 0;
-  while (s < 63 && ((uint64_t)1 << s) < v) ++s;
-  return s;
+  return v <= 1 ? 0 : 64 - __builtin_clzll(v - 1);
 }
 
 template <class X>
@@ -195,6 +199,15 @@ struct Decoder {
 
   CTC_HD float lse(float a, float b) const { return ctcmath::lse(a, b, tbl); }
 
+  // Step-to-step state, identical in every thread (kept in registers, not LDS)
+  int st_n = 1, st_pool = 1, st_dmin = 0, st_wlog = 32;
+  uint32_t st_maxkey = 0;
+
+  CTC_HD int *pvars(int t) const { return w.vars + VAR_PAR0 + (t & 1) * P_SIZE; }
+  CTC_HD void reset_pvars(int *pv) const {
+    pv[P_NPIN] = 0; pv[P_LCOUNT] = 0; pv[P_SCOUNT] = 0; pv[P_NDMIN] = kIntMax; pv[P_NMAXKEY] = 0;
+  }
+
   // ctc_beam_search_decoder.cpp:43-44 : root prefix, score = log_prob_b_prev = 0
   CTC_HD void init() {
     if (x.tid() == 0) {
@@ -204,13 +217,18 @@ struct Decoder {
       b.bprev[0] = 0.f; b.nbprev[0] = CTC_NEG_MAX; b.score[0] = 0.f; b.lpc[0] = CTC_NEG_MAX;
       PoolNode r; r.parent = -1; r.ch = -1; r.tstep = 0; r.lpc = CTC_NEG_MAX;
       pool[0] = r;
-      w.vars[VAR_N] = 1; w.vars[VAR_POOL] = 1; w.vars[VAR_DMIN] = 0; w.vars[VAR_STATUS] = ST_OK;
-      w.vars[VAR_MAXKEY] = (int)ord_f32(0.f);
-      w.vars[VAR_WLOG] = 32;  // first select looks at the whole key range
+      w.vars[VAR_STATUS] = ST_OK;
+      reset_pvars(pvars(0));
+      reset_pvars(pvars(1));
     }
+    st_n = 1; st_pool = 1; st_dmin = 0; st_wlog = 32;  // first select looks at the whole key range
+    st_maxkey = ord_f32(0.f);
+    for (int i = x.tid(); i < kBins + kBins / 16; i += x.nt()) w.bins[i] = 0;
+    for (int i = x.tid(); i < 2 * d.K; i += x.nt()) w.hit[i] = 0;
+    for (int i = x.tid(); i < d.K; i += x.nt()) w.surv[d.K + i] = 0;
     if (d.use_rank_table)
       for (int c = x.tid(); c < d.V; c += x.nt()) w.rank_of[c] = -1;
-    x.sync();
+    x.sync_full();
   }
 
   CTC_HD int rank_of_char(const StepIn &in, int c) const {
@@ -229,54 +247,77 @@ struct Decoder {
   CTC_HD uint64_t slot_key48(int s) const { return key48(w.skey[s], w.sinfo[s]); }
 
   // ------------------------------------------------------------------------------------------------------ select
-  // K-th largest SCORE key (32 bit) among the S slots (holes have key 0): histogram over a window below the previous
-  // best key, then an exact rank inside the one bucket that holds it.  Leaves tau (VAR_TAU), G = #keys > tau and
-  // E = #keys == tau in vars.  Precondition: bins[] zeroed, VAR_LCOUNT == 0.
-  CTC_HD void select_kth(int S, int K) {
+  // Window of the first histogram round: [lo, 2^32) in score-key units, buckets of 2^shift keys, top bucket open.
+  struct Window { uint32_t lo; int shift; };
+  CTC_HD Window first_window() const {
+    Window wd;
+    uint64_t lo = 1, width = (uint64_t)1 << 32;
+    if (st_wlog < 32) {
+      width = (uint64_t)1 << st_wlog;
+      if (width <= (uint64_t)st_maxkey) lo = (uint64_t)st_maxkey - width + 1;
+    }
+    wd.lo = (uint32_t)lo;
+    wd.shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
+    return wd;
+  }
+  CTC_HD void hist_add(const Window &wd, uint32_t key) const {  // first-round histogram contribution of one candidate
+    if (key >= wd.lo) {
+      const uint32_t bk = (key - wd.lo) >> wd.shift;
+      x.atomic_add(&w.bins[bin_index(bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1)], 1);
+    }
+  }
+
+  // K-th largest SCORE key (32 bit) among the S slots (holes have key 0).  The first-round histogram (window
+  // first_window()) has already been accumulated in bins[].  Leaves tau (VAR_TAU), G = #keys > tau, E = #keys == tau.
+  // Fast path (one round, bucket small enough): the pass that lists the bucket's keys also appends every key above
+  // the bucket to the survivor list, and the ranking threads append the bucket's own survivors, so that no further
+  // pass over the slots is needed; returns true then (VAR_TIE says whether the K boundary splits equal SCORES, in
+  // which case the caller discards that list).  Precondition: pv[P_LCOUNT] == pv[P_SCOUNT] == 0.
+  CTC_HD bool select_kth(int S, int K, int *pv) {
     const int tid = x.tid(), nt = x.nt();
-    const uint32_t maxkey = (uint32_t)w.vars[VAR_MAXKEY];
-    const int wlog = w.vars[VAR_WLOG];
-    uint64_t lo = 1, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
-    if (wlog < 32 && ((uint64_t)1 << wlog) <= (uint64_t)maxkey) lo = (uint64_t)maxkey - ((uint64_t)1 << wlog) + 1;
+    const Window wd = first_window();
+    uint64_t lo = wd.lo, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
+    int shift = wd.shift;
     int need = K, gbase = 0;
     bool first = true;
     for (;;) {
-      uint64_t width = hi - lo;
-      if (first && wlog < 32) width = (uint64_t)1 << wlog;  // buckets sized for the window; the top bucket is open-ended
-      const int shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
-      const uint32_t lo32 = (uint32_t)lo, span = (uint32_t)(hi - lo - 1);  // key in range <=> key - lo32 <= span
-      for (int s = tid; s < S; s += nt) {
-        const uint32_t dk = w.skey[s] - lo32;
-        if (w.skey[s] >= lo32 && dk <= span) {
-          const uint32_t bk = dk >> shift;
-          x.atomic_add(&w.bins[bin_index(bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1)], 1);
-        }
-      }
-      x.sync();
-      x.mark(12);
       // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
       //    [2] #keys in the window, [3] #keys in b*.  Also re-zeroes bins[] and ends with a barrier.
       x.find_bucket(w.bins, need, &w.vars[VAR_FB0]);
-      const int bstar = w.vars[VAR_FB0], above = w.vars[VAR_FB1], total = w.vars[VAR_FB2], inb = w.vars[VAR_FB3];
+      const int bstar = x.uni(w.vars[VAR_FB0]), above = x.uni(w.vars[VAR_FB1]), total = x.uni(w.vars[VAR_FB2]), inb = x.uni(w.vars[VAR_FB3]);
       x.mark(13);
-      first = false;
+      uint64_t blo = 0, bhi = 0;
+      bool again = true;
       if (bstar < 0) {  // the K-th key lies below the window: look at everything under it
         gbase += total; need -= total; hi = lo; lo = 1;
-        continue;
+      } else {
+        blo = lo + ((uint64_t)bstar << shift);
+        bhi = (bstar == kBins - 1) ? hi : blo + ((uint64_t)1 << shift);
+        if (bhi > hi) bhi = hi;  // keys at or above hi are already counted in gbase
+        if (shift == 0 && bstar < kBins - 1) {  // the bucket is a single key value
+          if (tid == 0) { w.vars[VAR_TAU] = (int)(uint32_t)blo; w.vars[VAR_G] = gbase + above; w.vars[VAR_E] = inb; }
+          x.sync();
+          return false;
+        }
+        if (inb <= kListCap) again = false;
+        else { gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
       }
-      const uint64_t blo = lo + ((uint64_t)bstar << shift);
-      uint64_t bhi = (bstar == kBins - 1) ? hi : blo + ((uint64_t)1 << shift);
-      if (bhi > hi) bhi = hi;  // keys at or above hi are already counted in gbase
-      if (shift == 0 && bstar < kBins - 1) {  // the bucket is a single key value
-        if (tid == 0) { w.vars[VAR_TAU] = (int)(uint32_t)blo; w.vars[VAR_G] = gbase + above; w.vars[VAR_E] = inb; }
-        x.sync();
-        return;
-      }
-      if (inb <= kListCap) {  // exact rank inside the bucket, on offsets from its base
+      if (!again) {  // exact rank inside the bucket, on offsets from its base
         const uint32_t b32 = (uint32_t)blo, bspan = (uint32_t)(bhi - blo - 1);
+        const bool direct = first;  // single round: everything above the bucket survives, collect it right here
+        if (tid == 0) w.vars[VAR_TIE] = 0;
         for (int s = tid; s < S; s += nt) {
-          const uint32_t k = w.skey[s], dk = k - b32;
-          if (k >= b32 && dk <= bspan) w.list[x.atomic_add(&w.vars[VAR_LCOUNT], 1)] = dk + 1u;
+          const uint32_t k = w.skey[s];
+          if (k < b32) continue;
+          const uint32_t dk = k - b32;
+          if (dk <= bspan) {
+            const int li = x.atomic_add(&pv[P_LCOUNT], 1);
+            w.list[li] = dk + 1u;
+            w.lslot[li] = s;
+          } else if (direct) {
+            const int si = x.atomic_add(&pv[P_SCOUNT], 1);
+            if (si < K) w.surv[si] = s;
+          }
         }
         for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
         x.sync();
@@ -292,12 +333,29 @@ struct Decoder {
           }
           if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
             w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gbase + above + g; w.vars[VAR_E] = e;
+            if (g + e > want) w.vars[VAR_TIE] = 1;
+          }
+          if (direct && g < want) {  // key >= tau (with equal scores at the boundary more than K qualify: the caller
+            const int si = x.atomic_add(&pv[P_SCOUNT], 1);  // discards the list then)
+            if (si < K) w.surv[si] = w.lslot[q];
           }
         }
         x.sync();
-        return;
+        return direct;
       }
-      gbase += above; need -= above; lo = blo; hi = bhi;  // too crowded: histogram the bucket itself
+      // another histogram round over [lo, hi)
+      first = false;
+      const uint64_t width = hi - lo;
+      shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
+      const uint32_t lo32 = (uint32_t)lo, span = (uint32_t)(hi - lo - 1);  // key in range <=> key - lo32 <= span
+      for (int s = tid; s < S; s += nt) {
+        const uint32_t k = w.skey[s], dk = k - lo32;
+        if (k >= lo32 && dk <= span) {
+          const uint32_t bk = dk >> shift;
+          x.atomic_add(&w.bins[bin_index(bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1)], 1);
+        }
+      }
+      x.sync();
     }
   }
 
@@ -305,13 +363,13 @@ struct Decoder {
   // m of the E candidates with score key tau must survive.  Sets VAR_TAUC (smallest surviving inverted-character
   // code) and returns true when that cut is unambiguous; false when it would split a group of equivalent prefixes
   // (or the group is too large to rank here): the caller then replays std::nth_element.
-  CTC_HD bool resolve_by_character(int S, uint32_t tau, int m, int E) {
+  CTC_HD bool resolve_by_character(int S, uint32_t tau, int m, int E, int *pv) {
     const int tid = x.tid(), nt = x.nt();
     if (E > kListCap) return false;
-    if (tid == 0) { w.vars[VAR_LCOUNT] = 0; w.vars[VAR_CUT] = 0; }
+    if (tid == 0) { pv[P_LCOUNT] = 0; w.vars[VAR_CUT] = 0; }
     x.sync();
     for (int s = tid; s < S; s += nt)
-      if (w.skey[s] == tau) w.list[x.atomic_add(&w.vars[VAR_LCOUNT], 1)] = (w.sinfo[s] >> 16) + 1u;
+      if (w.skey[s] == tau) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = (w.sinfo[s] >> 16) + 1u;
     x.sync();
     for (int q = tid; q < E; q += nt) {
       const uint32_t mine = w.list[q];
@@ -324,7 +382,7 @@ struct Decoder {
       if (g < m && m <= g + e) { w.vars[VAR_TAUC] = (int)(mine - 1u); w.vars[VAR_CUT] = (g + e == m) ? 1 : 2; }
     }
     x.sync();
-    return w.vars[VAR_CUT] == 1;
+    return x.uni(w.vars[VAR_CUT]) == 1;
   }
 
   // min of lcp[] over (lo, hi] of the CURRENT beam (depth of the lowest common ancestor of entries lo and hi)
@@ -395,7 +453,7 @@ struct Decoder {
         }
       }
       x.sync();
-      const int cut = w.vars[VAR_CUT];
+      const int cut = x.uni(w.vars[VAR_CUT]);
       if (cut <= K) first = cut; else last = cut;
     }
     if (tid == 0) stlemu::introselect(v, first, K, last, depth, before);
@@ -408,59 +466,50 @@ struct Decoder {
     Beam &b = w.cur;
     Beam &nb = w.nxt;
     const int tid = x.tid(), nt = x.nt();
-    const int n = w.vars[VAR_N];
-    const int pool_count = w.vars[VAR_POOL];
-    const int dmin = w.vars[VAR_DMIN];
+    const int n = st_n, pool_count = st_pool, dmin = st_dmin;
     const int K = d.K;
     const int Vc = in.Vc, brank = in.blank_rank;
     const int Vnb = Vc - (brank >= 0 ? 1 : 0);
     const int S = n * (2 + Vnb);
-    const float lp_blank = brank >= 0 ? w.clp[brank] : CTC_NEG_MAX;
+    const float lp_blank = brank >= 0 ? x.unif(w.clp[brank]) : CTC_NEG_MAX;
     const bool small_vocab = Vnb <= 64;  // existing children fit a 64-bit mask per parent
+    int *pv = pvars(in.t);
+    int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
+    const Window wd = first_window();
 
-    // ---- A1: subtree ends and nearest in-beam ancestors from the LCP array
+    // ---- A1: per beam entry, from the LCP array alone: end of its subtree range and nearest in-beam ancestor
     for (int j = tid; j < n; j += nt) {
       const int dj = b.dep[j];
       int q = j + 1;
       while (q < n && b.lcp[q] >= dj) ++q;
-      w.e[j] = q;
-      int a = -1, m = kIntMax;
+      int P = -1, m = kIntMax;
       for (int i = j - 1; i >= 0; --i) {
         const int l = b.lcp[i + 1];
         m = l < m ? l : m;
-        if (m < dmin) break;
-        if (b.dep[i] <= m) { a = i; break; }
+        if (m < dmin) break;           // no beam entry is shallower than dmin: nothing further back can be an ancestor
+        if (b.dep[i] <= m) { P = i; break; }
       }
-      w.anc[j] = a;
-      w.hit[2 * j] = 0;
-      w.hit[2 * j + 1] = 0;
-    }
-    for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
-    if (tid == 0) {
-      w.vars[VAR_NPIN] = 0; w.vars[VAR_LCOUNT] = 0; w.vars[VAR_SCOUNT] = 0;
-      w.vars[VAR_NDMIN] = kIntMax; w.vars[VAR_NMAXKEY] = 0;
+      w.e[j] = q;
+      w.anc[j] = P;
     }
     x.sync();
-    x.mark(0);
-
-    // ---- A2: slot offsets; which children of in-beam parents already exist (in the beam, or dead-interior)
+    // ---- A2: Euler-tour slot offsets; which children of in-beam parents already exist
     int npin = 0;
     for (int j = tid; j < n; j += nt) {
+      const int dj = b.dep[j], q = w.e[j], P = w.anc[j];
       int a = 0;
-      for (int i = w.anc[j]; i >= 0; i = w.anc[i]) ++a;
-      const int ej = w.e[j];
+      for (int i = P; i >= 0; i = w.anc[i]) ++a;
       w.ostart[j] = 2 * j + Vnb * (j - a);
-      w.cstart[j] = 2 * ej + Vnb * (ej - 1 - a);
-      const int P = w.anc[j];
+      w.cstart[j] = 2 * q + Vnb * (q - 1 - a);
       int hv = 0, pr = -1, rr = -1;
       if (P >= 0) {
-        if (b.dep[P] == b.dep[j] - 1) {                      // parent in the beam: "hit" (path_trie.cpp:40-48)
+        if (b.dep[P] == dj - 1) {                            // parent in the beam: "hit" (path_trie.cpp:40-48)
           pr = rank_of_char(in, b.ch[j]);
         } else {
           // dead-interior child X of the nearest in-beam ancestor on the way down to j (alive because j is below it)
           hv = 1;
           if (b.viaanc[j] != b.node[P]) {
-            int hops = b.dep[j] - b.dep[P] - 1, xn = b.node[j];
+            int hops = dj - b.dep[P] - 1, xn = b.node[j];
             for (int h = 0; h < hops; ++h) xn = pool[xn].parent;
             b.via[j] = xn;
             b.viaanc[j] = b.node[P];
@@ -480,11 +529,11 @@ struct Decoder {
       w.revr[j] = rr;
       npin += pr >= 0;
     }
-    x.wave_add(&w.vars[VAR_NPIN], npin);
+    x.wave_add(&pv[P_NPIN], npin);
     x.sync();
-    x.mark(1);
+    x.mark(0);
 
-    // ---- B: score every candidate and lay it out in DFS (Euler-tour) slot order.
+    // ---- B: score every candidate, lay it out in DFS (Euler-tour) slot order and count it into the select histogram.
     // B1 (beam entries themselves + revived children) and B2 (brand-new children) are independent: with enough
     // waves they run side by side on disjoint threads.
     const int n1 = (n + 63) & ~63;
@@ -496,7 +545,7 @@ struct Decoder {
         const float sc = b.score[j], nbp = b.nbprev[j];
         float bcur = brank >= 0 ? lp_blank + sc : CTC_NEG_MAX;             // :97-101
         float nbcur = CTC_NEG_MAX;
-        if (r >= 0) nbcur = lse(nbcur, w.clp[r] + nbp);                     // :103-106
+        if (r >= 0) nbcur = w.clp[r] + nbp;  // :103-106 -- log_sum_exp(-FLT_MAX, y) returns y (decoder_utils.h:50)
         const int P = w.anc[j];
         const int pr = w.pinr[j];
         if (pr >= 0) {
@@ -529,8 +578,10 @@ struct Decoder {
           k0 = ord_f32(child_logp(P, cx, lp));
           i0 = mk_info(cx, T_REVIVED, j);
         }
+        const uint32_t k1 = ord_f32(ns);
         w.skey[s0] = k0; w.sinfo[s0] = i0;
-        w.skey[s0 + 1] = ord_f32(ns); w.sinfo[s0 + 1] = mk_info(c, T_SELF, j);
+        w.skey[s0 + 1] = k1; w.sinfo[s0 + 1] = mk_info(c, T_SELF, j);
+        if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
       }
     }
     if (!split || tid >= n1) {
@@ -548,8 +599,10 @@ struct Decoder {
           for (int i = t2 >> sh; i < n; i += ng) {
             const int s = w.cstart[i] + rn;
             const bool exists = (w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u;
-            w.skey[s] = exists ? 0u : ord_f32(child_logp(i, c, lp));
+            const uint32_t k = exists ? 0u : ord_f32(child_logp(i, c, lp));
+            w.skey[s] = k;
             w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
+            hist_add(wd, k);
           }
         }
       } else {
@@ -559,13 +612,15 @@ struct Decoder {
           const int c = in.identity ? r : w.cch[r];
           const int s = w.cstart[i] + rn;
           const bool exists = small_vocab && ((w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u);
-          w.skey[s] = exists ? 0u : ord_f32(child_logp(i, c, w.clp[r]));
+          const uint32_t k = exists ? 0u : ord_f32(child_logp(i, c, w.clp[r]));
+          w.skey[s] = k;
           w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
+          if (small_vocab) hist_add(wd, k);
         }
       }
     }
     x.sync();
-    if (!small_vocab) {  // children that already exist leave a hole in their parent's group
+    if (!small_vocab) {  // children that already exist leave a hole in their parent's group; then the histogram
       for (int j = tid; j < n; j += nt) {
         const int r = w.pinr[j] >= 0 ? w.pinr[j] : w.revr[j];
         if (r >= 0) {
@@ -574,27 +629,36 @@ struct Decoder {
         }
       }
       x.sync();
+      for (int s = tid; s < S; s += nt) hist_add(wd, w.skey[s]);
+      x.sync();
     }
     x.mark(2);
 
     // ---- C: the K-th best key.  #candidates = beam entries + new children - children that already exist as entries
-    const int N = n * (1 + Vnb) - w.vars[VAR_NPIN];
+    const int N = n * (1 + Vnb) - x.uni(pv[P_NPIN]);
     uint32_t tau = 0, tauc = 0;
-    bool exact = false;
+    bool exact = false, have_survivors = false;
+    if (tid == 0) reset_pvars(pvars(in.t + 1));  // the other parity set: free since the end of the previous step
+    for (int i = tid; i < 2 * n; i += nt) w.hit[i] = 0;  // all readers of hit[] are behind the barrier above
+    for (int i = tid; i < K; i += nt) rk[i] = 0;
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
-      select_kth(S, K);
-      tau = (uint32_t)w.vars[VAR_TAU];
-      const int E = w.vars[VAR_E], m = K - w.vars[VAR_G];
+      have_survivors = select_kth(S, K, pv) && x.uni(w.vars[VAR_TIE]) == 0;
+      tau = (uint32_t)x.uni(w.vars[VAR_TAU]);
+      const int E = x.uni(w.vars[VAR_E]), m = K - x.uni(w.vars[VAR_G]);
       if (E > m) {
-        if (resolve_by_character(S, tau, m, E)) tauc = (uint32_t)w.vars[VAR_TAUC];
+        have_survivors = false;
+        if (resolve_by_character(S, tau, m, E, pv)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);
         else exact = true;  // the boundary splits a group of equivalent prefixes
       }
       if (last) exact = true;  // decode() sorts the array exactly as nth_element left it (:164-190)
+    } else {
+      // nothing to prune; the histogram was filled for nothing: clear it for the next step
+      for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
     }
     x.mark(5);
 
-    // ---- D: who survives.  Normally a flag pass; when the outcome depends on it, an exact replay of std::nth_element.
-    int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
+    // ---- D: who survives, when the select pass could not already tell (no pruning, score ties at the boundary,
+    // several select rounds) -- a flag pass; or, when the outcome depends on it, an exact replay of std::nth_element.
     if (exact) {
       for (int s = tid; s <= S; s += nt) w.pos[s] = (s < S && info_type(w.sinfo[s]) != T_HOLE) ? 1u : 0u;
       x.sync();
@@ -606,15 +670,17 @@ struct Decoder {
       for (int k = tid; k < K; k += nt) surv[k] = (int)(w.ek[k] & 0xFFFFu);
       x.sync();
       x.mark(6);
-    } else {
+    } else if (!have_survivors) {
+      if (tid == 0) pv[P_SCOUNT] = 0;
+      x.sync();
       for (int s0 = 0; s0 < S; s0 += nt) {  // every thread takes part in every round (wave-aggregated append)
         const int s = s0 + tid;
         bool keep = false;
         if (s < S) {
-          const uint32_t k = w.skey[s], inf = w.sinfo[s];
-          keep = (N <= K) ? (info_type(inf) != T_HOLE) : (k > tau || (k == tau && (inf >> 16) >= tauc));
+          const uint32_t k = w.skey[s];
+          keep = (N <= K) ? (k != 0u) : (k > tau || (k == tau && (w.sinfo[s] >> 16) >= tauc));
         }
-        const int idx = x.append(&w.vars[VAR_SCOUNT], keep);
+        const int idx = x.append(&pv[P_SCOUNT], keep);
         if (keep) surv[idx] = s;
       }
       x.sync();
@@ -624,10 +690,8 @@ struct Decoder {
 
     // ---- E: rank the survivors by slot (= DFS order), then one thread per survivor builds the next beam entry.
     {
-      const int parts = nt / n_new > 0 ? (nt / n_new < 16 ? nt / n_new : 16) : 1;  // threads per survivor
-      if (parts > 1) {
-        for (int q = tid; q < n_new; q += nt) rk[q] = 0;
-        x.sync();
+      const int parts = nt / n_new < 16 ? nt / n_new : 16;  // threads per survivor
+      if (parts >= 2) {
         if (tid < parts * n_new) {
           const int q = tid % n_new, part = tid / n_new;
           const int mine = surv[q];
@@ -635,23 +699,22 @@ struct Decoder {
           for (int o = part; o < n_new; o += parts) r += surv[o] < mine;
           x.atomic_add(&rk[q], r);
         }
-        x.sync();
-        for (int q = tid; q < n_new; q += nt) ord[rk[q]] = q;
       } else {
         for (int q = tid; q < n_new; q += nt) {
           const int mine = surv[q];
           int r = 0;
           for (int o = 0; o < n_new; ++o) r += surv[o] < mine;
           rk[q] = r;
-          ord[r] = q;
         }
       }
+      x.sync();
+      for (int q = tid; q < n_new; q += nt) ord[rk[q]] = q;
     }
     x.sync();
     x.mark(4);
     if (pool_count + n_new > pool_cap) {  // cannot happen when the pool is sized 1 + K*T
       if (tid == 0) w.vars[VAR_STATUS] = ST_POOL_OVERFLOW;
-      x.sync();
+      x.sync_full();
       return;
     }
     int dloc = kIntMax;
@@ -701,32 +764,31 @@ struct Decoder {
       dloc = dd < dloc ? dd : dloc;
       kloc = w.skey[s] > kloc ? w.skey[s] : kloc;
     }
-    x.wave_min_to(&w.vars[VAR_NDMIN], dloc);
-    x.wave_max_to(&w.vars[VAR_NMAXKEY], kloc);
+    x.wave_min_to(&pv[P_NDMIN], dloc);
+    x.wave_max_to(&pv[P_NMAXKEY], kloc);
     if (last && !exact)
       for (int k = tid; k < n_new; k += nt) w.fin[k] = k;
     // un-register this step's candidates from the rank table
     if (!in.identity)
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
-    if (tid == 0) {
-      w.vars[VAR_N] = n_new;
-      w.vars[VAR_POOL] = pool_count + n_new;
-      w.vars[VAR_DMIN] = w.vars[VAR_NDMIN];
+    // every thread advances its copy of the step state
+    {
       // next select window.  It is anchored at this step's best key (an upper bound for the next step's keys when
       // log-probabilities are <= 0) and must reach down to the next K-th key: twice the distance from THIS step's
       // anchor (the previous best key) to this step's K-th key, rounded up to a power of two.
       int wl = 32;
       if (N > K) {
-        const uint32_t anchor = (uint32_t)w.vars[VAR_MAXKEY];
-        const uint32_t gap = anchor > tau ? anchor - tau : 0;
+        const uint32_t gap = st_maxkey > tau ? st_maxkey - tau : 0;
         wl = ceil_log2_u64((uint64_t)gap + 1) + 1;
         wl = wl < 10 ? 10 : (wl > 32 ? 32 : wl);
       }
-      w.vars[VAR_WLOG] = wl;
-      w.vars[VAR_MAXKEY] = w.vars[VAR_NMAXKEY];
+      st_wlog = wl;
+      st_maxkey = (uint32_t)x.uni(pv[P_NMAXKEY]);
+      st_dmin = x.uni(pv[P_NDMIN]);
+      st_n = n_new;
+      st_pool = pool_count + n_new;
     }
-    x.sync();
     x.mark(8);
     Beam t = w.cur; w.cur = w.nxt; w.nxt = t;
   }
@@ -737,7 +799,7 @@ struct Decoder {
                      int32_t *n_results) {
     const Beam &b = w.cur;
     const int tid = x.tid(), nt = x.nt();
-    const int n = w.vars[VAR_N];
+    const int n = st_n;
     const int nres = n < d.K ? n : d.K;
     if (!had_steps)
       for (int k = tid; k < nres; k += nt) w.fin[k] = k;
@@ -817,14 +879,14 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     } else {
       in.identity = 0;
       if (prefetch) {
-        in.Vc = pre_cnt;
+        in.Vc = x.uni(pre_cnt);
         if (tid < in.Vc) { w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid; }
         if (t + 1 < len) {
           pre_cnt = pr->cnt[t + 1];
           if (tid < width) { pre_ch = pr->ch[(size_t)(t + 1) * width + tid]; pre_lp = pr->lp[(size_t)(t + 1) * width + tid]; }
         }
       } else {
-        in.Vc = pr->cnt[t];
+        in.Vc = x.uni(pr->cnt[t]);
         for (int r = tid; r < in.Vc; r += nt) {
           const int c = pr->ch[(size_t)t * width + r];
           w.cch[r] = c;
@@ -833,11 +895,11 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
         }
       }
       x.sync();
-      in.blank_rank = w.rank_of[blank];
+      in.blank_rank = x.uni((int)w.rank_of[blank]);
     }
     x.mark(10);
     dec.step(in, t == len - 1);
-    if (w.vars[VAR_STATUS] != ST_OK) return w.vars[VAR_STATUS];
+    if (x.uni(w.vars[VAR_STATUS]) != ST_OK) return w.vars[VAR_STATUS];
   }
   dec.finish(len > 0, T_stride, out_tok, out_ts, out_score, out_len, n_results);
   x.sync();

@@ -71,6 +71,9 @@ struct DevX {
   // and the pool appends stay in flight across phases).  sync_full() is the fence that also drains global memory.
   __device__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
   __device__ void sync_full() { __syncthreads(); }
+  // a value every thread of the workgroup holds identically -> scalar register (branches/loops on it become scalar)
+  __device__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+  __device__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
   // one LDS atomic per wave
@@ -211,7 +214,7 @@ __global__ void ctc_beam_decode_kernel(KernelArgs a) {
   __shared__ long long prof[16];
   if (PROF && threadIdx.x < 16) prof[threadIdx.x] = 0;
   DevX<PROF> x{red, 0, prof, 0};
-  int len = a.seq_lens ? a.seq_lens[b] : a.T;
+  int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();
   if (PROF) x.last = (long long)wall_clock64();

@@ -21,6 +21,8 @@ struct HostX {
   int nt() const { return 1; }
   void sync() {}
   void sync_full() {}
+  int uni(int v) const { return v; }
+  float unif(float v) const { return v; }
   void mark(int) {}
   int reduce_add(int v) { return v; }
   uint32_t scan_excl(uint32_t *a, int n) {

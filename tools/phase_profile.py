@@ -9,9 +9,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-NAMES = ["A1 subtree ends / ancestors", "A2 slot offsets / existing children", "B score candidates", "D flag survivors", "E1 rank survivors",
-         "C4 select: exact rank in bucket", "D' exact nth_element replay", "(unused)", "E2 emit next beam", "(unused)",
-         "row load", "finish (sorts + back-trace)", "C1 select: histogram", "C2 select: find bucket", "C3 select: gather bucket", "(unused)"]
+NAMES = ["A per-entry LCP scans, slot offsets, existing children", "(unused)", "B score candidates + histogram", "D flag survivors (fallback)", "E1 rank survivors",
+         "C3 select: rank in bucket + survivors", "D' exact nth_element replay", "(unused)", "E2 emit next beam", "(unused)",
+         "row load", "finish (sorts + back-trace)", "(unused)", "C1 select: find bucket", "C2 select: gather bucket + sure survivors", "(unused)"]
 
 
 def main():
