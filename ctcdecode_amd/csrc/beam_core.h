@@ -269,11 +269,8 @@ struct Decoder {
 
   // K-th largest SCORE key (32 bit) among the S slots (holes have key 0).  The first-round histogram (window
   // first_window()) has already been accumulated in bins[].  Leaves tau (VAR_TAU), G = #keys > tau, E = #keys == tau.
-  // Fast path (one round, bucket small enough): the pass that lists the bucket's keys also appends every key above
-  // the bucket to the survivor list, and the ranking threads append the bucket's own survivors, so that no further
-  // pass over the slots is needed; returns true then (VAR_TIE says whether the K boundary splits equal SCORES, in
-  // which case the caller discards that list).  Precondition: pv[P_LCOUNT] == pv[P_SCOUNT] == 0.
-  CTC_HD bool select_kth(int S, int K, int *pv) {
+  // Precondition: pv[P_LCOUNT] == 0.
+  CTC_HD void select_kth(int S, int K, int *pv) {
     const int tid = x.tid(), nt = x.nt();
     const Window wd = first_window();
     uint64_t lo = wd.lo, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
@@ -297,27 +294,16 @@ struct Decoder {
         if (shift == 0 && bstar < kBins - 1) {  // the bucket is a single key value
           if (tid == 0) { w.vars[VAR_TAU] = (int)(uint32_t)blo; w.vars[VAR_G] = gbase + above; w.vars[VAR_E] = inb; }
           x.sync();
-          return false;
+          return;
         }
         if (inb <= kListCap) again = false;
         else { gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
       }
       if (!again) {  // exact rank inside the bucket, on offsets from its base
         const uint32_t b32 = (uint32_t)blo, bspan = (uint32_t)(bhi - blo - 1);
-        const bool direct = first;  // single round: everything above the bucket survives, collect it right here
-        if (tid == 0) w.vars[VAR_TIE] = 0;
         for (int s = tid; s < S; s += nt) {
-          const uint32_t k = w.skey[s];
-          if (k < b32) continue;
-          const uint32_t dk = k - b32;
-          if (dk <= bspan) {
-            const int li = x.atomic_add(&pv[P_LCOUNT], 1);
-            w.list[li] = dk + 1u;
-            w.lslot[li] = s;
-          } else if (direct) {
-            const int si = x.atomic_add(&pv[P_SCOUNT], 1);
-            if (si < K) w.surv[si] = s;
-          }
+          const uint32_t k = w.skey[s], dk = k - b32;
+          if (k >= b32 && dk <= bspan) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = dk + 1u;
         }
         for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
         x.sync();
@@ -333,15 +319,10 @@ struct Decoder {
           }
           if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
             w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gbase + above + g; w.vars[VAR_E] = e;
-            if (g + e > want) w.vars[VAR_TIE] = 1;
-          }
-          if (direct && g < want) {  // key >= tau (with equal scores at the boundary more than K qualify: the caller
-            const int si = x.atomic_add(&pv[P_SCOUNT], 1);  // discards the list then)
-            if (si < K) w.surv[si] = w.lslot[q];
           }
         }
         x.sync();
-        return direct;
+        return;
       }
       // another histogram round over [lo, hi)
       first = false;
@@ -637,16 +618,14 @@ struct Decoder {
     // ---- C: the K-th best key.  #candidates = beam entries + new children - children that already exist as entries
     const int N = n * (1 + Vnb) - x.uni(pv[P_NPIN]);
     uint32_t tau = 0, tauc = 0;
-    bool exact = false, have_survivors = false;
+    bool exact = false;
     if (tid == 0) reset_pvars(pvars(in.t + 1));  // the other parity set: free since the end of the previous step
     for (int i = tid; i < 2 * n; i += nt) w.hit[i] = 0;  // all readers of hit[] are behind the barrier above
-    for (int i = tid; i < K; i += nt) rk[i] = 0;
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
-      have_survivors = select_kth(S, K, pv) && x.uni(w.vars[VAR_TIE]) == 0;
+      select_kth(S, K, pv);
       tau = (uint32_t)x.uni(w.vars[VAR_TAU]);
       const int E = x.uni(w.vars[VAR_E]), m = K - x.uni(w.vars[VAR_G]);
       if (E > m) {
-        have_survivors = false;
         if (resolve_by_character(S, tau, m, E, pv)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);
         else exact = true;  // the boundary splits a group of equivalent prefixes
       }
@@ -657,8 +636,9 @@ struct Decoder {
     }
     x.mark(5);
 
-    // ---- D: who survives, when the select pass could not already tell (no pruning, score ties at the boundary,
-    // several select rounds) -- a flag pass; or, when the outcome depends on it, an exact replay of std::nth_element.
+    // ---- D: who survives, in DFS (= slot) order.  Normally an ordered compaction of the slots that pass the
+    // threshold; when the outcome depends on it, an exact replay of std::nth_element followed by a ranking by slot.
+    const int n_new = N < K ? N : K;
     if (exact) {
       for (int s = tid; s <= S; s += nt) w.pos[s] = (s < S && info_type(w.sinfo[s]) != T_HOLE) ? 1u : 0u;
       x.sync();
@@ -667,50 +647,26 @@ struct Decoder {
         if (w.pos[s + 1] != w.pos[s]) w.ek[w.pos[s]] = (slot_key48(s) << 16) | (uint64_t)s;
       x.sync();
       replay_nth_element(N, K);
-      for (int k = tid; k < K; k += nt) surv[k] = (int)(w.ek[k] & 0xFFFFu);
+      for (int k = tid; k < K; k += nt) { rk[k] = 0; ord[k] = (int)(w.ek[k] & 0xFFFFu); }  // ord: nth_element order
+      x.sync();
+      for (int q = tid; q < K; q += nt) {  // rank by slot
+        const int mine = ord[q];
+        int r = 0;
+        for (int o = 0; o < K; ++o) r += ord[o] < mine;
+        rk[q] = r;
+        surv[r] = mine;
+      }
       x.sync();
       x.mark(6);
-    } else if (!have_survivors) {
-      if (tid == 0) pv[P_SCOUNT] = 0;
-      x.sync();
-      for (int s0 = 0; s0 < S; s0 += nt) {  // every thread takes part in every round (wave-aggregated append)
-        const int s = s0 + tid;
-        bool keep = false;
-        if (s < S) {
-          const uint32_t k = w.skey[s];
-          keep = (N <= K) ? (k != 0u) : (k > tau || (k == tau && (w.sinfo[s] >> 16) >= tauc));
-        }
-        const int idx = x.append(&pv[P_SCOUNT], keep);
-        if (keep) surv[idx] = s;
-      }
-      x.sync();
+    } else {
+      const uint32_t *skey = w.skey, *sinfo = w.sinfo;
+      const bool all = N <= K;
+      x.compact_slots(S, surv, [=](int s) -> bool {
+        const uint32_t k = skey[s];
+        return all ? (k != 0u) : (k > tau || (k == tau && (sinfo[s] >> 16) >= tauc));
+      });
       x.mark(3);
     }
-    const int n_new = N < K ? N : K;
-
-    // ---- E: rank the survivors by slot (= DFS order), then one thread per survivor builds the next beam entry.
-    {
-      const int parts = nt / n_new < 16 ? nt / n_new : 16;  // threads per survivor
-      if (parts >= 2) {
-        if (tid < parts * n_new) {
-          const int q = tid % n_new, part = tid / n_new;
-          const int mine = surv[q];
-          int r = 0;
-          for (int o = part; o < n_new; o += parts) r += surv[o] < mine;
-          x.atomic_add(&rk[q], r);
-        }
-      } else {
-        for (int q = tid; q < n_new; q += nt) {
-          const int mine = surv[q];
-          int r = 0;
-          for (int o = 0; o < n_new; ++o) r += surv[o] < mine;
-          rk[q] = r;
-        }
-      }
-      x.sync();
-      for (int q = tid; q < n_new; q += nt) ord[rk[q]] = q;
-    }
-    x.sync();
     x.mark(4);
     if (pool_count + n_new > pool_cap) {  // cannot happen when the pool is sized 1 + K*T
       if (tid == 0) w.vars[VAR_STATUS] = ST_POOL_OVERFLOW;
@@ -719,8 +675,8 @@ struct Decoder {
     }
     int dloc = kIntMax;
     uint32_t kloc = 0;
-    for (int q = tid; q < n_new; q += nt) {
-      const int k = rk[q], s = surv[q];
+    for (int k = tid; k < n_new; k += nt) {
+      const int s = surv[k];
       const uint32_t inf = w.sinfo[s];
       const uint32_t type = info_type(inf);
       const int j = info_entry(inf);
@@ -728,14 +684,13 @@ struct Decoder {
       // off (a brand-new child never lies on an existing path), capped by the depth of a revived interior node.
       int l = -1;
       if (k > 0) {
-        const uint32_t pinf = w.sinfo[surv[ord[k - 1]]];
+        const uint32_t pinf = w.sinfo[surv[k - 1]];
         const int pj = info_entry(pinf);
         l = lca_depth(pj, j);
         if (type == T_REVIVED) { const int dx = b.dep[w.anc[j]] + 1; l = dx < l ? dx : l; }
         if (info_type(pinf) == T_REVIVED) { const int dx = b.dep[w.anc[pj]] + 1; l = dx < l ? dx : l; }
       }
       nb.lcp[k] = l;
-      if (last && exact) w.fin[q] = k;
       int dd;
       if (type == T_SELF) {
         nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = dd = b.dep[j];
@@ -766,8 +721,9 @@ struct Decoder {
     }
     x.wave_min_to(&pv[P_NDMIN], dloc);
     x.wave_max_to(&pv[P_NMAXKEY], kloc);
-    if (last && !exact)
-      for (int k = tid; k < n_new; k += nt) w.fin[k] = k;
+    if (last) {  // the order std::nth_element left the survivors in (identity when it was not called)
+      for (int q = tid; q < n_new; q += nt) w.fin[q] = exact ? rk[q] : q;
+    }
     // un-register this step's candidates from the rank table
     if (!in.identity)
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;

@@ -103,6 +103,43 @@ struct DevX {
     if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
   }
 
+  // Ordered compaction: out[r] = s for every slot s in [0, S) with pred(s), r = number of such slots below s.
+  // Each wave owns a contiguous range of slots (consecutive lanes = consecutive slots), so the rank of a slot is
+  // (survivors in lower waves) + (survivors in this wave's earlier rounds) + (set ballot bits below the lane):
+  // no atomics, no sorting.  Starts and ends with a barrier-consistent state (caller synced before; syncs after).
+  template <class Pred>
+  __device__ void compact_slots(int S, int *out, Pred pred) {
+    const int lane = (int)threadIdx.x & 63, nw = ((int)blockDim.x + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int rounds = (S + 64 * nw - 1) / (64 * nw);
+    const int first = wave * rounds * 64;
+    unsigned long long flags = 0ull;
+    int cnt = 0;
+    for (int it = 0; it < rounds; ++it) {
+      const int s = first + it * 64 + lane;
+      const bool f = s < S && pred(s);
+      cnt += __popcll(__ballot(f));
+      if (f && it < 64) flags |= 1ull << it;
+    }
+    int *row = red + parity * 16;
+    parity ^= 1;
+    if (lane == 0) row[wave] = cnt;
+    sync();
+    // exclusive prefix over the <= 16 wave totals: one LDS read per lane + a row-level DPP scan, then one readlane
+    int tot = lane < nw ? row[lane] : 0;
+    tot += CTC_DPP(0, tot, 0x111, 0xf); tot += CTC_DPP(0, tot, 0x112, 0xf);
+    tot += CTC_DPP(0, tot, 0x114, 0xf); tot += CTC_DPP(0, tot, 0x118, 0xf);
+    int base = wave > 0 ? __builtin_amdgcn_readlane(tot, wave - 1) : 0;
+    for (int it = 0; it < rounds; ++it) {
+      const int s = first + it * 64 + lane;
+      const bool f = it < 64 ? ((flags >> it) & 1ull) != 0ull : (s < S && pred(s));
+      const unsigned long long m = __ballot(f);
+      if (f) out[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = s;
+      base += __popcll(m);
+    }
+    sync();
+  }
+
   // bins complete (caller synced), padded layout ctcbeam::bin_index.  Wave 0 finds the bucket holding the need-th
   // largest key; everyone gets out[0..3] = {bucket or -1, #keys above it, #keys total, #keys in it} after the closing
   // barrier; bins are re-zeroed.
@@ -440,7 +477,7 @@ struct Buf {
 
 struct ctcd_decoder {
   int device = 0;
-  int threads = 512;
+  int threads = 1024;
   int max_lds = 0;
   Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far;
   long long prune_host_rows = 0;  // frames of the last call that were resolved on the host

@@ -138,14 +138,15 @@ CTC_HD float logf_normal(float x, const uint64_t *tbl) {
   return (float)__builtin_fma(r2, y, t);
 }
 
-// log_sum_exp<float> exactly as decoder_utils.h:47-54 evaluates it.
+// log_sum_exp<float> exactly as decoder_utils.h:47-54 evaluates it:  logf(expf(x - m) + expf(y - m)) + m, m = max.
+// One of the two exponentials is expf(+0) = 1.0f exactly (glibc returns exactly 1 for a zero argument), and float
+// addition commutes, so only the other one is evaluated: the sum, and everything after it, is bit-identical.
 CTC_HD float lse(float x, float y, const uint64_t *tbl) {
   if (x <= CTC_NEG_MAX) return y;
   if (y <= CTC_NEG_MAX) return x;
-  float m = (x < y) ? y : x;  // std::max(x, y)
-  float ex = expf_nonpos(x - m, tbl);
-  float ey = expf_nonpos(y - m, tbl);
-  float s = ex + ey;
+  const float m = (x < y) ? y : x;  // std::max(x, y)
+  const float lo = (x < y) ? x : y;
+  const float s = 1.0f + expf_nonpos(lo - m, tbl);
   return logf_normal(s, tbl) + m;
 }
 

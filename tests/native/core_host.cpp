@@ -51,6 +51,12 @@ struct HostX {
     for (int b = 0; b < kBins + kBins / 16; ++b) bins[b] = 0;
   }
   int append(int *counter, bool pred) { return pred ? (*counter)++ : -1; }
+  template <class Pred>
+  void compact_slots(int S, int *out, Pred pred) {
+    int k = 0;
+    for (int s = 0; s < S; ++s)
+      if (pred(s)) out[k++] = s;
+  }
   void wave_min_to(int *p, int v) { *p = std::min(*p, v); }
   void wave_max_to(int *p, uint32_t v) { *p = (int)std::max((uint32_t)*p, v); }
 };
