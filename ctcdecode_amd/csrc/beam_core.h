@@ -301,9 +301,20 @@ struct Decoder {
       }
       if (!again) {  // exact rank inside the bucket, on offsets from its base
         const uint32_t b32 = (uint32_t)blo, bspan = (uint32_t)(bhi - blo - 1);
-        for (int s = tid; s < S; s += nt) {
-          const uint32_t k = w.skey[s], dk = k - b32;
-          if (k >= b32 && dk <= bspan) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = dk + 1u;
+        if (S <= 4 * nt) {  // common case: the (up to) four keys of this thread are requested together
+          uint32_t kk[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) kk[u] = tid + u * nt < S ? w.skey[tid + u * nt] : 0u;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t dk = kk[u] - b32;
+            if (kk[u] >= b32 && dk <= bspan) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = dk + 1u;
+          }
+        } else {
+          for (int s = tid; s < S; s += nt) {
+            const uint32_t k = w.skey[s], dk = k - b32;
+            if (k >= b32 && dk <= bspan) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = dk + 1u;
+          }
         }
         for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
         x.sync();
@@ -577,12 +588,19 @@ struct Decoder {
           const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
           const int c = in.identity ? r : w.cch[r];
           const float lp = w.clp[r];
+          const uint32_t childinfo = mk_info(c, T_CHILD, 0);
           for (int i = t2 >> sh; i < n; i += ng) {
-            const int s = w.cstart[i] + rn;
-            const bool exists = (w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u;
-            const uint32_t k = exists ? 0u : ord_f32(child_logp(i, c, lp));
+            // everything this candidate needs from its parent, requested in one go (one LDS round trip), no branches
+            const int cs = w.cstart[i];
+            const uint32_t hw = w.hit[2 * i + (rn >> 5)];
+            const int pch = b.ch[i];
+            const float psc = b.score[i], pbp = b.bprev[i];
+            const bool exists = (hw >> (rn & 31)) & 1u;
+            const float ext = lp + psc, rep = pbp > CTC_NEG_MAX ? lp + pbp : CTC_NEG_MAX;  // :110-118
+            const uint32_t k = exists ? 0u : ord_f32(c == pch ? rep : ext);
+            const int s = cs + rn;
             w.skey[s] = k;
-            w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
+            w.sinfo[s] = exists ? kHoleInfo : (childinfo | (uint32_t)i);
             hist_add(wd, k);
           }
         }

@@ -113,6 +113,30 @@ struct DevX {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rounds = (S + 64 * nw - 1) / (64 * nw);
     const int first = wave * rounds * 64;
+    int *row = red + parity * 16;
+    parity ^= 1;
+    if (rounds <= 4) {  // common case: straight-line code, the four slots' predicates evaluated together
+      const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
+      const bool f0 = s0 < S && pred(s0);
+      const bool f1 = rounds > 1 && s1 < S && pred(s1);
+      const bool f2 = rounds > 2 && s2 < S && pred(s2);
+      const bool f3 = rounds > 3 && s3 < S && pred(s3);
+      const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+      const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+      if (lane == 0) row[wave] = c0 + c1 + c2 + c3;
+      sync();
+      int tot = lane < nw ? row[lane] : 0;
+      tot += CTC_DPP(0, tot, 0x111, 0xf); tot += CTC_DPP(0, tot, 0x112, 0xf);
+      tot += CTC_DPP(0, tot, 0x114, 0xf); tot += CTC_DPP(0, tot, 0x118, 0xf);
+      const int base = wave > 0 ? __builtin_amdgcn_readlane(tot, wave - 1) : 0;
+#define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
+      if (f0) out[base + CTC_BELOW(m0)] = s0;
+      if (f1) out[base + c0 + CTC_BELOW(m1)] = s1;
+      if (f2) out[base + c0 + c1 + CTC_BELOW(m2)] = s2;
+      if (f3) out[base + c0 + c1 + c2 + CTC_BELOW(m3)] = s3;
+      sync();
+      return;
+    }
     unsigned long long flags = 0ull;
     int cnt = 0;
     for (int it = 0; it < rounds; ++it) {
@@ -121,8 +145,6 @@ struct DevX {
       cnt += __popcll(__ballot(f));
       if (f && it < 64) flags |= 1ull << it;
     }
-    int *row = red + parity * 16;
-    parity ^= 1;
     if (lane == 0) row[wave] = cnt;
     sync();
     // exclusive prefix over the <= 16 wave totals: one LDS read per lane + a row-level DPP scan, then one readlane
@@ -134,9 +156,10 @@ struct DevX {
       const int s = first + it * 64 + lane;
       const bool f = it < 64 ? ((flags >> it) & 1ull) != 0ull : (s < S && pred(s));
       const unsigned long long m = __ballot(f);
-      if (f) out[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = s;
+      if (f) out[base + CTC_BELOW(m)] = s;
       base += __popcll(m);
     }
+#undef CTC_BELOW
     sync();
   }
 
