@@ -40,3 +40,42 @@ def test_core_randomized_against_oracle():
 def test_core_north_star_shape():
     lp = ou.synth_logprobs(2, 1000, 29, 5)
     ou.assert_same(ou.decode(lp, beam=100), ou.decode_core_host(lp, beam=100))
+
+
+def _edge_cases():
+    yield "only_blank", ou.synth_logprobs(2, 20, 1, 1), dict(beam=5)
+    yield "two_labels_k1", ou.synth_logprobs(2, 30, 2, 2), dict(beam=1, blank_id=1)
+    yield "one_frame", ou.synth_logprobs(3, 1, 29, 3), dict(beam=100)
+    lp = ou.synth_logprobs(2, 60, 9, 4)
+    lp[:, ::3, 2] = -np.inf
+    lp[:, 5, :] = -np.inf
+    yield "minus_inf_inputs", lp, dict(beam=12)
+    lp = ou.synth_logprobs(2, 40, 9, 5)
+    lp[:, :, 0] = 0.0
+    yield "certain_blank", lp, dict(beam=12)
+    lp = np.full((2, 50, 6), np.float32(-1.7917595), np.float32)
+    yield "all_equal_maximal_ties", lp, dict(beam=20)
+    yield "coarse_quantised", ou.synth_logprobs(1, 300, 4, 7, quant=4.0), dict(beam=64, blank_id=3)
+    lp = ou.synth_logprobs(2, 40, 9, 8)
+    lp[0, 10:20, :] = -3.0e38
+    yield "near_minus_flt_max", lp, dict(beam=12)
+
+
+EDGE = list(_edge_cases())
+
+
+@pytest.mark.parametrize("name,lp,kw", EDGE, ids=[e[0] for e in EDGE])
+def test_core_edge_cases(name, lp, kw):
+    ou.assert_same(ou.decode(lp, which="restated", **kw), ou.decode_core_host(lp, **kw), name)
+
+
+@pytest.mark.skipif(not ou.have_reference(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,lp,kw", EDGE, ids=[e[0] for e in EDGE])
+def test_oracle_edge_cases_against_live_reference(name, lp, kw):
+    ou.assert_same(ou.decode(lp, which="restated", **kw), ou.decode(lp, which="reference", **kw), name)
+
+
+def test_core_hbm_scratch_layout(monkeypatch):
+    monkeypatch.setenv("CTC_HOST_BIG", "1")
+    lp = ou.synth_logprobs(2, 150, 29, 44, quant=0.5)
+    ou.assert_same(ou.decode(lp, beam=64), ou.decode_core_host(lp, beam=64))

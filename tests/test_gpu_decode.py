@@ -199,6 +199,15 @@ def test_config4_shape_large_vocab(torch_mod):
     print("configs[3]: frames resolved on the host:", n.lib.ctcd_last_prune_host_rows(dec._handle), "of", B * T)
 
 
+def test_edge_cases_on_gpu(torch_mod):
+    from test_core_host import EDGE
+
+    for name, lp, kw in EDGE:
+        want = ou.decode(lp, which="restated", **kw)
+        got = _decode(torch_mod, lp, **kw)
+        ou.assert_same(_with_nres(got, want), want, name)
+
+
 def test_empty_and_degenerate_batches(torch_mod):
     import ctcdecode_amd
 
