@@ -13,7 +13,9 @@
 #include <cstring>
 #include <algorithm>
 #include <limits>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -263,7 +265,7 @@ struct KernelArgs {
 };
 
 template <bool PROF, bool BIG>
-__global__ void ctc_beam_decode_kernel(KernelArgs a) {
+__global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
   __shared__ int red[32];
@@ -321,6 +323,8 @@ __global__ void prob_to_log_kernel(const float *in, float *out, size_t n, unsign
 // inherits; whenever a frame's result could depend on either (equal values at or above the cut, a cumulative sum
 // within rounding distance of cutoff_prob, a borderline float rounding of log) the frame is flagged and recomputed on
 // the host with the real std::sort / libm (host_prune_row below).  Everything else is decided here, exactly.
+constexpr int kPruneCand = 256;  // capacity of the pre-filter candidate list per frame
+
 struct PruneArgs {
   const float *in;          // [B, T, V]
   const int32_t *seq_lens;  // [B] or null
@@ -347,13 +351,18 @@ __device__ __forceinline__ double log_add_f64(double a, double b) {  // decoder_
   return log(exp(a - m) + exp(b - m)) + m;
 }
 
-__global__ void prune_rows_kernel(PruneArgs a) {
+// R > 0: the frame's keys are held in registers (64*R >= V); R == 0: re-read from memory on every pass.
+template <int R>
+__global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, wpb = (int)blockDim.x >> 6;
   const int n = a.top_n < a.V ? a.top_n : a.V;
-  uint32_t *lkey = (uint32_t *)psm + (size_t)wave * 3 * a.stride;  // per wave: keys, labels, labels in final order
+  // per wave: kept keys, labels, labels in final order (stride each); pre-filter candidates (keys, labels)
+  uint32_t *lkey = (uint32_t *)psm + (size_t)wave * (3 * a.stride + 2 * kPruneCand);
   int *lidx = (int *)lkey + a.stride;
   int *sidx = lidx + a.stride;
+  uint32_t *ckey = (uint32_t *)(sidx + a.stride);
+  int *cidx = (int *)ckey + kPruneCand;
   for (long long r = (long long)blockIdx.x * wpb + wave; r < a.rows; r += (long long)gridDim.x * wpb) {
     if (a.seq_lens) {  // frames beyond the utterance's length are never read (binding.cpp:64-65)
       const long long b = r / a.T;
@@ -363,40 +372,116 @@ __global__ void prune_rows_kernel(PruneArgs a) {
     }
     const float *x = a.in + (size_t)r * a.V;
     bool flag = false;
-    // n-th largest key, bit by bit
+    uint32_t keys[R > 0 ? R : 1];
+    if (R > 0) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) keys[u] = lane + 64 * u < a.V ? prune_key(x[lane + 64 * u]) : 0u;  // 0 < every real key
+    }
     uint32_t tau = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-      const uint32_t trial = tau | (1u << bit);
-      int c = 0;
-      for (int i = lane; i < a.V; i += 64) c += prune_key(x[i]) >= trial;
-      if (wave_sum(c) >= n) tau = trial;
-    }
-    int g = 0, e = 0;
-    for (int i = lane; i < a.V; i += 64) {
-      const uint32_t k = prune_key(x[i]);
-      g += k > tau;
-      e += k == tau;
-    }
-    g = wave_sum(g);
-    e = wave_sum(e);
-    if (e > n - g) flag = true;  // equal values straddle the cut: std::sort decides which of them are kept
-    // gather the kept values
-    int base = 0;
-    for (int i0 = 0; i0 < a.V; i0 += 64) {
-      const int i = i0 + lane;
-      uint32_t k = 0;
-      bool keep = false;
-      if (i < a.V) {
-        k = prune_key(x[i]);
-        keep = k > tau || (k == tau && !flag);
+    int g = 0, e = 0, base = 0;
+    bool done = false;
+    if (R > 0 && n <= 64) {
+      // Pre-filter: tau is at least the n-th largest of the 64 per-lane maxima (those are n elements >= it), so only
+      // keys >= that bound (a few dozen of V) can be among the top n.  They are listed in LDS and ranked exactly.
+      uint32_t lmax = 0;
+#pragma unroll
+      for (int u = 0; u < R; ++u) lmax = keys[u] > lmax ? keys[u] : lmax;
+      uint32_t bound = 0;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = bound | (1u << bit);
+        if (__popcll(__ballot(lmax >= trial)) >= n) bound = trial;
       }
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const int p = base + __popcll(m & ((1ull << lane) - 1ull));
-        lkey[p] = k;
-        lidx[p] = i;
+      int ns = 0;
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const bool in = keys[u] >= bound && keys[u] != 0u;
+        const unsigned long long m = __ballot(in);
+        if (m) {
+          const int p = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (in && p < kPruneCand) { ckey[p] = keys[u]; cidx[p] = lane + 64 * u; }
+          ns += __popcll(m);
+        }
       }
-      base += __popcll(m);
+      if (ns <= kPruneCand) {
+        // exact n-th largest among the ns candidates (every lane ranks its own candidates against all of them)
+        uint32_t found = 0;
+        for (int q = lane; q < ns; q += 64) {
+          const uint32_t mine = ckey[q];
+          int gg = 0, ee = 0;
+          for (int o = 0; o < ns; ++o) {
+            const uint32_t k = ckey[o];
+            gg += k > mine;
+            ee += k == mine;
+          }
+          if (gg < n && n <= gg + ee) found = mine;
+        }
+        const unsigned long long mf = __ballot(found != 0u);
+        tau = (uint32_t)__builtin_amdgcn_readlane((int)found, __ffsll((long long)mf) - 1);
+        for (int q = lane; q < ns; q += 64) { g += ckey[q] > tau; e += ckey[q] == tau; }
+        g = wave_sum(g);
+        e = wave_sum(e);
+        if (e > n - g) flag = true;  // equal values straddle the cut: std::sort decides which of them are kept
+        for (int q0 = 0; q0 < ns; q0 += 64) {
+          const int q = q0 + lane;
+          const uint32_t k = q < ns ? ckey[q] : 0u;
+          const bool keep = q < ns && (k > tau || (k == tau && !flag));
+          const unsigned long long m = __ballot(keep);
+          if (keep) {
+            const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            lkey[p] = k;
+            lidx[p] = cidx[q];
+          }
+          base += __popcll(m);
+        }
+        done = true;
+      }
+    }
+    if (!done) {
+      // n-th largest key, bit by bit, over all V values
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = tau | (1u << bit);
+        int c = 0;
+        if (R > 0) {
+#pragma unroll
+          for (int u = 0; u < R; ++u) c += keys[u] >= trial;
+        } else {
+          for (int i = lane; i < a.V; i += 64) c += prune_key(x[i]) >= trial;
+        }
+        if (wave_sum(c) >= n) tau = trial;
+      }
+      if (R > 0) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) { g += keys[u] > tau; e += keys[u] == tau; }
+      } else {
+        for (int i = lane; i < a.V; i += 64) {
+          const uint32_t k = prune_key(x[i]);
+          g += k > tau;
+          e += k == tau;
+        }
+      }
+      g = wave_sum(g);
+      e = wave_sum(e);
+      if (e > n - g) flag = true;  // equal values straddle the cut: std::sort decides which of them are kept
+      // gather the kept values
+      auto take = [&](int i, uint32_t k, bool valid) {
+        const bool keep = valid && (k > tau || (k == tau && !flag));
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+          const int p = base + __popcll(m & ((1ull << lane) - 1ull));
+          lkey[p] = k;
+          lidx[p] = i;
+        }
+        base += __popcll(m);
+      };
+      if (R > 0) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) take(lane + 64 * u, keys[u], lane + 64 * u < a.V);
+      } else {
+        for (int i0 = 0; i0 < a.V; i0 += 64) {
+          const int i = i0 + lane;
+          take(i, i < a.V ? prune_key(x[i]) : 0u, i < a.V);
+        }
+      }
     }
     const int kept = base;  // == n unless flagged
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
@@ -424,19 +509,36 @@ __global__ void prune_rows_kernel(PruneArgs a) {
     }
     flag = __ballot(flag) != 0ull;
     int len = kept;
-    if (a.cutoff_prob < 1.0 && !flag) {  // decoder_utils.cpp:25-32: cum starts at 0.0 (sic)
-      if (lane == 0) {
-        double cum = 0.0;
-        len = 0;
-        for (int i = 0; i < kept; ++i) {
-          const double p = (double)x[sidx[i]];
-          cum = log_add_f64(cum, a.log_input ? p : log(p));
-          ++len;
-          if (fabs(cum - a.cutoff_prob) <= 1e-9 * (1.0 + fabs(cum)) || !(cum == cum)) { flag = true; break; }
-          if (cum >= a.cutoff_prob || len >= a.top_n) break;
+    if (a.cutoff_prob < 1.0 && !flag) {
+      // decoder_utils.cpp:25-32: cum = log_sum_exp(cum, log p_i) starting from cum = 0.0 (sic), i.e. after i+1 terms
+      // cum = log(1 + p_0 + ... + p_i); keep going until cum >= cutoff_prob or cutoff_top_n entries.  Evaluated here
+      // as a wave-parallel prefix sum (differs from the reference's sequential double chain by ~1e-14 relative); a
+      // frame where any partial sum comes within 1e-9 of the threshold is left to the host.
+      int stop = kept;  // number of entries kept
+      double carry = 0.0;
+      for (int i0 = 0; i0 < kept && stop == kept; i0 += 64) {
+        const int i = i0 + lane;
+        double p = 0.0;
+        if (i < kept) {
+          const double v = (double)x[sidx[i]];
+          p = a.log_input ? exp(v) : v;
         }
+        double incl = p;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const double o = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += o;
+        }
+        const double cum = log(1.0 + carry + incl);
+        const bool near = i < kept && (fabs(cum - a.cutoff_prob) <= 1e-9 * (1.0 + fabs(cum)) || !(cum == cum));
+        const bool hit = i < kept && (cum >= a.cutoff_prob || i + 1 >= a.top_n);
+        const unsigned long long mh = __ballot(hit), mn = __ballot(near);
+        const int firsthit = mh ? __ffsll((long long)mh) - 1 : 64;
+        if (mn && (__ffsll((long long)mn) - 1) <= firsthit) flag = true;  // ambiguous before (or at) the stopping point
+        if (mh) stop = i0 + firsthit + 1;
+        carry += __shfl(incl, 63, 64);
       }
-      len = __builtin_amdgcn_readfirstlane(len);
+      len = stop;
       flag = __ballot(flag) != 0ull;
     }
     if (lane == 0) {
@@ -446,6 +548,23 @@ __global__ void prune_rows_kernel(PruneArgs a) {
         if (k < a.flag_cap) a.flag_rows[k] = (unsigned)r;
       }
     }
+  }
+}
+
+// Flagged frames: rows to a contiguous staging buffer, and host-resolved records back into the candidate lists.
+__global__ void gather_rows_kernel(const float *in, const unsigned *rows, int V, float *out) {
+  const float *src = in + (size_t)rows[blockIdx.x] * V;
+  float *dst = out + (size_t)blockIdx.x * V;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) dst[i] = src[i];
+}
+__global__ void scatter_pruned_kernel(const int32_t *recs, const unsigned *rows, int stride, int *cnt, int *ch, float *lp) {
+  const int32_t *r = recs + (size_t)blockIdx.x * (1 + 2 * (size_t)stride);
+  const size_t row = rows[blockIdx.x];
+  const int n = r[0];
+  if (threadIdx.x == 0) cnt[row] = n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    ch[row * stride + i] = r[1 + i];
+    lp[row * stride + i] = __int_as_float(r[1 + stride + i]);
   }
 }
 
@@ -682,29 +801,53 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
     pa.stride = stride; pa.rows = rows; pa.cutoff_prob = cutoff_prob; pa.cnt = (int *)d->pr_cnt.p; pa.ch = (int *)d->pr_ch.p;
     pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
     const int wpb = 4;
-    const size_t psm = (size_t)wpb * 3 * stride * 4;
+    const size_t psm = (size_t)wpb * (3 * (size_t)stride + 2 * kPruneCand) * 4;
     if (psm > (size_t)d->max_lds) return fail(CTCD_EUNSUPPORTED, "cutoff_top_n too large for the prune pass");
     const int blocks = (int)std::min<long long>((rows + wpb - 1) / wpb, 256 * 16);
-    HIP_TRY(hipFuncSetAttribute((const void *)prune_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm));
-    hipLaunchKernelGGL(prune_rows_kernel, dim3(blocks), dim3(wpb * 64), psm, stream, pa);
+    const void *pfn = V <= 64 ? (const void *)prune_rows_kernel<1> : V <= 256 ? (const void *)prune_rows_kernel<4>
+                    : V <= 1024 ? (const void *)prune_rows_kernel<16> : V <= 4096 ? (const void *)prune_rows_kernel<64>
+                    : V <= 10240 ? (const void *)prune_rows_kernel<160> : (const void *)prune_rows_kernel<0>;
+    HIP_TRY(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm));
+    void *pargs[] = {&pa};
+    HIP_TRY(hipLaunchKernel(pfn, dim3(blocks), dim3(wpb * 64), pargs, psm, stream));
     HIP_TRY(hipGetLastError());
     unsigned nf = 0;
     HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (nf > cap) return fail(CTCD_EUNSUPPORTED, "more than 65536 frames with tied / borderline values in one call");
-    if (nf) {  // toolchain-defined cases: let the toolchain decide (real std::sort, real libm)
+    if (nf) {  // toolchain-defined cases: let the toolchain decide (real std::sort, real libm) -- batched transfers
       std::vector<unsigned> fr(nf);
       HIP_TRY(hipMemcpy(fr.data(), flag_rows, (size_t)nf * 4, hipMemcpyDeviceToHost));
-      std::vector<float> row(V), hlp(stride);
-      std::vector<int> hch(stride);
-      for (unsigned k = 0; k < nf; ++k) {
-        const size_t r = fr[k];
-        HIP_TRY(hipMemcpy(row.data(), probs + r * V, (size_t)V * 4, hipMemcpyDeviceToHost));
-        const int cnt = host_prune_row(row.data(), V, cutoff_prob, cutoff_top_n, log_input, hch.data(), hlp.data());
-        HIP_TRY(hipMemcpy((int *)d->pr_cnt.p + r, &cnt, 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy((int *)d->pr_ch.p + r * stride, hch.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy((float *)d->pr_lp.p + r * stride, hlp.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
+      const size_t rec = 1 + 2 * (size_t)stride;  // per frame: count, labels, log-probs
+      if ((rc = d->stage_in.ensure((size_t)nf * V * 4))) return rc;
+      if ((rc = d->stage_out.ensure((size_t)nf * rec * 4))) return rc;
+      hipLaunchKernelGGL(gather_rows_kernel, dim3(nf), dim3(256), 0, stream, probs, flag_rows, V, (float *)d->stage_in.p);
+      HIP_TRY(hipGetLastError());
+      std::vector<float> rowsh((size_t)nf * V);
+      HIP_TRY(hipMemcpyAsync(rowsh.data(), d->stage_in.p, rowsh.size() * 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      std::vector<int32_t> recs((size_t)nf * rec, 0);
+      {  // the flagged frames are independent: one host thread each (up to the core count)
+        std::atomic<unsigned> next{0};
+        auto work = [&] {
+          for (;;) {
+            const unsigned k = next.fetch_add(1);
+            if (k >= nf) return;
+            int32_t *rr = recs.data() + (size_t)k * rec;
+            rr[0] = host_prune_row(rowsh.data() + (size_t)k * V, V, cutoff_prob, cutoff_top_n, log_input, rr + 1, (float *)(rr + 1 + stride));
+          }
+        };
+        const unsigned nth = std::min<unsigned>(nf, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < nth; ++i) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
       }
+      HIP_TRY(hipMemcpyAsync(d->stage_out.p, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(scatter_pruned_kernel, dim3(nf), dim3(64), 0, stream, (const int32_t *)d->stage_out.p, flag_rows, stride,
+                         (int *)d->pr_cnt.p, (int *)d->pr_ch.p, (float *)d->pr_lp.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(stream));  // recs (host memory) must outlive the copy
       d->prune_host_rows = nf;
     }
   } else if (!log_input && T > 0) {
