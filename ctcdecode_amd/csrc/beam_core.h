@@ -103,6 +103,7 @@ constexpr int kSerialCut = 96;  // introselect ranges at most this long are fini
 struct Work {
   Beam cur, nxt;
   int *e, *anc, *ostart, *cstart, *hasvia, *pinr, *revr;  // per beam entry, this step
+  int *ancbuf, *acntbuf;  // 2K each: nearest in-beam ancestor / number of in-beam ancestors, painted; by step parity
   uint32_t *hit;   // 2 words per entry: ranks (non-blank numbering) of the children that already exist
   float *b_new, *nb_new, *sc_new, *rev_lpc;
   int *cch;        // candidate characters of this step (unused in identity mode)
@@ -142,7 +143,8 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
     b.bprev = carve_ptr<float>(p, K); b.nbprev = carve_ptr<float>(p, K); b.score = carve_ptr<float>(p, K);
     b.lpc = carve_ptr<float>(p, K);
   }
-  w.e = carve_ptr<int>(p, K); w.anc = carve_ptr<int>(p, K); w.ostart = carve_ptr<int>(p, K);
+  w.e = carve_ptr<int>(p, K); w.ancbuf = carve_ptr<int>(p, 2 * K); w.acntbuf = carve_ptr<int>(p, 2 * K); w.anc = w.ancbuf;
+  w.ostart = carve_ptr<int>(p, K);
   w.cstart = carve_ptr<int>(p, K); w.hasvia = carve_ptr<int>(p, K); w.pinr = carve_ptr<int>(p, K);
   w.revr = carve_ptr<int>(p, K); w.hit = carve_ptr<uint32_t>(p, 2 * K);
   w.b_new = carve_ptr<float>(p, K); w.nb_new = carve_ptr<float>(p, K); w.sc_new = carve_ptr<float>(p, K); w.rev_lpc = carve_ptr<float>(p, K);
@@ -225,7 +227,7 @@ struct Decoder {
     st_maxkey = ord_f32(0.f);
     for (int i = x.tid(); i < kBins + kBins / 16; i += x.nt()) w.bins[i] = 0;
     for (int i = x.tid(); i < 2 * d.K; i += x.nt()) w.hit[i] = 0;
-    for (int i = x.tid(); i < d.K; i += x.nt()) w.surv[d.K + i] = 0;
+    for (int i = x.tid(); i < 2 * d.K; i += x.nt()) { w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
     if (d.use_rank_table)
       for (int c = x.tid(); c < d.V; c += x.nt()) w.rank_of[c] = -1;
     x.sync_full();
@@ -458,7 +460,7 @@ struct Decoder {
     Beam &b = w.cur;
     Beam &nb = w.nxt;
     const int tid = x.tid(), nt = x.nt();
-    const int n = st_n, pool_count = st_pool, dmin = st_dmin;
+    const int n = st_n, pool_count = st_pool;
     const int K = d.K;
     const int Vc = in.Vc, brank = in.blank_rank;
     const int Vnb = Vc - (brank >= 0 ? 1 : 0);
@@ -469,28 +471,44 @@ struct Decoder {
     int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
     const Window wd = first_window();
 
-    // ---- A1: per beam entry, from the LCP array alone: end of its subtree range and nearest in-beam ancestor
-    for (int j = tid; j < n; j += nt) {
-      const int dj = b.dep[j];
-      int q = j + 1;
-      while (q < n && b.lcp[q] >= dj) ++q;
-      int P = -1, m = kIntMax;
-      for (int i = j - 1; i >= 0; --i) {
-        const int l = b.lcp[i + 1];
-        m = l < m ? l : m;
-        if (m < dmin) break;           // no beam entry is shallower than dmin: nothing further back can be an ancestor
-        if (b.dep[i] <= m) { P = i; break; }
+    // ---- A1: per beam entry, from the LCP array alone: the end of its subtree range (first later entry whose LCP
+    // with its predecessor is shallower than the entry), found by a wave-wide search; every entry then "paints" its
+    // proper descendants with itself, which leaves in anc[] the nearest in-beam ancestor (max = innermost enclosing
+    // range) and in acnt[] the number of in-beam ancestors.  Cost is bounded even for deeply nested beams.
+    w.anc = w.ancbuf + (in.t & 1) * K;
+    int *acnt = w.acntbuf + (in.t & 1) * K;
+    {
+      const int grp = x.group(), ngr = x.ngroups();
+      const int mine = grp < n ? (n - grp + ngr - 1) / ngr : 0;  // entries grp, grp + ngr, ... belong to this group
+      for (int k0 = 0; k0 < mine; k0 += x.lanes()) {
+        // leaves (the next entry is not a descendant) are settled one per lane; only entries with in-beam
+        // descendants need the wave-wide search and the painting
+        const int k = k0 + x.lane();
+        const int j = grp + k * ngr;
+        bool internal = false;
+        if (k < mine) {
+          internal = j + 1 < n && b.lcp[j + 1] >= b.dep[j];
+          if (!internal) w.e[j] = j + 1;
+        }
+        unsigned long long todo = x.ballot(internal);
+        while (todo) {
+          const int kk = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const int jj = grp + (k0 + kk) * ngr;
+          const int q = x.first_below(b.lcp, jj + 2, n, x.uni(b.dep[jj]));
+          if (x.lane() == 0) w.e[jj] = q;
+          for (int c = jj + 1 + x.lane(); c < q; c += x.lanes()) {
+            x.atomic_max(&w.anc[c], jj);
+            x.atomic_add(&acnt[c], 1);
+          }
+        }
       }
-      w.e[j] = q;
-      w.anc[j] = P;
     }
     x.sync();
     // ---- A2: Euler-tour slot offsets; which children of in-beam parents already exist
     int npin = 0;
     for (int j = tid; j < n; j += nt) {
-      const int dj = b.dep[j], q = w.e[j], P = w.anc[j];
-      int a = 0;
-      for (int i = P; i >= 0; i = w.anc[i]) ++a;
+      const int dj = b.dep[j], q = w.e[j], P = w.anc[j], a = acnt[j];
       w.ostart[j] = 2 * j + Vnb * (j - a);
       w.cstart[j] = 2 * q + Vnb * (q - 1 - a);
       int hv = 0, pr = -1, rr = -1;
@@ -639,6 +657,10 @@ struct Decoder {
     bool exact = false;
     if (tid == 0) reset_pvars(pvars(in.t + 1));  // the other parity set: free since the end of the previous step
     for (int i = tid; i < 2 * n; i += nt) w.hit[i] = 0;  // all readers of hit[] are behind the barrier above
+    {
+      int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;  // next step's paint buffers
+      for (int i = tid; i < K; i += nt) { oa[i] = -1; oc[i] = 0; }
+    }
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
       select_kth(S, K, pv);
       tau = (uint32_t)x.uni(w.vars[VAR_TAU]);
@@ -691,7 +713,6 @@ struct Decoder {
       x.sync_full();
       return;
     }
-    int dloc = kIntMax;
     uint32_t kloc = 0;
     for (int k = tid; k < n_new; k += nt) {
       const int s = surv[k];
@@ -709,9 +730,8 @@ struct Decoder {
         if (info_type(pinf) == T_REVIVED) { const int dx = b.dep[w.anc[pj]] + 1; l = dx < l ? dx : l; }
       }
       nb.lcp[k] = l;
-      int dd;
       if (type == T_SELF) {
-        nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = dd = b.dep[j];
+        nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = b.dep[j];
         nb.via[k] = b.via[j]; nb.viaanc[k] = b.viaanc[j]; nb.viach[k] = b.viach[j];
         nb.bprev[k] = w.b_new[j]; nb.nbprev[k] = w.nb_new[j]; nb.score[k] = w.sc_new[j]; nb.lpc[k] = b.lpc[j];
       } else {
@@ -730,14 +750,12 @@ struct Decoder {
           id = b.via[j];
           lpc = w.rev_lpc[j];
         }
-        nb.node[k] = id; nb.par[k] = b.node[P]; nb.ch[k] = c; nb.dep[k] = dd = b.dep[P] + 1;
+        nb.node[k] = id; nb.par[k] = b.node[P]; nb.ch[k] = c; nb.dep[k] = b.dep[P] + 1;
         nb.viaanc[k] = -1;
         nb.bprev[k] = CTC_NEG_MAX; nb.nbprev[k] = logp; nb.score[k] = logp; nb.lpc[k] = lpc;
       }
-      dloc = dd < dloc ? dd : dloc;
       kloc = w.skey[s] > kloc ? w.skey[s] : kloc;
     }
-    x.wave_min_to(&pv[P_NDMIN], dloc);
     x.wave_max_to(&pv[P_NMAXKEY], kloc);
     if (last) {  // the order std::nth_element left the survivors in (identity when it was not called)
       for (int q = tid; q < n_new; q += nt) w.fin[q] = exact ? rk[q] : q;
@@ -759,7 +777,6 @@ struct Decoder {
       }
       st_wlog = wl;
       st_maxkey = (uint32_t)x.uni(pv[P_NMAXKEY]);
-      st_dmin = x.uni(pv[P_NDMIN]);
       st_n = n_new;
       st_pool = pool_count + n_new;
     }

@@ -77,6 +77,22 @@ struct DevX {
   __device__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   __device__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+  __device__ void atomic_max(int *p, int v) { atomicMax(p, v); }
+  // a "group" = one wave: work items that the 64 lanes search / paint together
+  __device__ int group() const { return __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); }
+  __device__ int ngroups() const { return ((int)blockDim.x + 63) >> 6; }
+  __device__ int lane() const { return (int)threadIdx.x & 63; }
+  __device__ int lanes() const { return 64; }
+  __device__ unsigned long long ballot(bool p) const { return __ballot(p); }
+  // first q in [from, n) with arr[q] < bound (n if none); arguments uniform across the wave
+  __device__ int first_below(const int *arr, int from, int n, int bound) const {
+    for (int base = from; base < n; base += 64) {
+      const int q = base + ((int)threadIdx.x & 63);
+      const unsigned long long m = __ballot(q < n && arr[q] < bound);
+      if (m) return base + __ffsll((long long)m) - 1;
+    }
+    return n;
+  }
   __device__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
   // one LDS atomic per wave
   __device__ void wave_add(int *p, int v) {

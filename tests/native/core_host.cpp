@@ -22,6 +22,17 @@ struct HostX {
   void sync() {}
   void sync_full() {}
   int uni(int v) const { return v; }
+  int group() const { return 0; }
+  int ngroups() const { return 1; }
+  int lane() const { return 0; }
+  int lanes() const { return 1; }
+  unsigned long long ballot(bool p) const { return p ? 1ull : 0ull; }
+  int first_below(const int *arr, int from, int n, int bound) const {
+    int q = from;
+    while (q < n && arr[q] >= bound) ++q;
+    return q;
+  }
+  void atomic_max(int *p, int v) { *p = std::max(*p, v); }
   float unif(float v) const { return v; }
   void mark(int) {}
   int reduce_add(int v) { return v; }
