@@ -90,9 +90,9 @@ struct Dims {
 // the step after next without racing with threads that still read this one.
 enum {
   VAR_STATUS = 0,
-  VAR_FB0, VAR_FB1, VAR_FB2, VAR_FB3, VAR_CUT, VAR_TAU, VAR_TAUC, VAR_G, VAR_E, VAR_TIE,
+  VAR_FB0, VAR_FB1, VAR_FB2, VAR_FB3, VAR_CUT, VAR_TAU, VAR_TAUC, VAR_G, VAR_E,
   VAR_PAR0 = 12,  // first per-parity set
-  P_NPIN = 0, P_LCOUNT, P_SCOUNT, P_NDMIN, P_NMAXKEY, P_SIZE = 6,
+  P_NPIN = 0, P_LCOUNT, P_NMAXKEY, P_SIZE = 4,
   VAR_COUNT = VAR_PAR0 + 2 * P_SIZE
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
@@ -102,12 +102,13 @@ constexpr int kSerialCut = 96;  // introselect ranges at most this long are fini
 
 struct Work {
   Beam cur, nxt;
-  int *e, *anc, *ostart, *cstart, *hasvia, *pinr, *revr;  // per beam entry, this step
+  int *e, *anc, *ostart, *cstart, *pinr, *revr;  // per beam entry, this step
   int *ancbuf, *acntbuf;  // 2K each: nearest in-beam ancestor / number of in-beam ancestors, painted; by step parity
   uint32_t *hit;   // 2 words per entry: ranks (non-blank numbering) of the children that already exist
   float *b_new, *nb_new, *sc_new, *rev_lpc;
   int *cch;        // candidate characters of this step (unused in identity mode)
-  float *clp;      // their log-probs
+  float *clp;      // their log-probs (points into clpbuf: the buffer of the current frame)
+  float *clpbuf;   // two frames' worth: the next frame's row is staged while the current one is decoded
   int16_t *rank_of;  // V entries, -1 = not a candidate (only when Dims::use_rank_table; V <= 32767 then)
   uint32_t *skey, *sinfo, *pos;  // S_max (+1 for pos): score key, info word, scratch
   int *surv;       // 3K: slots of the survivors | their rank in slot (= DFS) order | inverse of that ranking
@@ -115,7 +116,6 @@ struct Work {
   uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition
   int *bins;       // kBins
   uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
-  int *lslot;      // kListCap: their slots
   int *fin, *sstack;
   int *vars;
 };
@@ -145,16 +145,15 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   }
   w.e = carve_ptr<int>(p, K); w.ancbuf = carve_ptr<int>(p, 2 * K); w.acntbuf = carve_ptr<int>(p, 2 * K); w.anc = w.ancbuf;
   w.ostart = carve_ptr<int>(p, K);
-  w.cstart = carve_ptr<int>(p, K); w.hasvia = carve_ptr<int>(p, K); w.pinr = carve_ptr<int>(p, K);
+  w.cstart = carve_ptr<int>(p, K); w.pinr = carve_ptr<int>(p, K);
   w.revr = carve_ptr<int>(p, K); w.hit = carve_ptr<uint32_t>(p, 2 * K);
   w.b_new = carve_ptr<float>(p, K); w.nb_new = carve_ptr<float>(p, K); w.sc_new = carve_ptr<float>(p, K); w.rev_lpc = carve_ptr<float>(p, K);
   w.cch = carve_ptr<int>(p, (size_t)d.Vc_max);
-  w.clp = carve_ptr<float>(p, (size_t)d.Vc_max);
+  w.clpbuf = carve_ptr<float>(p, 2 * (size_t)d.Vc_max); w.clp = w.clpbuf;
   w.rank_of = carve_ptr<int16_t>(p, d.use_rank_table ? (size_t)d.V : 0);
   w.skey = carve_ptr<uint32_t>(p, S);
   w.surv = carve_ptr<int>(p, 3 * K + 4);
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
-  w.lslot = carve_ptr<int>(p, kListCap + 4);
   w.fin = carve_ptr<int>(p, K);
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
@@ -202,12 +201,12 @@ struct Decoder {
   CTC_HD float lse(float a, float b) const { return ctcmath::lse(a, b, tbl); }
 
   // Step-to-step state, identical in every thread (kept in registers, not LDS)
-  int st_n = 1, st_pool = 1, st_dmin = 0, st_wlog = 32;
+  int st_n = 1, st_pool = 1, st_wlog = 32;
   uint32_t st_maxkey = 0;
 
   CTC_HD int *pvars(int t) const { return w.vars + VAR_PAR0 + (t & 1) * P_SIZE; }
   CTC_HD void reset_pvars(int *pv) const {
-    pv[P_NPIN] = 0; pv[P_LCOUNT] = 0; pv[P_SCOUNT] = 0; pv[P_NDMIN] = kIntMax; pv[P_NMAXKEY] = 0;
+    pv[P_NPIN] = 0; pv[P_LCOUNT] = 0; pv[P_NMAXKEY] = 0;
   }
 
   // ctc_beam_search_decoder.cpp:43-44 : root prefix, score = log_prob_b_prev = 0
@@ -223,7 +222,7 @@ struct Decoder {
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
     }
-    st_n = 1; st_pool = 1; st_dmin = 0; st_wlog = 32;  // first select looks at the whole key range
+    st_n = 1; st_pool = 1; st_wlog = 32;  // first select looks at the whole key range
     st_maxkey = ord_f32(0.f);
     for (int i = x.tid(); i < kBins + kBins / 16; i += x.nt()) w.bins[i] = 0;
     for (int i = x.tid(); i < 2 * d.K; i += x.nt()) w.hit[i] = 0;
@@ -278,7 +277,6 @@ struct Decoder {
     uint64_t lo = wd.lo, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
     int shift = wd.shift;
     int need = K, gbase = 0;
-    bool first = true;
     for (;;) {
       // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
       //    [2] #keys in the window, [3] #keys in b*.  Also re-zeroes bins[] and ends with a barrier.
@@ -338,7 +336,6 @@ struct Decoder {
         return;
       }
       // another histogram round over [lo, hi)
-      first = false;
       const uint64_t width = hi - lo;
       shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
       const uint32_t lo32 = (uint32_t)lo, span = (uint32_t)(hi - lo - 1);  // key in range <=> key - lo32 <= span
@@ -456,7 +453,9 @@ struct Decoder {
 
   // One time step.  w.clp/w.cch (and rank_of in pruned mode) hold this step's candidates; `last` selects the
   // bookkeeping that DecoderState::decode() needs (the permutation std::nth_element leaves behind).
-  CTC_HD void step(const StepIn &in, bool last) {
+  // `stage`/`stage_val`: in identity mode the caller hands over its prefetched value of the NEXT frame's row; it is
+  // parked in the other half of clpbuf before the closing fence, so the next frame starts without a load phase.
+  CTC_HD void step(const StepIn &in, bool last, bool stage = false, float stage_val = 0.f) {
     Beam &b = w.cur;
     Beam &nb = w.nxt;
     const int tid = x.tid(), nt = x.nt();
@@ -511,13 +510,12 @@ struct Decoder {
       const int dj = b.dep[j], q = w.e[j], P = w.anc[j], a = acnt[j];
       w.ostart[j] = 2 * j + Vnb * (j - a);
       w.cstart[j] = 2 * q + Vnb * (q - 1 - a);
-      int hv = 0, pr = -1, rr = -1;
+      int pr = -1, rr = -1;
       if (P >= 0) {
         if (b.dep[P] == dj - 1) {                            // parent in the beam: "hit" (path_trie.cpp:40-48)
           pr = rank_of_char(in, b.ch[j]);
         } else {
           // dead-interior child X of the nearest in-beam ancestor on the way down to j (alive because j is below it)
-          hv = 1;
           if (b.viaanc[j] != b.node[P]) {
             int hops = dj - b.dep[P] - 1, xn = b.node[j];
             for (int h = 0; h < hops; ++h) xn = pool[xn].parent;
@@ -534,7 +532,6 @@ struct Decoder {
           x.atomic_or(&w.hit[2 * P + (bit >> 5)], 1u << (bit & 31));
         }
       }
-      w.hasvia[j] = hv;
       w.pinr[j] = pr;
       w.revr[j] = rr;
       npin += pr >= 0;
@@ -763,7 +760,10 @@ struct Decoder {
     // un-register this step's candidates from the rank table
     if (!in.identity)
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
+    if (stage && tid < d.V) w.clpbuf[((in.t + 1) & 1) * d.Vc_max + tid] = stage_val;
+    x.mark(7);
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
+    x.mark(9);
     // every thread advances its copy of the step state
     {
       // next select window.  It is anchored at this step's best key (an upper bound for the next step's keys when
@@ -853,20 +853,26 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       pre_lp = rows[tid];
     }
   }
+  if (pr == nullptr && prefetch && len > 0) {  // frame 0 goes straight to LDS; from then on step() stages frame t+1
+    if (tid < d.V) w.clpbuf[tid] = pre_lp;
+    x.sync();
+  }
   for (int t = 0; t < len; ++t) {
     StepIn in;
     in.t = t;
+    bool stage = false;
     if (pr == nullptr) {
       in.Vc = d.V;
       in.identity = 1;
       in.blank_rank = blank;
       if (prefetch) {
-        if (tid < d.V) w.clp[tid] = pre_lp;
-        if (t + 1 < len && tid < d.V) pre_lp = rows[(size_t)(t + 1) * d.V + tid];
+        w.clp = w.clpbuf + (t & 1) * d.Vc_max;
+        stage = t + 1 < len;
+        if (stage && tid < d.V) pre_lp = rows[(size_t)(t + 1) * d.V + tid];  // consumed at the end of this frame
       } else {
         for (int r = tid; r < d.V; r += nt) w.clp[r] = rows[(size_t)t * d.V + r];
+        x.sync();
       }
-      x.sync();
     } else {
       in.identity = 0;
       if (prefetch) {
@@ -889,7 +895,8 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       in.blank_rank = x.uni((int)w.rank_of[blank]);
     }
     x.mark(10);
-    dec.step(in, t == len - 1);
+    dec.step(in, t == len - 1, stage, pre_lp);
+    x.mark(12);
     if (x.uni(w.vars[VAR_STATUS]) != ST_OK) return w.vars[VAR_STATUS];
   }
   dec.finish(len > 0, T_stride, out_tok, out_ts, out_score, out_len, n_results);

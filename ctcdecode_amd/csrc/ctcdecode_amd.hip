@@ -100,22 +100,6 @@ struct DevX {
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
   }
 
-  // Wave-aggregated append: lanes with `pred` get consecutive indices from *counter (one LDS atomic per wave).
-  // Must be called by every lane of the wave.
-  __device__ int append(int *counter, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return -1;
-    const int lane = (int)threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(m));
-    base = __builtin_amdgcn_readlane(base, leader);
-    return base + __popcll(m & ((1ull << lane) - 1ull));
-  }
-  __device__ void wave_min_to(int *p, int v) {
-    v = wave_min(v);
-    if ((threadIdx.x & 63) == 0 && v != ctcbeam::kIntMax) atomicMin(p, v);
-  }
   __device__ void wave_max_to(int *p, uint32_t v) {
     v = wave_max_u32(v);
     if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
@@ -214,20 +198,6 @@ struct DevX {
       }
     }
     sync();
-  }
-
-  // Sum over the workgroup, same value returned to every thread.  One barrier per call: consecutive calls alternate
-  // between two scratch rows, and a row is only rewritten after a later barrier that every reader has passed.
-  __device__ int reduce_add(int v) {
-    v = wave_sum(v);
-    const int wave = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
-    int *row = red + parity * 16;
-    parity ^= 1;
-    if ((threadIdx.x & 63) == 0) row[wave] = v;
-    sync();
-    int tot = 0;
-    for (int i = 0; i < nw; ++i) tot += row[i];
-    return tot;
   }
 
   // In-place exclusive prefix sum of a[0, n) in LDS; returns the total.  Each thread owns a contiguous chunk.

@@ -35,7 +35,6 @@ struct HostX {
   void atomic_max(int *p, int v) { *p = std::max(*p, v); }
   float unif(float v) const { return v; }
   void mark(int) {}
-  int reduce_add(int v) { return v; }
   uint32_t scan_excl(uint32_t *a, int n) {
     uint32_t run = 0;
     for (int i = 0; i < n; ++i) {
@@ -61,14 +60,12 @@ struct HostX {
     out[0] = bstar; out[1] = above; out[2] = total; out[3] = inb;
     for (int b = 0; b < kBins + kBins / 16; ++b) bins[b] = 0;
   }
-  int append(int *counter, bool pred) { return pred ? (*counter)++ : -1; }
   template <class Pred>
   void compact_slots(int S, int *out, Pred pred) {
     int k = 0;
     for (int s = 0; s < S; ++s)
       if (pred(s)) out[k++] = s;
   }
-  void wave_min_to(int *p, int v) { *p = std::min(*p, v); }
   void wave_max_to(int *p, uint32_t v) { *p = (int)std::max((uint32_t)*p, v); }
 };
 

@@ -208,6 +208,35 @@ def test_edge_cases_on_gpu(torch_mod):
         ou.assert_same(_with_nres(got, want), want, name)
 
 
+def test_host_pointer_entry_point(torch_mod):
+    """ctcd_beam_decode_host: the entry point a maintainer of the reference would bind in place of paddle_beam_decode
+     -- CPU buffers in, CPU buffers out, through the raw C ABI."""
+    import ctypes
+
+    import ctcdecode_amd._native as n
+
+    args, want = gu.load("ragged_b5_t60_k16")
+    probs = np.ascontiguousarray(args["probs"])
+    sl = np.ascontiguousarray(args["seq_lens"], np.int32)
+    B, T, V = probs.shape
+    K = args["beam"]
+    tok = np.full((B, K, T), -7, np.int32)
+    ts = np.full((B, K, T), -7, np.int32)
+    sc = np.full((B, K), -7, np.float32)
+    ln = np.full((B, K), -7, np.int32)
+    nres = np.zeros((B,), np.int32)
+    h = ctypes.c_void_p()
+    n.check(n.lib.ctcd_create(ctypes.byref(h), 0))
+    try:
+        n.check(n.lib.ctcd_beam_decode_host(h, probs.ctypes.data, sl.ctypes.data, B, T, V, K, 4, 1.0, args["cutoff_top_n"], args["blank_id"], 1,
+                                            tok.ctypes.data, ts.ctypes.data, sc.ctypes.data, ln.ctypes.data, nres.ctypes.data))
+    finally:
+        n.lib.ctcd_destroy(h)
+    got = dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)
+    ou.assert_same(got, want, "host entry point")
+    assert np.array_equal(nres, want["nres"])
+
+
 def test_empty_and_degenerate_batches(torch_mod):
     import ctcdecode_amd
 
