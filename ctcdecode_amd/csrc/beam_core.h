@@ -591,6 +591,7 @@ struct Decoder {
         if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
       }
     }
+    x.mark(1);
     if (!split || tid >= n1) {
       const int t2 = split ? tid - n1 : tid, nt2 = split ? nt - n1 : nt;
       int lp2 = 1;
