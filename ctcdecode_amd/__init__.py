@@ -11,7 +11,7 @@ import torch
 from . import _native
 from ._native import NativeError  # noqa: F401
 
-__all__ = ["CTCBeamDecoder", "NativeError"]
+__all__ = ["CTCBeamDecoder", "OnlineCTCBeamDecoder", "DecoderState", "NativeError"]
 
 
 class CTCBeamDecoder(object):
@@ -112,3 +112,115 @@ class CTCBeamDecoder(object):
             except Exception:
                 pass
             self._handle = None
+
+
+class OnlineCTCBeamDecoder(object):
+    """Streaming drop-in for ctcdecode/__init__.py:143-250 (no language model): feed an utterance chunk by chunk through a
+    ``DecoderState``; results are produced for the items whose ``is_eos_s`` entry is True.  The beam and node pool of
+    every stream stay in HBM between calls; ``timesteps`` count frames from the beginning of the stream."""
+
+    def __init__(self, labels, model_path=None, alpha=0, beta=0, cutoff_top_n=40, cutoff_prob=1.0, beam_width=100,
+                 num_processes=4, blank_id=0, log_probs_input=False, device=None):
+        self._cutoff_top_n = cutoff_top_n
+        self._beam_width = beam_width
+        self._scorer = None
+        self._num_processes = num_processes
+        self._labels = list(labels)
+        self._num_labels = len(labels)
+        self._blank_id = blank_id
+        self._log_probs = 1 if log_probs_input else 0
+        self._cutoff_prob = cutoff_prob
+        if model_path:
+            raise NotImplementedError("ctcdecode_amd: the KenLM scorer tier (model_path) is not built; decode without a language model")
+        if not torch.cuda.is_available():
+            raise RuntimeError("ctcdecode_amd: no HIP device visible; this decoder has no CPU path")
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self._device.index is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        h = ctypes.c_void_p()
+        _native.check(_native.lib.ctcd_create(ctypes.byref(h), self._device.index))
+        self._handle = h
+
+    def decode(self, probs, states, is_eos_s, seq_lens=None):
+        """Same contract as ctcdecode/__init__.py:189-238: returns CPU tensors (beam_results[B, R, L], beam_scores[B, K],
+        timesteps[B, R, L], out_lens[B, K]) with R = most results of any item that ended (0 if none), L = longest beam."""
+        if probs.dim() != 3:
+            raise ValueError("probs must be [batch, time, labels]")
+        B, T, V = probs.shape
+        if V != self._num_labels:
+            raise ValueError("probs.shape[2] (%d) does not match the number of labels (%d)" % (V, self._num_labels))
+        if len(states) != B or len(is_eos_s) != B:
+            raise ValueError("states and is_eos_s need one entry per batch item")
+        probs = probs.to(device=self._device, dtype=torch.float32).contiguous()
+        if seq_lens is None:
+            lens_cpu = torch.full((B,), T, dtype=torch.int32)
+        else:
+            lens_cpu = seq_lens.detach().cpu().to(torch.int32).contiguous()
+        K = self._beam_width
+        eos = (ctypes.c_ubyte * max(B, 1))(*[1 if e else 0 for e in is_eos_s])
+        ptrs = (ctypes.c_void_p * max(B, 1))(*[st._ptr(self) for st in states])
+        out_T = 0
+        for b in range(B):
+            if is_eos_s[b]:
+                out_T = max(out_T, int(_native.lib.ctcd_stream_frames(ptrs[b])) + max(0, min(int(lens_cpu[b]), T)))
+        with torch.cuda.device(self._device):
+            output = torch.empty((B, K, out_T), dtype=torch.int32, device=self._device)
+            timesteps = torch.empty((B, K, out_T), dtype=torch.int32, device=self._device)
+            scores = torch.empty((B, K), dtype=torch.float32, device=self._device)
+            out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
+            nres = torch.empty((B,), dtype=torch.int32, device=self._device)
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            _native.check(_native.lib.ctcd_stream_decode(
+                self._handle, ptrs, eos, probs.data_ptr(), lens_cpu.data_ptr(), B, T, V, K, self._num_processes,
+                float(self._cutoff_prob), int(self._cutoff_top_n), int(self._blank_id), self._log_probs,
+                output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), nres.data_ptr(), out_T, stream))
+            _native.check(_native.lib.ctcd_check_status(self._handle, B))
+        nres_c = nres.cpu()
+        out_len_c = out_len.cpu()
+        R = int(nres_c.max()) if B else 0          # binding.cpp:186-205: sized to the most results / the longest beam
+        L = int(out_len_c.max()) if B and R else 0
+        return output[:, :R, :L].cpu().contiguous(), scores.cpu(), timesteps[:, :R, :L].cpu().contiguous(), out_len_c
+
+    def character_based(self):
+        return None
+
+    def max_order(self):
+        return None
+
+    def dict_size(self):
+        return None
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                _native.lib.ctcd_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+
+class DecoderState(object):
+    """State of one audio stream (ctcdecode/__init__.py:253-272).  Bound to the decoder it is first used with; not reusable
+    after its stream ended, as in the reference."""
+
+    def __init__(self, decoder):
+        self._decoder = decoder
+        h = ctypes.c_void_p()
+        _native.check(_native.lib.ctcd_stream_create(decoder._handle, ctypes.byref(h), decoder._num_labels, decoder._beam_width, 0))
+        self.state = h
+
+    def _ptr(self, decoder):
+        if decoder is not self._decoder:
+            raise ValueError("DecoderState used with a different decoder than it was created for")
+        return self.state.value
+
+    def __del__(self):
+        h = getattr(self, "state", None)
+        d = getattr(self, "_decoder", None)
+        if h is not None and h.value and d is not None and getattr(d, "_handle", None) is not None:
+            try:
+                _native.lib.ctcd_stream_destroy(d._handle, h)
+            except Exception:
+                pass
+            self.state = None

@@ -170,6 +170,18 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   return (size_t)(p - base);
 }
 
+// Persistent decoder state of one audio stream (the reference's DecoderState object kept alive between decode()
+// calls, ctc_beam_search_decoder.h:73-124 / ctcdecode/__init__.py:253-272), stored in HBM between launches:
+// hdr[0..7] = {frames fed so far (abs_time_step, ctc_beam_search_decoder.cpp:69), beam size, pool count, window log,
+// best key, fin valid, reserved...}; arrays = the 12 beam arrays then fin, K entries each.  The node pool lives in
+// the same allocation and is passed separately.
+struct StreamState {
+  int *hdr;
+  int *arrays;
+  int finish;  // this call ends the stream: run DecoderState::decode()
+};
+enum { SH_FRAMES = 0, SH_N, SH_POOL, SH_WLOG, SH_MAXKEY, SH_FINVALID, SH_WORDS = 8 };
+
 struct StepIn {
   int t;           // absolute time step
   int Vc;          // number of candidate characters
@@ -230,6 +242,46 @@ struct Decoder {
     if (d.use_rank_table)
       for (int c = x.tid(); c < d.V; c += x.nt()) w.rank_of[c] = -1;
     x.sync_full();
+  }
+
+  // Restore / park the beam of a stream.  Transient per-frame scratch is re-initialised exactly as init() does.
+  CTC_HD void load_state(const StreamState &ss) {
+    const int tid = x.tid(), nt = x.nt(), K = d.K;
+    st_n = x.uni(ss.hdr[SH_N]); st_pool = x.uni(ss.hdr[SH_POOL]); st_wlog = x.uni(ss.hdr[SH_WLOG]);
+    st_maxkey = (uint32_t)x.uni(ss.hdr[SH_MAXKEY]);
+    Beam &b = w.cur;
+    int *ia[8] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach};
+    float *fa[4] = {b.bprev, b.nbprev, b.score, b.lpc};
+    for (int i = tid; i < st_n; i += nt) {
+      for (int a = 0; a < 8; ++a) ia[a][i] = ss.arrays[a * K + i];
+      for (int a = 0; a < 4; ++a) fa[a][i] = ctcmath::bits_to_f32((uint32_t)ss.arrays[(8 + a) * K + i]);
+      w.fin[i] = ss.arrays[12 * K + i];
+    }
+    if (tid == 0) {
+      w.vars[VAR_STATUS] = ST_OK;
+      reset_pvars(pvars(0));
+      reset_pvars(pvars(1));
+    }
+    for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
+    for (int i = tid; i < 2 * K; i += nt) { w.hit[i] = 0; w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
+    if (d.use_rank_table)
+      for (int c = tid; c < d.V; c += nt) w.rank_of[c] = -1;
+    x.sync_full();
+  }
+  CTC_HD void save_state(const StreamState &ss, int frames) {
+    const int tid = x.tid(), nt = x.nt(), K = d.K;
+    const Beam &b = w.cur;
+    const int *ia[8] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach};
+    const float *fa[4] = {b.bprev, b.nbprev, b.score, b.lpc};
+    for (int i = tid; i < st_n; i += nt) {
+      for (int a = 0; a < 8; ++a) ss.arrays[a * K + i] = ia[a][i];
+      for (int a = 0; a < 4; ++a) ss.arrays[(8 + a) * K + i] = (int)ctcmath::f32_to_bits(fa[a][i]);
+      ss.arrays[12 * K + i] = w.fin[i];
+    }
+    if (tid == 0) {
+      ss.hdr[SH_FRAMES] = frames; ss.hdr[SH_N] = st_n; ss.hdr[SH_POOL] = st_pool; ss.hdr[SH_WLOG] = st_wlog;
+      ss.hdr[SH_MAXKEY] = (int)st_maxkey;
+    }
   }
 
   CTC_HD int rank_of_char(const StepIn &in, int c) const {
@@ -837,9 +889,12 @@ struct PrunedRows {
 template <class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int pool_cap, const uint64_t *tbl, int T_stride, int32_t *out_tok,
-                            int32_t *out_ts, float *out_score, int32_t *out_len, int32_t *n_results) {
+                            int32_t *out_ts, float *out_score, int32_t *out_len, int32_t *n_results,
+                            const StreamState *ss = nullptr) {
   Decoder<X> dec(x, w, d, blank, pool, pool_cap, tbl);
-  dec.init();
+  // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
+  const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
+  if (t0 > 0) dec.load_state(*ss); else dec.init();
   const int tid = x.tid(), nt = x.nt();
   // Prefetch: the candidates of step t+1 are requested from HBM before step t runs, so the latency hides behind it.
   const int width = pr ? pr->stride : d.V;
@@ -855,19 +910,19 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     }
   }
   if (pr == nullptr && prefetch && len > 0) {  // frame 0 goes straight to LDS; from then on step() stages frame t+1
-    if (tid < d.V) w.clpbuf[tid] = pre_lp;
+    if (tid < d.V) w.clpbuf[(t0 & 1) * d.Vc_max + tid] = pre_lp;
     x.sync();
   }
   for (int t = 0; t < len; ++t) {
     StepIn in;
-    in.t = t;
+    in.t = t0 + t;
     bool stage = false;
     if (pr == nullptr) {
       in.Vc = d.V;
       in.identity = 1;
       in.blank_rank = blank;
       if (prefetch) {
-        w.clp = w.clpbuf + (t & 1) * d.Vc_max;
+        w.clp = w.clpbuf + ((t0 + t) & 1) * d.Vc_max;
         stage = t + 1 < len;
         if (stage && tid < d.V) pre_lp = rows[(size_t)(t + 1) * d.V + tid];  // consumed at the end of this frame
       } else {
@@ -900,7 +955,8 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     x.mark(12);
     if (x.uni(w.vars[VAR_STATUS]) != ST_OK) return w.vars[VAR_STATUS];
   }
-  dec.finish(len > 0, T_stride, out_tok, out_ts, out_score, out_len, n_results);
+  if (ss) dec.save_state(*ss, t0 + len);
+  if (!ss || ss->finish) dec.finish(t0 + len > 0, T_stride, out_tok, out_ts, out_score, out_len, n_results);
   x.sync();
   x.mark(11);
   return ST_OK;

@@ -244,6 +244,12 @@ struct KernelArgs {
   long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
   char *far;                // BIG layout: per-utterance HBM scratch, far_stride bytes each
   long long far_stride;
+  // streaming (ctcd_stream_decode): per item, the HBM block that holds its parked beam + node pool
+  char **st_base;           // [B] or null
+  const int *st_poolcap;    // [B] nodes the pool of each stream can hold
+  const unsigned char *st_eos;  // [B] 1: this call ends the stream (run decode())
+  long long st_pool_off;    // byte offset of the node pool inside a stream block
+  int out_T;                // row stride of out_tok / out_ts (== T for the one-shot call)
   const int *pr_cnt;        // pruned mode: [B, T] candidates per frame (null in identity mode)
   const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
   const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
@@ -266,7 +272,6 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();
   if (PROF) x.last = (long long)wall_clock64();
-  const size_t kt = (size_t)a.K * a.T;
   PrunedRows prow;
   if (a.pr_cnt) {
     prow.cnt = a.pr_cnt + (size_t)b * a.T;
@@ -274,11 +279,23 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
     prow.lp = a.pr_lp + (size_t)b * a.T * a.pr_stride;
     prow.stride = a.pr_stride;
   }
+  PoolNode *pool = a.pool + (size_t)b * a.pool_stride;
+  int pool_cap = (int)a.pool_stride;
+  StreamState ss;
+  if (a.st_base) {
+    char *base = a.st_base[b];
+    ss.hdr = (int *)base;
+    ss.arrays = ss.hdr + SH_WORDS;
+    ss.finish = a.st_eos[b];
+    pool = (PoolNode *)(base + a.st_pool_off);
+    pool_cap = a.st_poolcap[b];
+  }
+  const size_t ko = (size_t)a.K * a.out_T;
   const int st = decode_utterance(x, w, a.dims, a.blank, a.pr_cnt ? nullptr : a.probs + (size_t)b * a.T * a.V,
-                                  a.pr_cnt ? &prow : (const PrunedRows *)nullptr, len,
-                                  a.pool + (size_t)b * a.pool_stride, (int)a.pool_stride, tbl, a.T,
-                                  a.out_tok + (size_t)b * kt, a.out_ts + (size_t)b * kt, a.out_score + (size_t)b * a.K,
-                                  a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr);
+                                  a.pr_cnt ? &prow : (const PrunedRows *)nullptr, len, pool, pool_cap, tbl, a.out_T,
+                                  a.out_tok + (size_t)b * ko, a.out_ts + (size_t)b * ko, a.out_score + (size_t)b * a.K,
+                                  a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr,
+                                  a.st_base ? &ss : (const StreamState *)nullptr);
   if (threadIdx.x == 0) a.status[b] = st;
   if (PROF && threadIdx.x < 16) a.prof[(size_t)b * 16 + threadIdx.x] = prof[threadIdx.x];
 }
@@ -607,7 +624,7 @@ struct ctcd_decoder {
   int device = 0;
   int threads = 1024;
   int max_lds = 0;
-  Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far;
+  Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
   long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
   bool tables_ready = false;
   bool timing = false;
@@ -617,7 +634,24 @@ struct ctcd_decoder {
   std::mutex mu;
 };
 
+// One audio stream's parked decoder state (ctcd_stream_*): a single HBM block [header | beam arrays | node pool].
+struct ctcd_stream {
+  char *block = nullptr;
+  size_t bytes = 0;
+  int V = 0, beam = 0;
+  long long frames = 0;      // frames fed so far (host mirror of the header word)
+  long long cap_frames = 0;  // frames the node pool can take
+};
+
 namespace {
+
+struct StreamCall {          // extra arguments of a streaming decode
+  ctcd_stream **states;
+  const unsigned char *is_eos;  // host
+  int out_T;
+};
+
+size_t stream_pool_offset(int beam) { return ((size_t)(SH_WORDS + 13 * (size_t)beam) * 4 + 255) / 256 * 256; }
 
 Dims make_dims(int beam, int V, int cutoff_top_n, double cutoff_prob) {
   const bool pruned = cutoff_prob < 1.0 || cutoff_top_n < V;
@@ -712,7 +746,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   (void)hipSetDevice(d->device);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
-  d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release();
+  d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release();
   delete d;
 }
 
@@ -722,11 +756,15 @@ int ctcd_set_threads(ctcd_decoder *d, int t) {
   return CTCD_OK;
 }
 
-int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
-                     int /*num_processes*/, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
-                     int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
+static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                         double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, int32_t *out_tok, int32_t *out_ts,
+                         float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_, const StreamCall *sc) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
-  int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, out_tok, out_ts, out_sc, out_len);
+  const int out_T = sc ? sc->out_T : T;
+  // (a streaming call in which no stream ends has out_T == 0 and may pass null token / timestep buffers)
+  const bool no_rows = sc && out_T == 0;
+  int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, no_rows ? (const void *)d : (const void *)out_tok,
+                      no_rows ? (const void *)d : (const void *)out_ts, out_sc, out_len);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(d->mu);
   hipStream_t stream = (hipStream_t)stream_;
@@ -750,13 +788,14 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
   if (big && (rc = d->far.ensure((size_t)B * far_bytes))) return rc;
 
   // outputs: everything outside the valid region is defined as 0
-  const size_t kt = (size_t)B * beam * T;
+  const size_t kt = (size_t)B * beam * out_T;
   if (kt) {
     HIP_TRY(hipMemsetAsync(out_tok, 0, kt * 4, stream));
     HIP_TRY(hipMemsetAsync(out_ts, 0, kt * 4, stream));
   }
   HIP_TRY(hipMemsetAsync(out_sc, 0, (size_t)B * beam * 4, stream));
   HIP_TRY(hipMemsetAsync(out_len, 0, (size_t)B * beam * 4, stream));
+  if (sc && n_results) HIP_TRY(hipMemsetAsync(n_results, 0, (size_t)B * 4, stream));
 
   if (!d->tables_ready) {
     if ((rc = d->tables.ensure(sizeof(ctcmath::Tables)))) return rc;
@@ -764,8 +803,28 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
     d->tables_ready = true;
   }
   const long long pool_stride = (long long)beam * T + 1;
-  if ((rc = d->pool.ensure((size_t)B * pool_stride * sizeof(PoolNode)))) return rc;
+  if (!sc && (rc = d->pool.ensure((size_t)B * pool_stride * sizeof(PoolNode)))) return rc;
   if ((rc = d->status.ensure((size_t)B * 4))) return rc;
+  // streaming: per-item block pointers, pool capacities and end-of-stream flags go to the device
+  char **st_base = nullptr;
+  int *st_cap = nullptr;
+  unsigned char *st_eos = nullptr;
+  if (sc) {
+    const size_t off_cap = (size_t)B * 8, off_eos = off_cap + (size_t)B * 4;
+    if ((rc = d->st_args.ensure(off_eos + (size_t)B + 16))) return rc;
+    std::vector<char> hostbuf(off_eos + (size_t)B);
+    for (int b = 0; b < B; ++b) {
+      ctcd_stream *st = sc->states[b];
+      ((char **)hostbuf.data())[b] = st->block;
+      ((int *)(hostbuf.data() + off_cap))[b] = (int)(st->cap_frames * beam + 1);
+      hostbuf[off_eos + b] = sc->is_eos[b] ? 1 : 0;
+    }
+    HIP_TRY(hipMemcpyAsync(d->st_args.p, hostbuf.data(), hostbuf.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // hostbuf is about to go out of scope
+    st_base = (char **)d->st_args.p;
+    st_cap = (int *)((char *)d->st_args.p + off_cap);
+    st_eos = (unsigned char *)d->st_args.p + off_eos;
+  }
 
   const float *logp = probs;
   d->prune_host_rows = 0;
@@ -869,6 +928,8 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
   a.pool = (PoolNode *)d->pool.p; a.pool_stride = pool_stride; a.tables = (const uint64_t *)d->tables.p;
   a.out_tok = out_tok; a.out_ts = out_ts; a.out_len = out_len; a.n_results = n_results; a.out_score = out_sc;
   a.status = (int32_t *)d->status.p;
+  a.st_base = st_base; a.st_poolcap = st_cap; a.st_eos = st_eos; a.st_pool_off = (long long)stream_pool_offset(beam);
+  a.out_T = out_T;
   a.pr_cnt = nullptr; a.pr_ch = nullptr; a.pr_lp = nullptr; a.pr_stride = 0;
   if (dims.use_rank_table) {
     a.pr_cnt = (const int *)d->pr_cnt.p; a.pr_ch = (const int *)d->pr_ch.p; a.pr_lp = (const float *)d->pr_lp.p;
@@ -888,6 +949,84 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
   HIP_TRY(hipLaunchKernel(fn, dim3(B), dim3(d->threads), kargs, lds, stream));
   HIP_TRY(hipGetLastError());
   if (d->timing) HIP_TRY(hipEventRecord(d->ev1, stream));
+  return CTCD_OK;
+}
+
+int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                     int /*num_processes*/, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                     int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
+  return decode_common(d, probs, seq_lens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok, out_ts, out_sc,
+                       out_len, n_results, stream_, nullptr);
+}
+
+// ---- streaming: DecoderState kept between calls (ctcdecode/__init__.py:143-272, binding.cpp:153-265)
+int ctcd_stream_create(ctcd_decoder *d, ctcd_stream **out, int V, int beam, int frames_hint) {
+  if (!d || !out || V <= 0 || beam <= 0 || beam > kMaxBeam) return fail(CTCD_EINVAL, "bad stream parameters");
+  HIP_TRY(hipSetDevice(d->device));
+  ctcd_stream *st = new ctcd_stream;
+  st->V = V;
+  st->beam = beam;
+  st->cap_frames = frames_hint > 0 ? frames_hint : 1024;
+  st->bytes = stream_pool_offset(beam) + ((size_t)st->cap_frames * beam + 1) * sizeof(PoolNode);
+  hipError_t e = hipMalloc((void **)&st->block, st->bytes);
+  if (e != hipSuccess) { delete st; return fail(CTCD_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  e = hipMemset(st->block, 0, stream_pool_offset(beam));  // frames == 0: the first call initialises the beam
+  if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(CTCD_EHIP, std::string("hipMemset: ") + hipGetErrorString(e)); }
+  *out = st;
+  return CTCD_OK;
+}
+
+void ctcd_stream_destroy(ctcd_decoder *d, ctcd_stream *st) {
+  if (!st) return;
+  if (d) (void)hipSetDevice(d->device);
+  if (st->block) (void)hipFree(st->block);
+  delete st;
+}
+
+long long ctcd_stream_frames(const ctcd_stream *st) { return st ? st->frames : -1; }
+
+int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned char *is_eos, const float *probs,
+                       const int32_t *seq_lens_host, int B, int T, int V, int beam, int /*num_processes*/, double cutoff_prob,
+                       int cutoff_top_n, int blank_id, int log_input, int32_t *out_tok, int32_t *out_ts, float *out_sc,
+                       int32_t *out_len, int32_t *n_results, int out_T, void *stream_) {
+  if (!d || !states || !is_eos || B < 0 || T < 0 || out_T < 0) return fail(CTCD_EINVAL, "bad arguments");
+  if (B == 0) return CTCD_OK;
+  HIP_TRY(hipSetDevice(d->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<int32_t> lens(B);
+  for (int b = 0; b < B; ++b) {
+    ctcd_stream *st = states[b];
+    if (!st || st->V != V || st->beam != beam) return fail(CTCD_EINVAL, "stream state does not match the decoder configuration");
+    for (int c = 0; c < b; ++c)
+      if (states[c] == st) return fail(CTCD_EINVAL, "the same stream state appears twice in one batch");
+    int len = seq_lens_host ? seq_lens_host[b] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);  // binding.cpp:171
+    lens[b] = len;
+    if (is_eos[b] && st->frames + len > out_T) return fail(CTCD_EINVAL, "out_T is smaller than the number of frames of a finishing stream");
+    if ((st->frames + len) * (long long)beam + 1 > 0x7fffffffLL) return fail(CTCD_EUNSUPPORTED, "stream too long for this beam width");
+    if (st->frames + len > st->cap_frames) {  // grow the node pool (device-to-device copy of the parked state)
+      long long cap = st->cap_frames * 2;
+      while (cap < st->frames + len) cap *= 2;
+      const size_t bytes = stream_pool_offset(beam) + ((size_t)cap * beam + 1) * sizeof(PoolNode);
+      char *nb = nullptr;
+      HIP_TRY(hipMalloc((void **)&nb, bytes));
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipMemcpy(nb, st->block, stream_pool_offset(beam) + ((size_t)st->frames * beam + 1) * sizeof(PoolNode), hipMemcpyDeviceToDevice));
+      (void)hipFree(st->block);
+      st->block = nb;
+      st->bytes = bytes;
+      st->cap_frames = cap;
+    }
+  }
+  int rc;
+  if ((rc = d->stage_in.ensure((size_t)B * 4 + 16))) return rc;
+  HIP_TRY(hipMemcpyAsync(d->stage_in.p, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  StreamCall sc{states, is_eos, out_T};
+  rc = decode_common(d, probs, (const int32_t *)d->stage_in.p, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok,
+                     out_ts, out_sc, out_len, n_results, stream_, &sc);
+  if (rc) return rc;
+  for (int b = 0; b < B; ++b) states[b]->frames += lens[b];
   return CTCD_OK;
 }
 

@@ -59,6 +59,22 @@ int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *
                           int32_t *out_tokens, int32_t *out_timesteps, float *out_scores, int32_t *out_lens,
                           int32_t *n_results);
 
+/* ---- Streaming ("online") decoding: replaces ctcdecode/src/binding.cpp:153-265 (paddle_get_decoder_state,
+ * paddle_beam_decode_with_given_state, paddle_release_state) = DecoderState objects kept alive between calls
+ * (ctcdecode/src/ctc_beam_search_decoder.cpp:230-243,288-317).  A ctcd_stream parks one utterance's beam and node pool
+ * in HBM between launches; frame numbers in `timesteps` keep counting across chunks (abs_time_step, :69).
+ * ctcd_stream_decode feeds chunk b (probs[b, 0:min(seq_lens_host[b], T)], DEVICE pointer) to states[b]; where
+ * is_eos[b] != 0 the stream's final beams are written to row b of the outputs (row stride out_T >= total frames of that
+ * stream), elsewhere row b stays zero and n_results[b] = 0.  seq_lens_host and is_eos are HOST arrays (B entries). */
+typedef struct ctcd_stream ctcd_stream;
+int ctcd_stream_create(ctcd_decoder *dec, ctcd_stream **out, int V, int beam, int frames_hint);
+void ctcd_stream_destroy(ctcd_decoder *dec, ctcd_stream *st);
+long long ctcd_stream_frames(const ctcd_stream *st);
+int ctcd_stream_decode(ctcd_decoder *dec, ctcd_stream **states, const unsigned char *is_eos, const float *probs,
+                       const int32_t *seq_lens_host, int B, int T, int V, int beam, int num_processes, double cutoff_prob,
+                       int cutoff_top_n, int blank_id, int log_input, int32_t *out_tokens, int32_t *out_timesteps,
+                       float *out_scores, int32_t *out_lens, int32_t *n_results, int out_T, void *stream);
+
 /* Host check of the per-item status words written by the last ctcd_beam_decode (synchronises the device). */
 int ctcd_check_status(ctcd_decoder *dec, int B);
 

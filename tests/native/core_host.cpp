@@ -148,3 +148,35 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
   for (auto &t : pool_threads) t.join();
   return bad ? -bad : 1;
 }
+
+// Streaming form of the same core: every utterance is fed chunk by chunk (frame boundaries in `bounds`, nchunks + 1
+// increasing values from 0 to T), state parked in a StreamState between chunks, results taken at the last chunk.
+// Must reproduce the one-shot decode exactly.  No vocabulary pruning here (identity candidate lists).
+extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int V, int beam, int blank_id, const int32_t *bounds,
+                                          int nchunks, int32_t *out_tokens, int32_t *out_timesteps, float *out_scores,
+                                          int32_t *out_lens, int32_t *n_results) {
+  using namespace ctcbeam;
+  Dims d;
+  d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0;
+  Work w;
+  size_t far_bytes = 0;
+  std::vector<char> mem(carve<false>(w, nullptr, nullptr, d, &far_bytes) + 64);
+  for (int b = 0; b < B; ++b) {
+    std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
+    std::vector<int> hdr(SH_WORDS, 0), arrays((size_t)13 * beam, 0);
+    for (int c = 0; c < nchunks; ++c) {
+      const int lo = bounds[c], hi = bounds[c + 1];
+      // a fresh workspace every chunk, as a new kernel launch would have
+      std::fill(mem.begin(), mem.end(), (char)0x5a);
+      carve<false>(w, mem.data(), nullptr, d, nullptr);
+      HostX x;
+      StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
+      int st = decode_utterance(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
+                                (int)pool.size(), ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T,
+                                out_timesteps + (size_t)b * beam * T, out_scores + (size_t)b * beam, out_lens + (size_t)b * beam,
+                                n_results + b, &ss);
+      if (st != ST_OK) return -st;
+    }
+  }
+  return 1;
+}

@@ -135,3 +135,21 @@ def decode_core_host(probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top
     if rc != 1:
         raise RuntimeError("core returned %d" % rc)
     return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)
+
+
+def decode_core_host_chunked(probs, bounds, beam=100, blank_id=0):
+    """The host build of the core fed chunk by chunk (bounds = frame boundaries 0 < ... < T) through its stream state."""
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    B, T, V = probs.shape
+    bounds = np.ascontiguousarray([0] + [int(x) for x in bounds] + [T], dtype=np.int32)
+    tok = np.zeros((B, beam, T), np.int32)
+    ts = np.zeros((B, beam, T), np.int32)
+    sc = np.zeros((B, beam), np.float32)
+    ln = np.zeros((B, beam), np.int32)
+    nres = np.zeros((B,), np.int32)
+    lib = ctypes.CDLL(build_core_host())
+    rc = lib.ctccore_decode_chunked_f32(_ptr(probs, _f32p), B, T, V, beam, blank_id, _ptr(bounds, _i32p), len(bounds) - 1,
+                                        _ptr(tok, _i32p), _ptr(ts, _i32p), _ptr(sc, _f32p), _ptr(ln, _i32p), _ptr(nres, _i32p))
+    if rc != 1:
+        raise RuntimeError("core returned %d" % rc)
+    return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)

@@ -45,6 +45,16 @@ def test_python_signature_mirrors_reference():
     assert list(inspect.signature(ctcdecode_amd.CTCBeamDecoder.decode).parameters) == ["self", "probs", "seq_lens"]
 
 
+def test_online_signature_mirrors_reference():
+    import ctcdecode_amd
+
+    sig = inspect.signature(ctcdecode_amd.OnlineCTCBeamDecoder.__init__)
+    assert list(sig.parameters)[1:11] == ["labels", "model_path", "alpha", "beta", "cutoff_top_n", "cutoff_prob", "beam_width", "num_processes", "blank_id", "log_probs_input"]
+    # ctcdecode/__init__.py:189
+    assert list(inspect.signature(ctcdecode_amd.OnlineCTCBeamDecoder.decode).parameters) == ["self", "probs", "states", "is_eos_s", "seq_lens"]
+    assert list(inspect.signature(ctcdecode_amd.DecoderState.__init__).parameters) == ["self", "decoder"]
+
+
 def test_product_does_not_touch_the_oracle():
     """The product path must never import/load anything under oracle/ (it is test infrastructure)."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ctcdecode_amd")):

@@ -79,3 +79,16 @@ def test_core_hbm_scratch_layout(monkeypatch):
     monkeypatch.setenv("CTC_HOST_BIG", "1")
     lp = ou.synth_logprobs(2, 150, 29, 44, quant=0.5)
     ou.assert_same(ou.decode(lp, beam=64), ou.decode_core_host(lp, beam=64))
+
+
+def test_core_streaming_equals_one_shot():
+    """The stream state (beam parked between chunks) on the host build: arbitrary chunkings, empty chunks included."""
+    rng = np.random.default_rng(3)
+    for it in range(40):
+        V = int(rng.choice([3, 9, 29]))
+        K = int(rng.choice([2, 16, 50, 100]))
+        T = int(rng.integers(2, 150))
+        quant = [None, 0.5, 1.0][int(rng.integers(0, 3))]
+        lp = ou.synth_logprobs(2, T, V, 900 + it, quant=quant, blank_bias=float(rng.choice([0, 3])))
+        bounds = sorted(set(int(x) for x in rng.integers(0, T + 1, size=int(rng.integers(0, 6)))))
+        ou.assert_same(ou.decode(lp, beam=K), ou.decode_core_host_chunked(lp, bounds, beam=K), "chunks %s" % bounds)

@@ -237,6 +237,76 @@ def test_host_pointer_entry_point(torch_mod):
     assert np.array_equal(nres, want["nres"])
 
 
+def test_streaming_reference_cases(torch_mod):
+    """tests/test_decode.py:117-139,161-187 of the reference (online decoder, no LM): whole utterance in one call, and
+    split into two chunks."""
+    import ctcdecode_amd
+
+    vocab = ["'", " ", "a", "b", "c", "d", "_"]
+    args, _ = gu.load("ref_fixtures_prob")
+    probs = torch_mod.from_numpy(args["probs"])
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder(vocab, beam_width=20, blank_id=vocab.index("_"))
+    s1, s2 = ctcdecode_amd.DecoderState(dec), ctcdecode_amd.DecoderState(dec)
+    out, sc, ts, ln = dec.decode(probs, [s1, s2], [True, True])
+    assert ["".join(vocab[x] for x in out[b][0][: ln[b][0]]) for b in range(2)] == ["acdc", "b'a"]
+    s1, s2 = ctcdecode_amd.DecoderState(dec), ctcdecode_amd.DecoderState(dec)
+    out, sc, ts, ln = dec.decode(probs[:, :2], [s1, s2], [False, False])
+    assert tuple(out.shape) == (2, 0, 0) and (ln == 0).all()
+    out, sc, ts, ln = dec.decode(probs[:, 2:], [s1, s2], [True, True])
+    assert ["".join(vocab[x] for x in out[b][0][: ln[b][0]]) for b in range(2)] == ["acdc", "b'a"]
+    assert out.shape[2] >= int(ln.max())  # test_online_decoder_decoding_with_a_lot_calls_no_lm_check_size
+
+
+@pytest.mark.parametrize("case", [dict(T=240, V=29, K=50, seed=61, cuts=[1, 2, 100, 100, 239]), dict(T=150, V=9, K=100, seed=62, quant=0.5, cuts=[0, 75, 150]),
+                                  dict(T=300, V=29, K=20, seed=63, blank_bias=4.0, cuts=[37, 38, 200]), dict(T=120, V=64, K=16, seed=64, top_n=8, cuts=[60])],
+                         ids=lambda c: "T%(T)d_V%(V)d_K%(K)d" % c)
+def test_streaming_equals_one_shot(torch_mod, case):
+    """Feeding an utterance in arbitrary chunks (empty ones included, also an empty final chunk) must give exactly the
+    one-shot result, which is checked against the oracle; timesteps keep counting across chunks."""
+    import ctcdecode_amd
+
+    c = case
+    B = 3
+    lp = ou.synth_logprobs(B, c["T"], c["V"], c["seed"], quant=c.get("quant"), blank_bias=c.get("blank_bias", 0.0))
+    want = ou.decode(lp, beam=c["K"], cutoff_top_n=c.get("top_n", 40), which="restated")
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(c["V"])], beam_width=c["K"], cutoff_top_n=c.get("top_n", 40), log_probs_input=True)
+    states = [ctcdecode_amd.DecoderState(dec) for _ in range(B)]
+    x = torch_mod.from_numpy(lp)
+    bounds = [0] + list(c["cuts"]) + [c["T"]]
+    for i in range(len(bounds) - 1):
+        last = i == len(bounds) - 2
+        out, sc, ts, ln = dec.decode(x[:, bounds[i]:bounds[i + 1]], states, [last] * B)
+    K, T = c["K"], c["T"]
+    L = out.shape[2]
+    got = dict(tokens=np.zeros((B, K, T), np.int32), timesteps=np.zeros((B, K, T), np.int32), scores=sc.numpy(), lens=ln.numpy(), nres=want["nres"])
+    got["tokens"][:, : out.shape[1], :L] = out.numpy()
+    got["timesteps"][:, : out.shape[1], :L] = ts.numpy()
+    ou.assert_same(got, want, "chunked")
+
+
+def test_streaming_mixed_batch_and_growth(torch_mod):
+    """Streams of different ages in one batch (one ends while the other continues), ragged chunk lengths, and a stream
+    that outgrows its initial node pool (1024 frames)."""
+    import ctcdecode_amd
+
+    V, K = 29, 12
+    lp = ou.synth_logprobs(2, 1500, V, 66)
+    want = ou.decode(lp, np.array([1500, 700], np.int32), beam=K, which="restated")
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], beam_width=K, log_probs_input=True)
+    a, b = ctcdecode_amd.DecoderState(dec), ctcdecode_amd.DecoderState(dec)
+    x = torch_mod.from_numpy(lp)
+    dec.decode(x[:, :500], [a, b], [False, False])
+    o1, s1, t1, l1 = dec.decode(x[:, 500:1000], [a, b], [False, True], seq_lens=torch_mod.tensor([500, 200]))  # b ends at frame 700
+    assert int(l1[0].max()) == 0 and int(l1[1, 0]) == int(want["lens"][1, 0])
+    assert np.array_equal(o1[1, 0, : l1[1, 0]].numpy(), want["tokens"][1, 0, : want["lens"][1, 0]])
+    assert np.array_equal(s1[1].numpy().view(np.uint32), want["scores"][1].view(np.uint32))
+    o2, s2, t2, l2 = dec.decode(x[:1, 1000:], [a], [True])
+    assert np.array_equal(l2[0].numpy(), want["lens"][0]) and np.array_equal(s2[0].numpy().view(np.uint32), want["scores"][0].view(np.uint32))
+    for p in range(K):
+        n = int(l2[0, p])
+        assert np.array_equal(o2[0, p, :n].numpy(), want["tokens"][0, p, :n]) and np.array_equal(t2[0, p, :n].numpy(), want["timesteps"][0, p, :n])
+
+
 def test_empty_and_degenerate_batches(torch_mod):
     import ctcdecode_amd
 
