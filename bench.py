@@ -5,7 +5,8 @@ Workload (BASELINE.json configs[1], per GPU): B=256 utterances, T=1000 frames, V
 cutoff_top_n=29 (no pruning), no LM; inputs are float32 log-softmax of N(0,1) logits, resident in HBM before the
 timed region.  A "step" = one decode of that whole batch through the product path (C ABI -> HIP kernel).  With N GPUs
 every rank decodes its own B utterances (weak scaling, no data-path collective) and rank 0 then gathers the four result
-tensors over RCCL (north_star's "trivial gather") inside the timed region.
+tensors over RCCL (north_star's "trivial gather") inside the timed region; by default batch i's gather overlaps the
+decode of batch i+1 (ctcdecode_amd.distributed.ResultGatherer), all gathers complete before the clock stops.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -32,7 +33,10 @@ def parse():
     ap.add_argument("--vocab", type=int, default=29)
     ap.add_argument("--beam", type=int, default=100)
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = library default)")
-    ap.add_argument("--gather", choices=["full", "none"], default="full", help="N>1: gather results to rank 0 inside the timed region")
+    ap.add_argument("--gather", choices=["overlap", "sync", "none"], default="overlap",
+                    help="N>1: gather the four result tensors to rank 0 inside the timed region; 'overlap' lets batch i's gather "
+                         "run (RCCL streams) while batch i+1 is decoded, 'sync' finishes it before the next decode")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the gather path even with one rank (self-test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -78,11 +82,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    # RCCL prints a version banner on stdout; keep stdout for the ONE JSON line: everything else goes to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     B, T, V, K = a.batch, a.frames, a.vocab, a.beam
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -93,22 +102,26 @@ def main():
         dec.set_threads(a.threads)
     dec.set_timing(True)
 
-    gathered = None
-    if world > 1 and a.gather == "full" and rank == 0:
-        gathered = [[torch.empty((B, K, T), dtype=torch.int32, device=dev) for _ in range(world)],
-                    [torch.empty((B, K), dtype=torch.float32, device=dev) for _ in range(world)],
-                    [torch.empty((B, K, T), dtype=torch.int32, device=dev) for _ in range(world)],
-                    [torch.empty((B, K), dtype=torch.int32, device=dev) for _ in range(world)]]
+    gatherer = None
+    if use_dist and a.gather != "none":
+        from ctcdecode_amd.distributed import ResultGatherer
+
+        shapes = [((B, K, T), torch.int32), ((B, K), torch.float32), ((B, K, T), torch.int32), ((B, K), torch.int32)]
+        gatherer = ResultGatherer(shapes, dev, dst=0, depth=2)
 
     def step():
         res = dec.decode_device(lp, None, check=False)
-        if world > 1 and a.gather == "full":
-            for i, t in enumerate(res):
-                dist.gather(t, gathered[i] if rank == 0 else None, dst=0)
+        if gatherer is not None:
+            gatherer.submit(res)
+            if a.gather == "sync":
+                gatherer.wait()
         return res
 
     def fence():
-        if world > 1:
+        if gatherer is not None:
+            gatherer.wait()  # every submitted gather has completed (part of the timed work)
+        torch.cuda.synchronize()
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -120,7 +133,7 @@ def main():
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -157,7 +170,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: CTC prefix beam search, no LM, log-softmax of N(0,1) logits",
                        "utterances_per_gpu": B, "frames": T, "vocab": V, "beam_width": K, "cutoff_top_n": V,
-                       "global_batch": world * B, "parallelism": "batch-sharded x%d, gather=%s" % (world, a.gather if world > 1 else "n/a"),
+                       "global_batch": world * B, "parallelism": "batch-sharded x%d, gather=%s" % (world, a.gather if use_dist else "n/a"),
                        "threads_per_workgroup": a.threads or "default"},
             "kernel_ms": round(kern_ms, 4),
             "us_per_frame": round(kern_ms * 1e3 / T, 4),
@@ -167,8 +180,8 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(lp_cpu.numpy(), K, a.cpu_seconds)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

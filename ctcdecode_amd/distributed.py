@@ -48,3 +48,46 @@ def decode_sharded(decode_fn, probs, seq_lens=None, dst=0, group=None):
     lo, hi = shard_bounds(B, world, rank)
     res = decode_fn(probs[lo:hi], None if seq_lens is None else seq_lens[lo:hi])
     return gather_results(res, B, dst=dst, group=group)
+
+
+class ResultGatherer(object):
+    """Pipelined gather of per-rank result shards to ``dst``: ``submit(results)`` launches the four gathers
+    asynchronously (they run on RCCL's own streams and only wait for the decode that produced ``results``), so the next
+    batch can be decoded while the previous one's results travel over xGMI; ``wait()`` drains everything submitted.
+    Receive buffers on ``dst`` are allocated once and reused (collectives of one process group execute in order)."""
+
+    def __init__(self, shard_shapes_dtypes, device, dst=0, group=None, depth=2):
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.depth = max(1, depth)
+        self._inflight = []
+        self._recv = None
+        if self.rank == dst:
+            self._recv = [[[torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world)] for shape, dtype in shard_shapes_dtypes]
+                          for _ in range(self.depth)]
+        self._n = 0
+
+    def submit(self, results):
+        slot = self._n % self.depth
+        while len(self._inflight) >= self.depth:  # a receive slot is reused only after its previous gather completed
+            works, _ = self._inflight.pop(0)
+            for wk in works:
+                wk.wait()
+        works = []
+        for i, t in enumerate(results):
+            works.append(dist.gather(t.contiguous(), self._recv[slot][i] if self.rank == self.dst else None, dst=self.dst,
+                                     group=self.group, async_op=True))
+        self._inflight.append((works, results))  # keep the source tensors alive until the collective has read them
+        self._n += 1
+        return slot
+
+    def wait(self):
+        while self._inflight:
+            works, _ = self._inflight.pop(0)
+            for wk in works:
+                wk.wait()
+
+    def received(self, slot):
+        """On ``dst``: the per-rank parts of the batch submitted into ``slot`` (valid after its gather completed)."""
+        return self._recv[slot] if self._recv is not None else None

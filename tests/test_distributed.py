@@ -89,3 +89,52 @@ def test_shard_bounds_cover_the_batch():
                 lo, hi = dd.shard_bounds(B, world, r)
                 seen += list(range(lo, hi))
             assert seen == list(range(B))
+
+
+def _gatherer_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import importlib.util
+
+    import torch
+    import torch.distributed as dist
+
+    spec = importlib.util.spec_from_file_location("ctcd_distributed", os.path.join(ROOT, "ctcdecode_amd", "distributed.py"))
+    dd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dd)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = [((3, 2, 5), torch.int32), ((3, 2), torch.float32)]
+    g = dd.ResultGatherer(shapes, torch.device("cpu"), dst=0, depth=2)
+    ok = True
+    slots = []
+    for step in range(5):  # more submissions than receive slots: slots are recycled in order
+        res = (torch.full((3, 2, 5), 100 * step + rank, dtype=torch.int32), torch.full((3, 2), float(10 * step + rank)))
+        slots.append(g.submit(res))
+        if step % 2 == 1:
+            g.wait()
+            if rank == 0:
+                parts = g.received(slots[-1])
+                ok = ok and all(int(parts[0][r][0, 0, 0]) == 100 * step + r and float(parts[1][r][0, 0]) == 10 * step + r for r in range(world))
+    g.wait()
+    if rank == 0:
+        parts = g.received(slots[-1])
+        ok = ok and all(int(parts[0][r][0, 0, 0]) == 400 + r for r in range(world))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gatherer_gloo_world2():
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_gatherer_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
