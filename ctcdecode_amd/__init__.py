@@ -14,6 +14,19 @@ from ._native import NativeError  # noqa: F401
 __all__ = ["CTCBeamDecoder", "OnlineCTCBeamDecoder", "DecoderState", "NativeError"]
 
 
+def _to_host(tensors):
+    """Device -> host copy of the result tensors through page-locked memory (PyTorch's caching host allocator recycles
+    the blocks), all copies in flight together, one synchronisation: several times faster than ``.cpu()`` on pageable
+    memory for the 2 x [B, K, T] int32 results."""
+    outs = []
+    for t in tensors:
+        h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        outs.append(h)
+    torch.cuda.current_stream(tensors[0].device).synchronize()
+    return tuple(outs)
+
+
 class CTCBeamDecoder(object):
     """See ctcdecode/__init__.py:6-51 of the reference for the meaning of the arguments.
 
@@ -89,8 +102,8 @@ class CTCBeamDecoder(object):
 
     def decode(self, probs, seq_lens=None):
         """Drop-in for ctcdecode/__init__.py:53-123: returns CPU tensors (output, scores, timesteps, out_seq_len)."""
-        output, scores, timesteps, out_len = self.decode_device(probs, seq_lens)
-        return output.cpu(), scores.cpu(), timesteps.cpu(), out_len.cpu()
+        res = self.decode_device(probs, seq_lens)
+        return _to_host(res)
 
     def character_based(self):
         return None  # ctcdecode/__init__.py:125-126 without a scorer
@@ -179,7 +192,7 @@ class OnlineCTCBeamDecoder(object):
         out_len_c = out_len.cpu()
         R = int(nres_c.max()) if B else 0          # binding.cpp:186-205: sized to the most results / the longest beam
         L = int(out_len_c.max()) if B and R else 0
-        return output[:, :R, :L].cpu().contiguous(), scores.cpu(), timesteps[:, :R, :L].cpu().contiguous(), out_len_c
+        return _to_host((output[:, :R, :L].contiguous(), scores, timesteps[:, :R, :L].contiguous(), out_len))
 
     def character_based(self):
         return None
