@@ -114,7 +114,7 @@ struct Work {
   int *surv;       // 3K: slots of the survivors | their rank in slot (= DFS) order | inverse of that ranking
   uint64_t *ek;    // S_max: (key48 << 16 | slot) in DFS order, for the exact replay
   uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition
-  int *bins;       // kBins
+  int *bins;       // kBins fine buckets, then kBins/16 coarse ones (each the sum of 16 fine buckets)
   uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
   int *fin, *sstack;
   int *vars;
@@ -189,9 +189,6 @@ struct StepIn {
   int identity;    // 1: candidate r is character r (no pruning)
 };
 
-// histogram bins are stored with one pad word per 16 so that the 64 lanes of find_bucket (16 consecutive bins each)
-// hit distinct LDS banks
-CTC_HD int bin_index(int b) { return b + (b >> 4); }
 
 CTC_HD int ceil_log2_u64(uint64_t v) {  // smallest s with (1 << s) >= v, v >= 1
   return v <= 1 ? 0 : 64 - __builtin_clzll(v - 1);
@@ -316,7 +313,9 @@ struct Decoder {
   CTC_HD void hist_add(const Window &wd, uint32_t key) const {  // first-round histogram contribution of one candidate
     if (key >= wd.lo) {
       const uint32_t bk = (key - wd.lo) >> wd.shift;
-      x.atomic_add(&w.bins[bin_index(bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1)], 1);
+      const int bb = bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1;
+      x.atomic_add(&w.bins[bb], 1);
+      x.atomic_add(&w.bins[kBins + (bb >> 4)], 1);
     }
   }
 
@@ -331,8 +330,10 @@ struct Decoder {
     int need = K, gbase = 0;
     for (;;) {
       // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
-      //    [2] #keys in the window, [3] #keys in b*.  Also re-zeroes bins[] and ends with a barrier.
+      //    [2] #keys in the window, [3] #keys in b*.  Two-level: the coarse buckets locate the group of 16 fine ones.
+      //    Ends with a barrier; the histogram is cleared afterwards (next frame / next round needs it empty).
       x.find_bucket(w.bins, need, &w.vars[VAR_FB0]);
+      for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
       const int bstar = x.uni(w.vars[VAR_FB0]), above = x.uni(w.vars[VAR_FB1]), total = x.uni(w.vars[VAR_FB2]), inb = x.uni(w.vars[VAR_FB3]);
       x.mark(13);
       uint64_t blo = 0, bhi = 0;
@@ -388,6 +389,7 @@ struct Decoder {
         return;
       }
       // another histogram round over [lo, hi)
+      x.sync();  // the histogram has been cleared by every thread
       const uint64_t width = hi - lo;
       shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
       const uint32_t lo32 = (uint32_t)lo, span = (uint32_t)(hi - lo - 1);  // key in range <=> key - lo32 <= span
@@ -395,7 +397,9 @@ struct Decoder {
         const uint32_t k = w.skey[s], dk = k - lo32;
         if (k >= lo32 && dk <= span) {
           const uint32_t bk = dk >> shift;
-          x.atomic_add(&w.bins[bin_index(bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1)], 1);
+          const int bb = bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1;
+          x.atomic_add(&w.bins[bb], 1);
+          x.atomic_add(&w.bins[kBins + (bb >> 4)], 1);
         }
       }
       x.sync();

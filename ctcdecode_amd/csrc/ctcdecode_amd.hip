@@ -165,36 +165,29 @@ struct DevX {
     sync();
   }
 
-  // bins complete (caller synced), padded layout ctcbeam::bin_index.  Wave 0 finds the bucket holding the need-th
-  // largest key; everyone gets out[0..3] = {bucket or -1, #keys above it, #keys total, #keys in it} after the closing
-  // barrier; bins are re-zeroed.
-  __device__ void find_bucket(int *bins, int need, int *out) {
+  // Histogram complete (caller synced): bins[0, 1024) fine buckets, bins[1024, 1088) coarse sums of 16.  Wave 0 finds the
+  // bucket holding the need-th largest key: a suffix scan over the 64 coarse buckets (one per lane) picks the group,
+  // a 16-lane suffix scan inside it picks the bucket.  Everyone gets out[0..3] = {bucket or -1, #keys above it, #keys
+  // total, #keys in it} after the closing barrier.
+  __device__ void find_bucket(const int *bins, int need, int *out) {
     if (threadIdx.x < 64) {
       const int lane = (int)threadIdx.x;
-      constexpr int per = ctcbeam::kBins / 64;  // 16
-      const int owner = 63 - lane;  // lane 0 owns the TOP bins: a prefix scan over lanes is a suffix sum over bins
-      int *mine = bins + owner * (per + 1);
-      int v[per];
-      int sum = 0;
-#pragma unroll
-      for (int k = 0; k < per; ++k) {
-        v[k] = mine[k];
-        mine[k] = 0;
-        sum += v[k];
-      }
-      const int incl = wave_scan(sum, 0, [](int a, int b) { return a + b; });
+      const int c = 63 - lane;  // lane 0 owns the TOP coarse bucket: a prefix scan over lanes is a suffix sum over buckets
+      const int cv = bins[ctcbeam::kBins + c];
+      const int incl = wave_scan(cv, 0, [](int a, int b) { return a + b; });
       const int total = __builtin_amdgcn_readlane(incl, 63);
       const unsigned long long m = __ballot(incl >= need);
       if (m == 0ull) {
         if (lane == 0) { out[0] = -1; out[1] = 0; out[2] = total; out[3] = 0; }
-      } else if (lane == __ffsll((long long)m) - 1) {
-        int run = incl - sum;  // keys in bins above this lane's
-        bool done = false;
-#pragma unroll
-        for (int k = per - 1; k >= 0; --k) {
-          if (!done && run + v[k] >= need) { out[0] = owner * per + k; out[1] = run; out[2] = total; out[3] = v[k]; done = true; }
-          if (!done) run += v[k];
-        }
+      } else {
+        const int l1 = __ffsll((long long)m) - 1;            // lane of the coarse bucket holding the key
+        const int cstar = 63 - l1;
+        const int above_c = __builtin_amdgcn_readlane(incl, l1) - __builtin_amdgcn_readlane(cv, l1);
+        const int fv = lane < 16 ? bins[cstar * 16 + (15 - lane)] : 0;  // its 16 fine buckets, top one in lane 0
+        const int fincl = wave_scan(fv, 0, [](int a, int b) { return a + b; }) + above_c;
+        const unsigned long long mf = __ballot(lane < 16 && fincl >= need);
+        const int l2 = __ffsll((long long)mf) - 1;
+        if (lane == l2) { out[0] = cstar * 16 + (15 - lane); out[1] = fincl - fv; out[2] = total; out[3] = fv; }
       }
     }
     sync();

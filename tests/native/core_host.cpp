@@ -48,17 +48,15 @@ struct HostX {
   void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
   void wave_add(int *p, int v) { *p += v; }
   void find_bucket(int *bins, int need, int *out) {
-    using ctcbeam::bin_index;
     using ctcbeam::kBins;
     int run = 0, bstar = -1, above = 0, inb = 0, total = 0;
-    for (int b = 0; b < kBins; ++b) total += bins[bin_index(b)];
+    for (int c = 0; c < kBins / 16; ++c) total += bins[kBins + c];
     for (int b = kBins - 1; b >= 0; --b) {
-      const int v = bins[bin_index(b)];
+      const int v = bins[b];
       if (run + v >= need) { bstar = b; above = run; inb = v; break; }
       run += v;
     }
     out[0] = bstar; out[1] = above; out[2] = total; out[3] = inb;
-    for (int b = 0; b < kBins + kBins / 16; ++b) bins[b] = 0;
   }
   template <class Pred>
   void compact_slots(int S, int *out, Pred pred) {
