@@ -116,6 +116,8 @@ struct Work {
   uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition
   int *bins;       // kBins fine buckets, then kBins/16 coarse ones (each the sum of 16 fine buckets)
   uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
+  int *lslot;      // kListCap: their slots
+  uint32_t *bitmap;  // one bit per slot: survives (select fast path)
   int *fin, *sstack;
   int *vars;
 };
@@ -154,6 +156,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.skey = carve_ptr<uint32_t>(p, S);
   w.surv = carve_ptr<int>(p, 3 * K + 4);
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
+  w.lslot = carve_ptr<int>(p, kListCap + 4); w.bitmap = carve_ptr<uint32_t>(p, 2 * ((S + 63) / 64 + 17));
   w.fin = carve_ptr<int>(p, K);
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
@@ -321,13 +324,17 @@ struct Decoder {
 
   // K-th largest SCORE key (32 bit) among the S slots (holes have key 0).  The first-round histogram (window
   // first_window()) has already been accumulated in bins[].  Leaves tau (VAR_TAU), G = #keys > tau, E = #keys == tau.
-  // Precondition: pv[P_LCOUNT] == 0.
-  CTC_HD void select_kth(int S, int K, int *pv) {
+  // Fast path (the first histogram round already isolates a small bucket): the pass that lists the bucket's keys also
+  // records, one bit per slot, every key ABOVE the bucket; the ranking threads add the bucket's own survivors; the
+  // caller then only expands that bitmap (in slot = DFS order).  Returns true when the bitmap is complete (the caller
+  // must still discard it if several candidates tie on the K-th SCORE).  Precondition: pv[P_LCOUNT] == 0.
+  CTC_HD bool select_kth(int S, int K, int *pv) {
     const int tid = x.tid(), nt = x.nt();
     const Window wd = first_window();
     uint64_t lo = wd.lo, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
     int shift = wd.shift;
     int need = K, gbase = 0;
+    bool first = true;
     for (;;) {
       // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
       //    [2] #keys in the window, [3] #keys in b*.  Two-level: the coarse buckets locate the group of 16 fine ones.
@@ -347,27 +354,30 @@ struct Decoder {
         if (shift == 0 && bstar < kBins - 1) {  // the bucket is a single key value
           if (tid == 0) { w.vars[VAR_TAU] = (int)(uint32_t)blo; w.vars[VAR_G] = gbase + above; w.vars[VAR_E] = inb; }
           x.sync();
-          return;
+          return false;
         }
         if (inb <= kListCap) again = false;
         else { gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
       }
       if (!again) {  // exact rank inside the bucket, on offsets from its base
         const uint32_t b32 = (uint32_t)blo, bspan = (uint32_t)(bhi - blo - 1);
-        if (S <= 4 * nt) {  // common case: the (up to) four keys of this thread are requested together
-          uint32_t kk[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) kk[u] = tid + u * nt < S ? w.skey[tid + u * nt] : 0u;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint32_t dk = kk[u] - b32;
-            if (kk[u] >= b32 && dk <= bspan) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = dk + 1u;
-          }
-        } else {
-          for (int s = tid; s < S; s += nt) {
-            const uint32_t k = w.skey[s], dk = k - b32;
-            if (k >= b32 && dk <= bspan) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = dk + 1u;
-          }
+        const bool direct = first;
+        {
+          const uint32_t *skey = w.skey;
+          uint32_t *list = w.list;
+          int *lslot = w.lslot, *lcount = &pv[P_LCOUNT];
+          X &xx = x;
+          // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
+          x.mark_slots(S, w.bitmap, [=, &xx](int s) -> bool {
+            const uint32_t k = skey[s];
+            if (k < b32) return false;
+            const uint32_t dk = k - b32;
+            if (dk > bspan) return direct;
+            const int li = xx.atomic_add(lcount, 1);
+            list[li] = dk + 1u;
+            lslot[li] = s;
+            return false;
+          });
         }
         for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
         x.sync();
@@ -384,11 +394,16 @@ struct Decoder {
           if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
             w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gbase + above + g; w.vars[VAR_E] = e;
           }
+          if (direct && g < want) {  // key >= tau: survives (unless equal scores straddle the boundary -- caller's business)
+            const int sl = w.lslot[q];
+            x.atomic_or(&w.bitmap[sl >> 5], 1u << (sl & 31));
+          }
         }
         x.sync();
-        return;
+        return direct;
       }
       // another histogram round over [lo, hi)
+      first = false;
       x.sync();  // the histogram has been cleared by every thread
       const uint64_t width = hi - lo;
       shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
@@ -708,7 +723,7 @@ struct Decoder {
     // ---- C: the K-th best key.  #candidates = beam entries + new children - children that already exist as entries
     const int N = n * (1 + Vnb) - x.uni(pv[P_NPIN]);
     uint32_t tau = 0, tauc = 0;
-    bool exact = false;
+    bool exact = false, have_bitmap = false;
     if (tid == 0) reset_pvars(pvars(in.t + 1));  // the other parity set: free since the end of the previous step
     for (int i = tid; i < 2 * n; i += nt) w.hit[i] = 0;  // all readers of hit[] are behind the barrier above
     {
@@ -716,10 +731,11 @@ struct Decoder {
       for (int i = tid; i < K; i += nt) { oa[i] = -1; oc[i] = 0; }
     }
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
-      select_kth(S, K, pv);
+      have_bitmap = select_kth(S, K, pv);
       tau = (uint32_t)x.uni(w.vars[VAR_TAU]);
       const int E = x.uni(w.vars[VAR_E]), m = K - x.uni(w.vars[VAR_G]);
       if (E > m) {
+        have_bitmap = false;
         if (resolve_by_character(S, tau, m, E, pv)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);
         else exact = true;  // the boundary splits a group of equivalent prefixes
       }
@@ -752,6 +768,9 @@ struct Decoder {
       }
       x.sync();
       x.mark(6);
+    } else if (have_bitmap) {
+      x.expand_bitmap(w.bitmap, (S + 63) / 64, surv);
+      x.mark(3);
     } else {
       const uint32_t *skey = w.skey, *sinfo = w.sinfo;
       const bool all = N <= K;

@@ -105,6 +105,45 @@ struct DevX {
     if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
   }
 
+  // bit s of bitmap = pred(s), for every slot s in [0, S): each wave owns a contiguous range of slots (the same mapping
+  // as compact_slots), so one ballot is one 64-bit word of the bitmap.  pred may have side effects (list appends).
+  template <class Pred>
+  __device__ void mark_slots(int S, uint32_t *bitmap, Pred pred) {
+    const int lane = (int)threadIdx.x & 63, nw = ((int)blockDim.x + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int rounds = (S + 64 * nw - 1) / (64 * nw);
+    const int first = wave * rounds * 64;
+    for (int it = 0; it < rounds; ++it) {
+      const int s = first + it * 64 + lane;
+      const unsigned long long m = __ballot(s < S && pred(s));
+      if (lane == 0) {
+        bitmap[2 * (wave * rounds + it)] = (uint32_t)m;
+        bitmap[2 * (wave * rounds + it) + 1] = (uint32_t)(m >> 32);
+      }
+    }
+  }
+  // out[r] = s for the r-th set bit s of the bitmap (ascending); one wave, the others wait at the closing barrier.
+  __device__ void expand_bitmap(const uint32_t *bitmap, int nwords64, int *out) {
+    if (threadIdx.x < 64) {
+      const int lane = (int)threadIdx.x;
+      int running = 0;
+      for (int w0 = 0; w0 < nwords64; w0 += 64) {
+        const int wi = w0 + lane;
+        unsigned long long word = 0ull;
+        if (wi < nwords64) word = (unsigned long long)bitmap[2 * wi] | ((unsigned long long)bitmap[2 * wi + 1] << 32);
+        const int cnt = __popcll(word);
+        const int incl = wave_scan(cnt, 0, [](int a, int b) { return a + b; });
+        int base = running + incl - cnt;
+        while (word) {
+          out[base++] = wi * 64 + __builtin_ctzll(word);
+          word &= word - 1ull;
+        }
+        running += __builtin_amdgcn_readlane(incl, 63);
+      }
+    }
+    sync();
+  }
+
   // Ordered compaction: out[r] = s for every slot s in [0, S) with pred(s), r = number of such slots below s.
   // Each wave owns a contiguous range of slots (consecutive lanes = consecutive slots), so the rank of a slot is
   // (survivors in lower waves) + (survivors in this wave's earlier rounds) + (set ballot bits below the lane):

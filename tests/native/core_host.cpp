@@ -59,6 +59,17 @@ struct HostX {
     out[0] = bstar; out[1] = above; out[2] = total; out[3] = inb;
   }
   template <class Pred>
+  void mark_slots(int S, uint32_t *bitmap, Pred pred) {
+    for (int wd = 0; wd < 2 * ((S + 63) / 64); ++wd) bitmap[wd] = 0;
+    for (int s = 0; s < S; ++s)
+      if (pred(s)) bitmap[s >> 5] |= 1u << (s & 31);
+  }
+  void expand_bitmap(const uint32_t *bitmap, int nwords64, int *out) {
+    int k = 0;
+    for (int s = 0; s < nwords64 * 64; ++s)
+      if ((bitmap[s >> 5] >> (s & 31)) & 1u) out[k++] = s;
+  }
+  template <class Pred>
   void compact_slots(int S, int *out, Pred pred) {
     int k = 0;
     for (int s = 0; s < S; ++s)
