@@ -89,8 +89,9 @@ struct Dims {
 // LDS scalars.  The per-step counters exist twice (index by step parity) so that a step can reset the other set for
 // the step after next without racing with threads that still read this one.
 enum {
-  VAR_STATUS = 0,
-  VAR_FB0, VAR_FB1, VAR_FB2, VAR_FB3, VAR_CUT, VAR_TAU, VAR_TAUC, VAR_G, VAR_E,
+  VAR_STATUS = 0, VAR_CUT, VAR_TAUC,
+  VAR_FB0 = 4, VAR_FB1, VAR_FB2, VAR_FB3,   // 16-byte aligned groups: read back with one LDS access (X::uni4)
+  VAR_TAU = 8, VAR_G, VAR_E, VAR_SPARE,
   VAR_PAR0 = 12,  // first per-parity set
   P_NPIN = 0, P_LCOUNT, P_NMAXKEY, P_SIZE = 4,
   VAR_COUNT = VAR_PAR0 + 2 * P_SIZE
@@ -341,7 +342,9 @@ struct Decoder {
       //    Ends with a barrier; the histogram is cleared afterwards (next frame / next round needs it empty).
       x.find_bucket(w.bins, need, &w.vars[VAR_FB0]);
       for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
-      const int bstar = x.uni(w.vars[VAR_FB0]), above = x.uni(w.vars[VAR_FB1]), total = x.uni(w.vars[VAR_FB2]), inb = x.uni(w.vars[VAR_FB3]);
+      int fb[4];
+      x.uni4(&w.vars[VAR_FB0], fb);
+      const int bstar = fb[0], above = fb[1], total = fb[2], inb = fb[3];
       x.mark(13);
       uint64_t blo = 0, bhi = 0;
       bool again = true;
@@ -732,8 +735,10 @@ struct Decoder {
     }
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
       have_bitmap = select_kth(S, K, pv);
-      tau = (uint32_t)x.uni(w.vars[VAR_TAU]);
-      const int E = x.uni(w.vars[VAR_E]), m = K - x.uni(w.vars[VAR_G]);
+      int tv[4];
+      x.uni4(&w.vars[VAR_TAU], tv);
+      tau = (uint32_t)tv[0];
+      const int E = tv[2], m = K - tv[1];
       if (E > m) {
         have_bitmap = false;
         if (resolve_by_character(S, tau, m, E, pv)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);

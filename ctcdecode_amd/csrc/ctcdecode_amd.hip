@@ -75,6 +75,12 @@ struct DevX {
   __device__ void sync_full() { __syncthreads(); }
   // a value every thread of the workgroup holds identically -> scalar register (branches/loops on it become scalar)
   __device__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+  // four consecutive, 16-byte aligned LDS words every thread reads identically: one ds_read_b128
+  __device__ void uni4(const int *p, int *out) const {
+    const int4 v = *reinterpret_cast<const int4 *>(p);
+    out[0] = __builtin_amdgcn_readfirstlane(v.x); out[1] = __builtin_amdgcn_readfirstlane(v.y);
+    out[2] = __builtin_amdgcn_readfirstlane(v.z); out[3] = __builtin_amdgcn_readfirstlane(v.w);
+  }
   __device__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ void atomic_max(int *p, int v) { atomicMax(p, v); }
@@ -113,6 +119,20 @@ struct DevX {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rounds = (S + 64 * nw - 1) / (64 * nw);
     const int first = wave * rounds * 64;
+    if (rounds <= 4) {  // common case: straight-line, the four predicates (and their LDS reads) issued together
+      const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
+      const bool f0 = s0 < S && pred(s0);
+      const bool f1 = rounds > 1 && s1 < S && pred(s1);
+      const bool f2 = rounds > 2 && s2 < S && pred(s2);
+      const bool f3 = rounds > 3 && s3 < S && pred(s3);
+      const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+      if (lane < rounds) {
+        const unsigned long long m = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : m3;
+        bitmap[2 * (wave * rounds + lane)] = (uint32_t)m;
+        bitmap[2 * (wave * rounds + lane) + 1] = (uint32_t)(m >> 32);
+      }
+      return;
+    }
     for (int it = 0; it < rounds; ++it) {
       const int s = first + it * 64 + lane;
       const unsigned long long m = __ballot(s < S && pred(s));

@@ -22,6 +22,7 @@ struct HostX {
   void sync() {}
   void sync_full() {}
   int uni(int v) const { return v; }
+  void uni4(const int *p, int *out) const { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = p[3]; }
   int group() const { return 0; }
   int ngroups() const { return 1; }
   int lane() const { return 0; }
