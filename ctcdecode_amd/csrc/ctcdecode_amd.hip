@@ -677,6 +677,7 @@ struct ctcd_decoder {
   int threads = 1024;
   int max_lds = 0;
   Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
+  Buf prune_in, prune_out, st_lens;  // own staging: the host-pointer entry points keep their tensors in stage_in/out
   long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
   bool tables_ready = false;
   bool timing = false;
@@ -798,7 +799,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   (void)hipSetDevice(d->device);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
-  d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release();
+  d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
   delete d;
 }
 
@@ -916,12 +917,12 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       std::vector<unsigned> fr(nf);
       HIP_TRY(hipMemcpy(fr.data(), flag_rows, (size_t)nf * 4, hipMemcpyDeviceToHost));
       const size_t rec = 1 + 2 * (size_t)stride;  // per frame: count, labels, log-probs
-      if ((rc = d->stage_in.ensure((size_t)nf * V * 4))) return rc;
-      if ((rc = d->stage_out.ensure((size_t)nf * rec * 4))) return rc;
-      hipLaunchKernelGGL(gather_rows_kernel, dim3(nf), dim3(256), 0, stream, probs, flag_rows, V, (float *)d->stage_in.p);
+      if ((rc = d->prune_in.ensure((size_t)nf * V * 4))) return rc;
+      if ((rc = d->prune_out.ensure((size_t)nf * rec * 4))) return rc;
+      hipLaunchKernelGGL(gather_rows_kernel, dim3(nf), dim3(256), 0, stream, probs, flag_rows, V, (float *)d->prune_in.p);
       HIP_TRY(hipGetLastError());
       std::vector<float> rowsh((size_t)nf * V);
-      HIP_TRY(hipMemcpyAsync(rowsh.data(), d->stage_in.p, rowsh.size() * 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(rowsh.data(), d->prune_in.p, rowsh.size() * 4, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       std::vector<int32_t> recs((size_t)nf * rec, 0);
       {  // the flagged frames are independent: one host thread each (up to the core count)
@@ -940,8 +941,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
         work();
         for (auto &t : pool) t.join();
       }
-      HIP_TRY(hipMemcpyAsync(d->stage_out.p, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(scatter_pruned_kernel, dim3(nf), dim3(64), 0, stream, (const int32_t *)d->stage_out.p, flag_rows, stride,
+      HIP_TRY(hipMemcpyAsync(d->prune_out.p, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(scatter_pruned_kernel, dim3(nf), dim3(64), 0, stream, (const int32_t *)d->prune_out.p, flag_rows, stride,
                          (int *)d->pr_cnt.p, (int *)d->pr_ch.p, (float *)d->pr_lp.p);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(stream));  // recs (host memory) must outlive the copy
@@ -1071,11 +1072,11 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
     }
   }
   int rc;
-  if ((rc = d->stage_in.ensure((size_t)B * 4 + 16))) return rc;
-  HIP_TRY(hipMemcpyAsync(d->stage_in.p, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream));
+  if ((rc = d->st_lens.ensure((size_t)B * 4 + 16))) return rc;
+  HIP_TRY(hipMemcpyAsync(d->st_lens.p, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   StreamCall sc{states, is_eos, out_T};
-  rc = decode_common(d, probs, (const int32_t *)d->stage_in.p, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok,
+  rc = decode_common(d, probs, (const int32_t *)d->st_lens.p, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok,
                      out_ts, out_sc, out_len, n_results, stream_, &sc);
   if (rc) return rc;
   for (int b = 0; b < B; ++b) states[b]->frames += lens[b];

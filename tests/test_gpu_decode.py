@@ -235,6 +235,24 @@ def test_host_pointer_entry_point(torch_mod):
     got = dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)
     ou.assert_same(got, want, "host entry point")
     assert np.array_equal(nres, want["nres"])
+    # same entry point with vocabulary pruning and tied values (frames resolved on the host use their own staging buffers)
+    lp = ou.synth_logprobs(3, 90, 64, 53, quant=0.5)
+    want = ou.decode(lp, beam=24, cutoff_top_n=8, which="restated")
+    B, T, V, K = 3, 90, 64, 24
+    tok = np.full((B, K, T), -7, np.int32); ts = np.full((B, K, T), -7, np.int32)
+    sc = np.full((B, K), -7, np.float32); ln = np.full((B, K), -7, np.int32); nres = np.zeros((B,), np.int32)
+    h = ctypes.c_void_p()
+    n.check(n.lib.ctcd_create(ctypes.byref(h), 0))
+    try:
+        n.check(n.lib.ctcd_beam_decode_host(h, lp.ctypes.data, None, B, T, V, K, 4, 1.0, 8, 0, 1,
+                                            tok.ctypes.data, ts.ctypes.data, sc.ctypes.data, ln.ctypes.data, nres.ctypes.data))
+        assert n.lib.ctcd_last_prune_host_rows(h) > 0
+    finally:
+        n.lib.ctcd_destroy(h)
+    ou.assert_same(dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres), want, "host entry point, pruned")
+    for b in range(B):
+        for p in range(K):
+            assert not tok[b, p, ln[b, p]:].any() and not ts[b, p, ln[b, p]:].any()
 
 
 def test_streaming_reference_cases(torch_mod):
