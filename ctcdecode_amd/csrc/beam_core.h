@@ -838,9 +838,12 @@ struct Decoder {
     if (last) {  // the order std::nth_element left the survivors in (identity when it was not called)
       for (int q = tid; q < n_new; q += nt) w.fin[q] = exact ? rk[q] : q;
     }
-    // un-register this step's candidates from the rank table
-    if (!in.identity)
+    // un-register this step's candidates from the rank table -- only once every wave has finished emitting (the emit
+    // loop above still looks characters up in it)
+    if (!in.identity) {
+      x.sync();
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
+    }
     if (stage && tid < d.V) w.clpbuf[((in.t + 1) & 1) * d.Vc_max + tid] = stage_val;
     x.mark(7);
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
@@ -861,6 +864,7 @@ struct Decoder {
       st_n = n_new;
       st_pool = pool_count + n_new;
     }
+    x.dump(in.t, n_new, nb.node, nb.dep, nb.lcp, nb.score);
     x.mark(8);
     Beam t = w.cur; w.cur = w.nxt; w.nxt = t;
   }

@@ -54,7 +54,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
       wave_scan((int)v, 0, [](int a, int b) { return (uint32_t)a > (uint32_t)b ? a : b; }), 63);
 }
 
-template <bool PROF>
+// FAR: part of the workspace lives in HBM (BIG layout): every barrier must then also drain global memory traffic.
+template <bool PROF, bool FAR>
 struct DevX {
   int *red;  // 2 x 16 ints of LDS
   int parity;
@@ -67,11 +68,25 @@ struct DevX {
       last = now;
     }
   }
+  // debugging aid (profiling build only): the beam after every frame -> dbg[t][0] = n, then (node, dep, lcp, score bits) per entry
+  int *dbg; int dbg_stride;
+  __device__ void dump(int t, int n, const int *node, const int *dep, const int *lcp, const float *score) {
+    if (PROF && dbg) {
+      int *o = dbg + (size_t)t * dbg_stride;
+      if (threadIdx.x == 0) o[0] = n;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        o[1 + 4 * i] = node[i]; o[2 + 4 * i] = dep[i]; o[3 + 4 * i] = lcp[i]; o[4 + 4 * i] = __float_as_int(score[i]);
+      }
+    }
+  }
   __device__ int tid() const { return (int)threadIdx.x; }
   __device__ int nt() const { return (int)blockDim.x; }
   // LDS-only barrier: waits for this wave's LDS traffic, not for outstanding global loads/stores (the row prefetch
   // and the pool appends stay in flight across phases).  sync_full() is the fence that also drains global memory.
-  __device__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  __device__ void sync() {
+    if (FAR) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
   __device__ void sync_full() { __syncthreads(); }
   // a value every thread of the workgroup holds identically -> scalar register (branches/loops on it become scalar)
   __device__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
@@ -294,6 +309,7 @@ struct KernelArgs {
   float *out_score;
   int32_t *status;          // [B]
   long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
+  int *dbg;                 // profiling build: beam of item 0 after every frame, [T][1 + 4K] (or null)
   char *far;                // BIG layout: per-utterance HBM scratch, far_stride bytes each
   long long far_stride;
   // streaming (ctcd_stream_decode): per item, the HBM block that holds its parked beam + node pool
@@ -319,7 +335,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
   __shared__ long long prof[16];
   if (PROF && threadIdx.x < 16) prof[threadIdx.x] = 0;
-  DevX<PROF> x{red, 0, prof, 0};
+  DevX<PROF, BIG> x{red, 0, prof, 0, (PROF && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K};
   int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();
@@ -681,8 +697,8 @@ struct ctcd_decoder {
   long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
   bool tables_ready = false;
   bool timing = false;
-  bool profile = false;
-  Buf prof;
+  bool profile = false, dbg_on = false;
+  Buf prof, dbg;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
 };
@@ -989,6 +1005,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     a.pr_stride = dims.Vc_max;
   }
   a.prof = nullptr;
+  a.dbg = nullptr;
+  if (d->profile && d->dbg_on) {
+    if ((rc = d->dbg.ensure((size_t)(T + 1) * (1 + 4 * (size_t)beam) * 4))) return rc;
+    a.dbg = (int *)d->dbg.p;
+  }
   if (d->profile) {
     if ((rc = d->prof.ensure((size_t)B * 16 * 8))) return rc;
     a.prof = (long long *)d->prof.p;
@@ -1142,6 +1163,18 @@ int ctcd_last_kernel_ms(ctcd_decoder *d, float *ms) {
 int ctcd_debug_set_profile(ctcd_decoder *d, int on) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   d->profile = on != 0;
+  return CTCD_OK;
+}
+
+// beam of batch item 0 after every frame (profiling build): out = int32 [T][1 + 4*beam]
+int ctcd_debug_beam_dump(ctcd_decoder *d, int on, int *out, int T, int beam) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  d->dbg_on = on != 0;
+  if (out && d->dbg.p) {
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d->dbg.p, (size_t)T * (1 + 4 * (size_t)beam) * 4, hipMemcpyDeviceToHost));
+  }
   return CTCD_OK;
 }
 

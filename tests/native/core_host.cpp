@@ -36,6 +36,7 @@ struct HostX {
   void atomic_max(int *p, int v) { *p = std::max(*p, v); }
   float unif(float v) const { return v; }
   void mark(int) {}
+  void dump(int, int, const int *, const int *, const int *, const float *) {}
   uint32_t scan_excl(uint32_t *a, int n) {
     uint32_t run = 0;
     for (int i = 0; i < n; ++i) {

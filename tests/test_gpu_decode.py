@@ -137,6 +137,27 @@ def test_vocabulary_pruning_against_oracle(torch_mod, c):
         assert host_rows == 0
 
 
+@pytest.mark.parametrize("threads", [128, 256, 1024])
+def test_pruned_wide_beam_regression(torch_mod, threads):
+    """Found by tools/gpu_stress.py: with vocabulary pruning and more surviving beams than one wave emits, the rank table
+    was un-registered by the first wave while later waves were still emitting (wrong log_prob for beams >= 128)."""
+    lp = ou.synth_logprobs(4, 61, 64, 7057, quant=2.0, blank_id=32)
+    sl = np.array([11, 30, 32, 47], np.int32)
+    want = ou.decode(lp, sl, beam=200, blank_id=32, cutoff_top_n=32, which="restated")
+    got = _decode(torch_mod, lp, sl, beam=200, blank_id=32, cutoff_top_n=32, threads=threads)
+    ou.assert_same(_with_nres(got, want), want)
+
+
+def test_randomised_stress_subset(torch_mod):
+    """A slice of tools/gpu_stress.py (random shapes, pruning, ragged lengths, streaming, every workgroup size)."""
+    import subprocess
+    import sys as _sys
+
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_stress.py"),
+                        "--n", "120", "--seed", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_north_star_shape_parity_and_properties(torch_mod):
     """BASELINE.json configs[1]: B=256, T=1000, V=29, beam=100.  Bit-exact against the oracle on a sample of the items
     (the CPU needs ~1 s per item), size-independent properties on all of them, and run-to-run determinism."""
