@@ -75,6 +75,7 @@ constexpr uint32_t kHoleInfo = T_HOLE << 14;
 
 struct Beam {  // struct-of-arrays, capacity K each
   int *node, *par, *ch, *dep, *lcp, *via, *viaanc, *viach;
+  int *up;  // express pointer of the entry's node (see kExpress)
   float *bprev, *nbprev, *score, *lpc;
 };
 
@@ -100,6 +101,10 @@ constexpr int kBins = 1024;     // histogram buckets of the select
 constexpr int kBinsLog = 10;
 constexpr int kListCap = 128;   // exact-rank list (one bucket's keys)
 constexpr int kSerialCut = 96;  // introselect ranges at most this long are finished by one lane
+// Express pointers for the final back-trace: every pool node X (depth d >= 1) also records up(X) = its ancestor at
+// depth ((d - 1) / kExpress) * kExpress, so a label sequence of length d is read back as d / kExpress + 1 independent
+// segments of at most kExpress parent hops each instead of one chain of d dependent loads.
+constexpr int kExpress = 32;
 
 struct Work {
   Beam cur, nxt;
@@ -142,7 +147,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
     Beam &b = *bs[i];
     b.node = carve_ptr<int>(p, K); b.par = carve_ptr<int>(p, K); b.ch = carve_ptr<int>(p, K);
     b.dep = carve_ptr<int>(p, K); b.lcp = carve_ptr<int>(p, K); b.via = carve_ptr<int>(p, K);
-    b.viaanc = carve_ptr<int>(p, K); b.viach = carve_ptr<int>(p, K);
+    b.viaanc = carve_ptr<int>(p, K); b.viach = carve_ptr<int>(p, K); b.up = carve_ptr<int>(p, K);
     b.bprev = carve_ptr<float>(p, K); b.nbprev = carve_ptr<float>(p, K); b.score = carve_ptr<float>(p, K);
     b.lpc = carve_ptr<float>(p, K);
   }
@@ -177,7 +182,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
 // Persistent decoder state of one audio stream (the reference's DecoderState object kept alive between decode()
 // calls, ctc_beam_search_decoder.h:73-124 / ctcdecode/__init__.py:253-272), stored in HBM between launches:
 // hdr[0..7] = {frames fed so far (abs_time_step, ctc_beam_search_decoder.cpp:69), beam size, pool count, window log,
-// best key, fin valid, reserved...}; arrays = the 12 beam arrays then fin, K entries each.  The node pool lives in
+// best key, fin valid, reserved...}; arrays = the 13 beam arrays then fin, K entries each (kStateArrays).  The node pool lives in
 // the same allocation and is passed separately.
 struct StreamState {
   int *hdr;
@@ -185,6 +190,7 @@ struct StreamState {
   int finish;  // this call ends the stream: run DecoderState::decode()
 };
 enum { SH_FRAMES = 0, SH_N, SH_POOL, SH_WLOG, SH_MAXKEY, SH_FINVALID, SH_WORDS = 8 };
+constexpr int kStateArrays = 14;
 
 struct StepIn {
   int t;           // absolute time step
@@ -205,11 +211,12 @@ struct Decoder {
   const Dims d;
   const int blank;
   PoolNode *pool;
+  int *pool_up;  // up(X) per pool node
   const int pool_cap;
   const uint64_t *tbl;  // exact_math tables
 
-  CTC_HD Decoder(X &x_, Work &w_, const Dims &d_, int blank_, PoolNode *pool_, int pool_cap_, const uint64_t *tbl_)
-      : x(x_), w(w_), d(d_), blank(blank_), pool(pool_), pool_cap(pool_cap_), tbl(tbl_) {}
+  CTC_HD Decoder(X &x_, Work &w_, const Dims &d_, int blank_, PoolNode *pool_, int *pool_up_, int pool_cap_, const uint64_t *tbl_)
+      : x(x_), w(w_), d(d_), blank(blank_), pool(pool_), pool_up(pool_up_), pool_cap(pool_cap_), tbl(tbl_) {}
 
   CTC_HD float lse(float a, float b) const { return ctcmath::lse(a, b, tbl); }
 
@@ -227,10 +234,11 @@ struct Decoder {
     if (x.tid() == 0) {
       Beam &b = w.cur;
       b.node[0] = 0; b.par[0] = -1; b.ch[0] = -1; b.dep[0] = 0; b.lcp[0] = -1;
-      b.via[0] = -1; b.viaanc[0] = -1; b.viach[0] = -1;
+      b.via[0] = -1; b.viaanc[0] = -1; b.viach[0] = -1; b.up[0] = 0;
       b.bprev[0] = 0.f; b.nbprev[0] = CTC_NEG_MAX; b.score[0] = 0.f; b.lpc[0] = CTC_NEG_MAX;
       PoolNode r; r.parent = -1; r.ch = -1; r.tstep = 0; r.lpc = CTC_NEG_MAX;
       pool[0] = r;
+      pool_up[0] = 0;
       w.vars[VAR_STATUS] = ST_OK;
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
@@ -251,12 +259,12 @@ struct Decoder {
     st_n = x.uni(ss.hdr[SH_N]); st_pool = x.uni(ss.hdr[SH_POOL]); st_wlog = x.uni(ss.hdr[SH_WLOG]);
     st_maxkey = (uint32_t)x.uni(ss.hdr[SH_MAXKEY]);
     Beam &b = w.cur;
-    int *ia[8] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach};
+    int *ia[9] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach, b.up};
     float *fa[4] = {b.bprev, b.nbprev, b.score, b.lpc};
     for (int i = tid; i < st_n; i += nt) {
-      for (int a = 0; a < 8; ++a) ia[a][i] = ss.arrays[a * K + i];
-      for (int a = 0; a < 4; ++a) fa[a][i] = ctcmath::bits_to_f32((uint32_t)ss.arrays[(8 + a) * K + i]);
-      w.fin[i] = ss.arrays[12 * K + i];
+      for (int a = 0; a < 9; ++a) ia[a][i] = ss.arrays[a * K + i];
+      for (int a = 0; a < 4; ++a) fa[a][i] = ctcmath::bits_to_f32((uint32_t)ss.arrays[(9 + a) * K + i]);
+      w.fin[i] = ss.arrays[13 * K + i];
     }
     if (tid == 0) {
       w.vars[VAR_STATUS] = ST_OK;
@@ -272,12 +280,12 @@ struct Decoder {
   CTC_HD void save_state(const StreamState &ss, int frames) {
     const int tid = x.tid(), nt = x.nt(), K = d.K;
     const Beam &b = w.cur;
-    const int *ia[8] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach};
+    const int *ia[9] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach, b.up};
     const float *fa[4] = {b.bprev, b.nbprev, b.score, b.lpc};
     for (int i = tid; i < st_n; i += nt) {
-      for (int a = 0; a < 8; ++a) ss.arrays[a * K + i] = ia[a][i];
-      for (int a = 0; a < 4; ++a) ss.arrays[(8 + a) * K + i] = (int)ctcmath::f32_to_bits(fa[a][i]);
-      ss.arrays[12 * K + i] = w.fin[i];
+      for (int a = 0; a < 9; ++a) ss.arrays[a * K + i] = ia[a][i];
+      for (int a = 0; a < 4; ++a) ss.arrays[(9 + a) * K + i] = (int)ctcmath::f32_to_bits(fa[a][i]);
+      ss.arrays[13 * K + i] = w.fin[i];
     }
     if (tid == 0) {
       ss.hdr[SH_FRAMES] = frames; ss.hdr[SH_N] = st_n; ss.hdr[SH_POOL] = st_pool; ss.hdr[SH_WLOG] = st_wlog;
@@ -810,7 +818,7 @@ struct Decoder {
       nb.lcp[k] = l;
       if (type == T_SELF) {
         nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = b.dep[j];
-        nb.via[k] = b.via[j]; nb.viaanc[k] = b.viaanc[j]; nb.viach[k] = b.viach[j];
+        nb.via[k] = b.via[j]; nb.viaanc[k] = b.viaanc[j]; nb.viach[k] = b.viach[j]; nb.up[k] = b.up[j];
         nb.bprev[k] = w.b_new[j]; nb.nbprev[k] = w.nb_new[j]; nb.score[k] = w.sc_new[j]; nb.lpc[k] = b.lpc[j];
       } else {
         const int c = info_ch(inf);
@@ -823,10 +831,14 @@ struct Decoder {
           id = pool_count + k;
           PoolNode pn; pn.parent = b.node[P]; pn.ch = c; pn.tstep = in.t; pn.lpc = lp;
           pool[id] = pn;
+          const int upv = (b.dep[P] & (kExpress - 1)) == 0 ? pn.parent : b.up[P];
+          pool_up[id] = upv;
+          nb.up[k] = upv;
           lpc = lp;
         } else {                // path_trie.cpp:50-56 : revived, probabilities reset
           id = b.via[j];
           lpc = w.rev_lpc[j];
+          nb.up[k] = pool_up[id];
         }
         nb.node[k] = id; nb.par[k] = b.node[P]; nb.ch[k] = c; nb.dep[k] = b.dep[P] + 1;
         nb.viaanc[k] = -1;
@@ -869,9 +881,64 @@ struct Decoder {
     Beam t = w.cur; w.cur = w.nxt; w.nxt = t;
   }
 
+  // == std::sort(v, v + n, before) of libstdc++ (stl_emul.h), element for element -- also where `before` ties.
+  // Introsort's sub-ranges are disjoint once split, so the order in which they are finished cannot change the
+  // result: every lane takes one pending range per round (median-of-three Hoare split, or the heap sort once the depth
+  // budget is spent), and the closing insertion sort -- which never moves an element across a split point, because
+  // the comparison is strict -- is done per final range (at most 16 elements) by one lane each.
+  template <class T, class C>
+  CTC_HD void sort_like_std(T *v, int n, C before) {
+    const int tid = x.tid(), nt = x.nt();
+    constexpr int kTaskCap = (kBins + kBins / 16) / 6;
+    if (n <= 16 || n / 17 + 1 > kTaskCap) {
+      if (tid == 0) stlemu::sort(v, 0, n, before, w.sstack);
+      x.sync();
+      return;
+    }
+    int *cur = w.bins, *nxt = w.bins + 3 * kTaskCap, *small = w.surv;
+    int *cnt = w.vars + VAR_TAU;  // [0], [1]: pending ranges of the next round (by round parity), [2]: final ranges
+    if (tid == 0) {
+      cnt[0] = 0; cnt[1] = 0; cnt[2] = 0;
+      cur[0] = 0; cur[1] = n; cur[2] = 2 * stlemu::floor_lg(n);
+    }
+    x.sync();
+    int ntask = 1;
+    for (int round = 0; ntask > 0; ++round) {
+      int *c_next = cnt + (round & 1);
+      for (int k = tid; k < ntask; k += nt) {
+        const int first = cur[3 * k], last = cur[3 * k + 1], depth = cur[3 * k + 2];
+        if (depth == 0) {
+          stlemu::heap_select(v, first, last, last, before);
+          stlemu::heap_sort_down(v, first, last, before);
+          continue;
+        }
+        const int cut = stlemu::split_with_median_pivot(v, first, last, before);
+        for (int side = 0; side < 2; ++side) {
+          const int a = side ? cut : first, e = side ? last : cut;
+          if (e - a > 16) {
+            const int i = x.atomic_add(c_next, 1);
+            nxt[3 * i] = a; nxt[3 * i + 1] = e; nxt[3 * i + 2] = depth - 1;
+          } else if (e - a > 1) {
+            const int i = x.atomic_add(cnt + 2, 1);
+            small[2 * i] = a; small[2 * i + 1] = e;
+          }
+        }
+      }
+      x.sync();
+      ntask = x.uni(*c_next);
+      if (tid == 0) cnt[(round + 1) & 1] = 0;  // the counter of the round after next; nobody reads it any more
+      int *t = cur; cur = nxt; nxt = t;
+      x.sync();
+    }
+    const int nsmall = x.uni(cnt[2]);
+    for (int k = tid; k < nsmall; k += nt) stlemu::insertion_sort(v, small[2 * k], small[2 * k + 1], before);
+    x.sync();
+  }
+
   // DecoderState::decode() + get_beam_search_result + binding.cpp:85-99 for one utterance.
-  // `had_steps`: false when the utterance has no frames (fin is then just the root).
-  CTC_HD void finish(bool had_steps, int T_stride, int32_t *out_tok, int32_t *out_ts, float *out_score, int32_t *out_len,
+  // `had_steps`: false when the utterance has no frames (fin is then just the root); `max_depth`: bound on the length
+  // of a label sequence (the number of frames fed).
+  CTC_HD void finish(bool had_steps, int max_depth, int T_stride, int32_t *out_tok, int32_t *out_ts, float *out_score, int32_t *out_len,
                      int32_t *n_results) {
     const Beam &b = w.cur;
     const int tid = x.tid(), nt = x.nt();
@@ -880,29 +947,97 @@ struct Decoder {
     if (!had_steps)
       for (int k = tid; k < nres; k += nt) w.fin[k] = k;
     x.sync();
-    if (tid == 0) {
+    // The two std::sorts (ctc_beam_search_decoder.cpp:188-190, decoder_utils.cpp:59) order by (score desc, character
+    // asc).  Equal float32 scores are common in a beam (it spans a few hundred ulps), so the order libstdc++ leaves
+    // equivalent prefixes in matters: both sorts are replayed exactly, on (key, entry) pairs packed into one word.
+    {
       const float *sc = b.score;
       const int *ch = b.ch;
-      auto before = [sc, ch](int a, int c) {
-        return key48(ord_f32(sc[a]), mk_info(ch[a], 0, 0)) > key48(ord_f32(sc[c]), mk_info(ch[c], 0, 0));
-      };
-      stlemu::sort(w.fin, 0, nres, before, w.sstack);  // ctc_beam_search_decoder.cpp:188-190
-      stlemu::sort(w.fin, 0, nres, before, w.sstack);  // decoder_utils.cpp:59
-      if (n_results) *n_results = nres;
+      uint64_t *pk = w.ek;
+      for (int p = tid; p < nres; p += nt) {
+        const int a = w.fin[p];
+        pk[p] = (key48(ord_f32(sc[a]), mk_info(ch[a], 0, 0)) << 16) | (uint64_t)a;
+      }
+      x.sync();
+      auto before = [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); };
+      sort_like_std(pk, nres, before);
+      sort_like_std(pk, nres, before);
+      for (int p = tid; p < nres; p += nt) w.fin[p] = (int)(pk[p] & 0xFFFFu);
     }
+    if (tid == 0 && n_results) *n_results = nres;
     x.sync();
     for (int p = tid; p < nres; p += nt) {
       const int j = w.fin[p];
       out_score[p] = -b.score[j];           // decoder_utils.cpp:68 (approx_ctc = score without a scorer)
-      int dd = b.dep[j], xn = b.node[j];
-      out_len[p] = dd;
-      int32_t *tk = out_tok + (size_t)p * T_stride, *ts = out_ts + (size_t)p * T_stride;
-      while (dd > 0) {                      // path_trie.cpp:113-126
+      out_len[p] = b.dep[j];
+    }
+    // path_trie.cpp:113-126 (get_path_vec).  Neighbours in the (DFS-ordered) beam share their first lcp labels, so
+    // every entry j reads back only the labels below that shared part -- depths (lcp[j], dep[j]] -- and the shared
+    // part of its row is then copied from the rows that did read it.  The read-back itself goes segment by segment
+    // (kExpress): segment 0 is the tail above the node's express ancestor, segment i >= 1 the kExpress labels below
+    // the i-th express ancestor; segment-major order keeps the walks of one wave equally long.
+    int *row_of = w.pinr, *owner = w.e;
+    for (int p = tid; p < nres; p += nt) row_of[w.fin[p]] = p;
+    for (int j = tid; j < nres; j += nt) {  // owner[j]: the nearest earlier entry that shares less with its own predecessor
+      int o = j - 1;
+      const int l = b.lcp[j];
+      while (o >= 0 && b.lcp[o] >= l) --o;
+      owner[j] = o;
+    }
+    x.sync();
+    x.mark(4);
+    const int maxseg = max_depth / kExpress + 1;
+    for (int idx = tid; idx < nres * maxseg; idx += nt) {
+      const int i = idx / nres, j = idx - i * nres;
+      const int dj = b.dep[j];
+      const int lo = b.lcp[j] > 0 ? b.lcp[j] : 0;
+      const int base = ((dj - 1) / kExpress) * kExpress;  // depth of the first express ancestor
+      if (dj <= 0 || i > base / kExpress) continue;
+      int dd = i == 0 ? dj : base - (i - 1) * kExpress;
+      int stop = i == 0 ? base : dd - kExpress;
+      if (dd <= lo) continue;
+      stop = stop < lo ? lo : stop;
+      int xn;
+      if (i == 0) {
+        xn = b.node[j];
+      } else {
+        xn = b.up[j];
+        for (int h = 1; h < i; ++h) xn = pool_up[xn];
+      }
+      const size_t row = (size_t)row_of[j] * T_stride;
+      int32_t *tk = out_tok + row, *ts = out_ts + row;
+      while (dd > stop) {
         const PoolNode pn = pool[xn];
         tk[dd - 1] = pn.ch;
         ts[dd - 1] = pn.tstep;
         xn = pn.parent;
         --dd;
+      }
+    }
+    x.sync_full();  // rows are read back below by other waves
+    x.mark(15);
+    const int grp = x.group(), ngr = x.ngroups(), lane = x.lane(), lanes = x.lanes();
+    constexpr int kU = 8;  // labels per lane and round: that many loads in flight
+    for (int j = 1 + grp; j < nres; j += ngr) {
+      const size_t row = (size_t)row_of[j] * T_stride;
+      const int hi = b.lcp[j];
+      const int o0 = owner[j];
+      for (int q0 = lane; q0 < hi; q0 += lanes * kU) {
+        int32_t tk[kU], ts[kU];
+        for (int u = 0; u < kU; ++u) {
+          const int q = q0 + u * lanes;
+          if (q < hi) {
+            int o = o0;
+            while (b.lcp[o] > q) o = owner[o];  // label q of row j was read back by entry o (lcp[0] = -1 ends the walk)
+            const size_t src = (size_t)row_of[o] * T_stride + q;
+            tk[u] = out_tok[src];
+            ts[u] = out_ts[src];
+          }
+        }
+        for (int u = 0; u < kU; ++u) {
+          const int q = q0 + u * lanes;
+          if (q < hi) { out_tok[row + q] = tk[u]; out_ts[row + q] = ts[u]; }
+        }
       }
     }
   }
@@ -920,10 +1055,10 @@ struct PrunedRows {
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
 template <class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
-                            PoolNode *pool, int pool_cap, const uint64_t *tbl, int T_stride, int32_t *out_tok,
+                            PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, int T_stride, int32_t *out_tok,
                             int32_t *out_ts, float *out_score, int32_t *out_len, int32_t *n_results,
                             const StreamState *ss = nullptr) {
-  Decoder<X> dec(x, w, d, blank, pool, pool_cap, tbl);
+  Decoder<X> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   if (t0 > 0) dec.load_state(*ss); else dec.init();
@@ -988,7 +1123,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     if (x.uni(w.vars[VAR_STATUS]) != ST_OK) return w.vars[VAR_STATUS];
   }
   if (ss) dec.save_state(*ss, t0 + len);
-  if (!ss || ss->finish) dec.finish(t0 + len > 0, T_stride, out_tok, out_ts, out_score, out_len, n_results);
+  if (!ss || ss->finish) dec.finish(t0 + len > 0, t0 + len, T_stride, out_tok, out_ts, out_score, out_len, n_results);
   x.sync();
   x.mark(11);
   return ST_OK;

@@ -303,6 +303,7 @@ struct KernelArgs {
   int B, T, V, K, blank;
   Dims dims;
   PoolNode *pool;           // [B, pool_stride]
+  int *pool_up;             // [B, pool_stride] express pointers (beam_core.h kExpress)
   long long pool_stride;
   const uint64_t *tables;   // 64 words (exact_math.h)
   int32_t *out_tok, *out_ts, *out_len, *n_results;
@@ -348,6 +349,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
     prow.stride = a.pr_stride;
   }
   PoolNode *pool = a.pool + (size_t)b * a.pool_stride;
+  int *pool_up = a.pool_up + (size_t)b * a.pool_stride;
   int pool_cap = (int)a.pool_stride;
   StreamState ss;
   if (a.st_base) {
@@ -357,10 +359,11 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
     ss.finish = a.st_eos[b];
     pool = (PoolNode *)(base + a.st_pool_off);
     pool_cap = a.st_poolcap[b];
+    pool_up = (int *)(pool + pool_cap);
   }
   const size_t ko = (size_t)a.K * a.out_T;
   const int st = decode_utterance(x, w, a.dims, a.blank, a.pr_cnt ? nullptr : a.probs + (size_t)b * a.T * a.V,
-                                  a.pr_cnt ? &prow : (const PrunedRows *)nullptr, len, pool, pool_cap, tbl, a.out_T,
+                                  a.pr_cnt ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, a.out_T,
                                   a.out_tok + (size_t)b * ko, a.out_ts + (size_t)b * ko, a.out_score + (size_t)b * a.K,
                                   a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr,
                                   a.st_base ? &ss : (const StreamState *)nullptr);
@@ -720,7 +723,12 @@ struct StreamCall {          // extra arguments of a streaming decode
   int out_T;
 };
 
-size_t stream_pool_offset(int beam) { return ((size_t)(SH_WORDS + 13 * (size_t)beam) * 4 + 255) / 256 * 256; }
+size_t stream_pool_offset(int beam) { return ((size_t)(SH_WORDS + kStateArrays * (size_t)beam) * 4 + 255) / 256 * 256; }
+// a stream block holds [header | beam arrays | node pool (nodes * 16 B) | express pointers (nodes * 4 B)]
+size_t stream_nodes(long long frames, int beam) { return (size_t)frames * beam + 1; }
+size_t stream_block_bytes(long long cap_frames, int beam) {
+  return stream_pool_offset(beam) + stream_nodes(cap_frames, beam) * (sizeof(PoolNode) + sizeof(int));
+}
 
 Dims make_dims(int beam, int V, int cutoff_top_n, double cutoff_prob) {
   const bool pruned = cutoff_prob < 1.0 || cutoff_top_n < V;
@@ -872,7 +880,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     d->tables_ready = true;
   }
   const long long pool_stride = (long long)beam * T + 1;
-  if (!sc && (rc = d->pool.ensure((size_t)B * pool_stride * sizeof(PoolNode)))) return rc;
+  if (!sc && (rc = d->pool.ensure((size_t)B * pool_stride * (sizeof(PoolNode) + sizeof(int))))) return rc;
   if ((rc = d->status.ensure((size_t)B * 4))) return rc;
   // streaming: per-item block pointers, pool capacities and end-of-stream flags go to the device
   char **st_base = nullptr;
@@ -994,7 +1002,9 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
 
   KernelArgs a;
   a.probs = logp; a.seq_lens = seq_lens; a.B = B; a.T = T; a.V = V; a.K = beam; a.blank = blank_id; a.dims = dims;
-  a.pool = (PoolNode *)d->pool.p; a.pool_stride = pool_stride; a.tables = (const uint64_t *)d->tables.p;
+  a.pool = (PoolNode *)d->pool.p; a.pool_stride = pool_stride;
+  a.pool_up = (int *)(a.pool + (size_t)B * pool_stride);
+  a.tables = (const uint64_t *)d->tables.p;
   a.out_tok = out_tok; a.out_ts = out_ts; a.out_len = out_len; a.n_results = n_results; a.out_score = out_sc;
   a.status = (int32_t *)d->status.p;
   a.st_base = st_base; a.st_poolcap = st_cap; a.st_eos = st_eos; a.st_pool_off = (long long)stream_pool_offset(beam);
@@ -1045,7 +1055,7 @@ int ctcd_stream_create(ctcd_decoder *d, ctcd_stream **out, int V, int beam, int 
   st->V = V;
   st->beam = beam;
   st->cap_frames = frames_hint > 0 ? frames_hint : 1024;
-  st->bytes = stream_pool_offset(beam) + ((size_t)st->cap_frames * beam + 1) * sizeof(PoolNode);
+  st->bytes = stream_block_bytes(st->cap_frames, beam);
   hipError_t e = hipMalloc((void **)&st->block, st->bytes);
   if (e != hipSuccess) { delete st; return fail(CTCD_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
   e = hipMemset(st->block, 0, stream_pool_offset(beam));  // frames == 0: the first call initialises the beam
@@ -1085,11 +1095,14 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
     if (st->frames + len > st->cap_frames) {  // grow the node pool (device-to-device copy of the parked state)
       long long cap = st->cap_frames * 2;
       while (cap < st->frames + len) cap *= 2;
-      const size_t bytes = stream_pool_offset(beam) + ((size_t)cap * beam + 1) * sizeof(PoolNode);
+      const size_t bytes = stream_block_bytes(cap, beam);
       char *nb = nullptr;
       HIP_TRY(hipMalloc((void **)&nb, bytes));
       HIP_TRY(hipStreamSynchronize(stream));
-      HIP_TRY(hipMemcpy(nb, st->block, stream_pool_offset(beam) + ((size_t)st->frames * beam + 1) * sizeof(PoolNode), hipMemcpyDeviceToDevice));
+      const size_t used = stream_nodes(st->frames, beam), off = stream_pool_offset(beam);
+      HIP_TRY(hipMemcpy(nb, st->block, off + used * sizeof(PoolNode), hipMemcpyDeviceToDevice));
+      HIP_TRY(hipMemcpy(nb + off + stream_nodes(cap, beam) * sizeof(PoolNode),
+                        st->block + off + stream_nodes(st->cap_frames, beam) * sizeof(PoolNode), used * sizeof(int), hipMemcpyDeviceToDevice));
       (void)hipFree(st->block);
       st->block = nb;
       st->bytes = bytes;

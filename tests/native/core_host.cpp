@@ -134,6 +134,7 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
     std::vector<char> mem((big ? carve<true>(w, nullptr, nullptr, d, &far_bytes) : carve<false>(w, nullptr, nullptr, d, &far_bytes)) + 64);
     std::vector<char> far(far_bytes + 64);
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
+    std::vector<int> pool_up(pool.size());
     std::vector<int> pcnt(T), pch((size_t)T * d.Vc_max);
     std::vector<float> plp((size_t)T * d.Vc_max);
     for (;;) {
@@ -147,7 +148,7 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
       PrunedRows pr{pcnt.data(), pch.data(), plp.data(), d.Vc_max};
       if (pruned)
         for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
-      int st = decode_utterance(x, w, d, blank_id, pruned ? nullptr : rows, pruned ? &pr : nullptr, len, pool.data(), (int)pool.size(),
+      int st = decode_utterance(x, w, d, blank_id, pruned ? nullptr : rows, pruned ? &pr : nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                 ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T, out_timesteps + (size_t)b * beam * T,
                                 out_scores + (size_t)b * beam, out_lens + (size_t)b * beam, n_results + b);
       if (st != ST_OK) bad = st;
@@ -174,7 +175,8 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
   std::vector<char> mem(carve<false>(w, nullptr, nullptr, d, &far_bytes) + 64);
   for (int b = 0; b < B; ++b) {
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
-    std::vector<int> hdr(SH_WORDS, 0), arrays((size_t)13 * beam, 0);
+    std::vector<int> pool_up(pool.size());
+    std::vector<int> hdr(SH_WORDS, 0), arrays((size_t)kStateArrays * beam, 0);
     for (int c = 0; c < nchunks; ++c) {
       const int lo = bounds[c], hi = bounds[c + 1];
       // a fresh workspace every chunk, as a new kernel launch would have
@@ -183,7 +185,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       HostX x;
       StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
       int st = decode_utterance(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
-                                (int)pool.size(), ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T,
+                                pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T,
                                 out_timesteps + (size_t)b * beam * T, out_scores + (size_t)b * beam, out_lens + (size_t)b * beam,
                                 n_results + b, &ss);
       if (st != ST_OK) return -st;

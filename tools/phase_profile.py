@@ -9,9 +9,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-NAMES = ["A per-entry LCP scans, slot offsets, existing children", "B1 beam entries (thread 0's own part of B)", "B wait for the new-children waves", "D ordered compaction of survivors", "(unused)",
+NAMES = ["A per-entry LCP scans, slot offsets, existing children", "B1 beam entries (thread 0's own part of B)", "B wait for the new-children waves", "D ordered compaction of survivors", "finish: final sort",
          "C3 select: rank in bucket", "D' exact nth_element replay", "E emit next beam (work)", "E state update", "E end-of-frame fence (global writes)",
-         "frame load", "finish (sorts + back-trace)", "loop tail", "C1 select: find bucket", "C2 select: gather bucket", "(unused)"]
+         "frame load", "finish: copy shared labels", "loop tail", "C1 select: find bucket", "C2 select: gather bucket", "finish: read back unshared labels"]
 
 
 def main():
