@@ -107,7 +107,11 @@ constexpr int kSerialCut = 96;  // introselect ranges at most this long are fini
 constexpr int kExpress = 32;
 
 struct Work {
-  Beam cur, nxt;
+  // The beam is double-buffered: step t reads the copy of parity p and writes the other one.  cur / nxt are re-derived
+  // from (beam0, beam_blk, p) at the top of every step instead of being swapped, so that they are not values carried
+  // around the frame loop (26 pointers that would otherwise stay live in scalar registers).
+  Beam cur, nxt, beam0;
+  size_t beam_blk;  // bytes from an array of copy 0 to the same array of copy 1
   int *e, *anc, *ostart, *cstart, *pinr, *revr;  // per beam entry, this step
   int *ancbuf, *acntbuf;  // 2K each: nearest in-beam ancestor / number of in-beam ancestors, painted; by step parity
   uint32_t *hit;   // 2 words per entry: ranks (non-blank numbering) of the children that already exist
@@ -143,6 +147,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   char *p = base;
   const size_t K = (size_t)d.K, S = (size_t)d.S_max();
   Beam *bs[2] = {&w.cur, &w.nxt};
+  w.beam_blk = 13 * (((K * 4 + 15) / 16) * 16);
   for (int i = 0; i < 2; ++i) {
     Beam &b = *bs[i];
     b.node = carve_ptr<int>(p, K); b.par = carve_ptr<int>(p, K); b.ch = carve_ptr<int>(p, K);
@@ -151,6 +156,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
     b.bprev = carve_ptr<float>(p, K); b.nbprev = carve_ptr<float>(p, K); b.score = carve_ptr<float>(p, K);
     b.lpc = carve_ptr<float>(p, K);
   }
+  w.beam0 = w.cur;
   w.e = carve_ptr<int>(p, K); w.ancbuf = carve_ptr<int>(p, 2 * K); w.acntbuf = carve_ptr<int>(p, 2 * K); w.anc = w.ancbuf;
   w.ostart = carve_ptr<int>(p, K);
   w.cstart = carve_ptr<int>(p, K); w.pinr = carve_ptr<int>(p, K);
@@ -223,6 +229,21 @@ struct Decoder {
   // Step-to-step state, identical in every thread (kept in registers, not LDS)
   int st_n = 1, st_pool = 1, st_wlog = 32;
   uint32_t st_maxkey = 0;
+  int st_par = 0;  // which copy of the beam is current
+
+  template <class P>
+  CTC_HD static P *shifted(P *q, size_t bytes) { return reinterpret_cast<P *>(reinterpret_cast<char *>(q) + bytes); }
+  CTC_HD Beam beam_at(int par) const {
+    const Beam &o = w.beam0;
+    const size_t off = par ? w.beam_blk : 0;
+    Beam r;
+    r.node = shifted(o.node, off); r.par = shifted(o.par, off); r.ch = shifted(o.ch, off); r.dep = shifted(o.dep, off);
+    r.lcp = shifted(o.lcp, off); r.via = shifted(o.via, off); r.viaanc = shifted(o.viaanc, off); r.viach = shifted(o.viach, off);
+    r.up = shifted(o.up, off); r.bprev = shifted(o.bprev, off); r.nbprev = shifted(o.nbprev, off);
+    r.score = shifted(o.score, off); r.lpc = shifted(o.lpc, off);
+    return r;
+  }
+  CTC_HD void select_beams() { w.cur = beam_at(st_par); w.nxt = beam_at(st_par ^ 1); }
 
   CTC_HD int *pvars(int t) const { return w.vars + VAR_PAR0 + (t & 1) * P_SIZE; }
   CTC_HD void reset_pvars(int *pv) const {
@@ -231,6 +252,8 @@ struct Decoder {
 
   // ctc_beam_search_decoder.cpp:43-44 : root prefix, score = log_prob_b_prev = 0
   CTC_HD void init() {
+    st_par = 0;
+    select_beams();
     if (x.tid() == 0) {
       Beam &b = w.cur;
       b.node[0] = 0; b.par[0] = -1; b.ch[0] = -1; b.dep[0] = 0; b.lcp[0] = -1;
@@ -258,6 +281,8 @@ struct Decoder {
     const int tid = x.tid(), nt = x.nt(), K = d.K;
     st_n = x.uni(ss.hdr[SH_N]); st_pool = x.uni(ss.hdr[SH_POOL]); st_wlog = x.uni(ss.hdr[SH_WLOG]);
     st_maxkey = (uint32_t)x.uni(ss.hdr[SH_MAXKEY]);
+    st_par = 0;
+    select_beams();
     Beam &b = w.cur;
     int *ia[9] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach, b.up};
     float *fa[4] = {b.bprev, b.nbprev, b.score, b.lpc};
@@ -279,6 +304,7 @@ struct Decoder {
   }
   CTC_HD void save_state(const StreamState &ss, int frames) {
     const int tid = x.tid(), nt = x.nt(), K = d.K;
+    select_beams();
     const Beam &b = w.cur;
     const int *ia[9] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach, b.up};
     const float *fa[4] = {b.bprev, b.nbprev, b.score, b.lpc};
@@ -538,8 +564,9 @@ struct Decoder {
   // `stage`/`stage_val`: in identity mode the caller hands over its prefetched value of the NEXT frame's row; it is
   // parked in the other half of clpbuf before the closing fence, so the next frame starts without a load phase.
   CTC_HD void step(const StepIn &in, bool last, bool stage = false, float stage_val = 0.f) {
-    Beam &b = w.cur;
-    Beam &nb = w.nxt;
+    select_beams();
+    const Beam b = w.cur;
+    const Beam nb = w.nxt;
     const int tid = x.tid(), nt = x.nt();
     const int n = st_n, pool_count = st_pool;
     const int K = d.K;
@@ -878,7 +905,7 @@ struct Decoder {
     }
     x.dump(in.t, n_new, nb.node, nb.dep, nb.lcp, nb.score);
     x.mark(8);
-    Beam t = w.cur; w.cur = w.nxt; w.nxt = t;
+    st_par ^= 1;
   }
 
   // == std::sort(v, v + n, before) of libstdc++ (stl_emul.h), element for element -- also where `before` ties.
@@ -940,6 +967,7 @@ struct Decoder {
   // of a label sequence (the number of frames fed).
   CTC_HD void finish(bool had_steps, int max_depth, int T_stride, int32_t *out_tok, int32_t *out_ts, float *out_score, int32_t *out_len,
                      int32_t *n_results) {
+    select_beams();
     const Beam &b = w.cur;
     const int tid = x.tid(), nt = x.nt();
     const int n = st_n;

@@ -325,7 +325,14 @@ struct KernelArgs {
   int pr_stride;
 };
 
-template <bool PROF, bool BIG>
+// LAYOUT: 0 = the workspace is laid out for the call's own beam width / vocabulary (array bases are run-time values);
+// 1 = fixed layout for beam <= kFixedK, vocabulary <= kFixedV: every LDS array sits at a compile-time address, which
+// frees the scalar registers the bases would occupy and folds them into the instructions' offset fields.
+constexpr int kFixedK = 128, kFixedV = 32;
+__host__ __device__ constexpr Dims fixed_layout_dims() { return Dims{kFixedK, kFixedV, kFixedV, 1}; }
+__host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
+
+template <bool PROF, bool BIG, int LAYOUT>
 __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -333,7 +340,8 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   const int b = (int)blockIdx.x;
   if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
   Work w;
-  carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
+  if (LAYOUT == 1) carve<false>(w, smem, nullptr, fixed_layout_dims(), nullptr);
+  else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
   __shared__ long long prof[16];
   if (PROF && threadIdx.x < 16) prof[threadIdx.x] = 0;
   DevX<PROF, BIG> x{red, 0, prof, 0, (PROF && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K};
@@ -701,6 +709,7 @@ struct ctcd_decoder {
   bool tables_ready = false;
   bool timing = false;
   bool profile = false, dbg_on = false;
+  bool no_fixed_layout = false;  // debugging: always use the run-time workspace layout
   Buf prof, dbg;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
@@ -853,7 +862,9 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (dims.use_rank_table && V > 32767) return fail(CTCD_EUNSUPPORTED, "vocabulary pruning with more than 32767 labels");
   Work wtmp;
   size_t far_bytes = 0;
-  size_t lds = carve<false>(wtmp, nullptr, nullptr, dims, nullptr);
+  const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout;
+  const Dims ldims = fixed ? fixed_layout_dims() : dims;
+  size_t lds = carve<false>(wtmp, nullptr, nullptr, ldims, nullptr);
   bool big = false;
   if (lds + 2048 > (size_t)d->max_lds) {  // wide beam: rare-path arrays go to HBM scratch
     big = true;
@@ -1025,8 +1036,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     a.prof = (long long *)d->prof.p;
   }
   a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
-  const void *fn = d->profile ? (big ? (const void *)ctc_beam_decode_kernel<true, true> : (const void *)ctc_beam_decode_kernel<true, false>)
-                              : (big ? (const void *)ctc_beam_decode_kernel<false, true> : (const void *)ctc_beam_decode_kernel<false, false>);
+  const void *fn;
+  if (d->profile)
+    fn = big ? (const void *)ctc_beam_decode_kernel<true, true, 0>
+             : (fixed ? (const void *)ctc_beam_decode_kernel<true, false, 1> : (const void *)ctc_beam_decode_kernel<true, false, 0>);
+  else
+    fn = big ? (const void *)ctc_beam_decode_kernel<false, true, 0>
+             : (fixed ? (const void *)ctc_beam_decode_kernel<false, false, 1> : (const void *)ctc_beam_decode_kernel<false, false, 0>);
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
   void *kargs[] = {&a};
@@ -1180,6 +1196,14 @@ int ctcd_last_kernel_ms(ctcd_decoder *d, float *ms) {
 int ctcd_debug_set_profile(ctcd_decoder *d, int on) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   d->profile = on != 0;
+  return CTCD_OK;
+}
+
+// Workspace layout: 1 (default) = small shapes use the kernel variant whose LDS arrays sit at compile-time addresses,
+// 0 = always the run-time layout.  Results are identical; the switch exists so tests can run both variants.
+int ctcd_debug_set_fixed_layout(ctcd_decoder *d, int on) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  d->no_fixed_layout = on == 0;
   return CTCD_OK;
 }
 

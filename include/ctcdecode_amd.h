@@ -94,6 +94,9 @@ int ctcd_debug_math_check(ctcd_decoder *dec, int mode, uint32_t lo, uint32_t hi,
 /* Test/tuning hook: instrumented build of the kernel; out = int64 [B][16] per-phase timer ticks. */
 int ctcd_debug_set_profile(ctcd_decoder *dec, int on);
 int ctcd_debug_get_profile(ctcd_decoder *dec, long long *out, int B);
+/* Test hook: 1 (default) = beams <= 128 over <= 32 labels run the kernel variant with a compile-time workspace layout,
+ * 0 = always the run-time layout (identical results). */
+int ctcd_debug_set_fixed_layout(ctcd_decoder *dec, int on);
 /* Debug aid (instrumented build): beam of batch item 0 after every frame, int32 [T][1 + 4*beam] = n, then
  * (node, depth, lcp, score bits) per entry.  Call with on=1 before a decode, then with out != NULL to fetch. */
 int ctcd_debug_beam_dump(ctcd_decoder *dec, int on, int *out, int T, int beam);
