@@ -59,9 +59,8 @@ constexpr int kIntMax = 0x7fffffff;
 // Order-preserving map float -> uint32 (larger float = larger integer); -0.0 and +0.0 coincide, as they do
 // under the reference's operator== / operator> on float scores.
 CTC_HD uint32_t ord_f32(float f) {
-  uint32_t u = ctcmath::f32_to_bits(f);
-  if (u == 0x80000000u) u = 0;
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  const uint32_t u = ctcmath::f32_to_bits(f + 0.0f);  // -0 + +0 = +0: both zeros get the same key; nothing else changes
+  return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
 // info word: [31:16] 0xFFFF-(ch+1) (larger = earlier under "character asc"), [15:14] type, [13:0] beam entry
 CTC_HD uint32_t mk_info(int ch, uint32_t type, int entry) {
@@ -563,7 +562,8 @@ struct Decoder {
   // bookkeeping that DecoderState::decode() needs (the permutation std::nth_element leaves behind).
   // `stage`/`stage_val`: in identity mode the caller hands over its prefetched value of the NEXT frame's row; it is
   // parked in the other half of clpbuf before the closing fence, so the next frame starts without a load phase.
-  CTC_HD void step(const StepIn &in, bool last, bool stage = false, float stage_val = 0.f) {
+  // Returns ST_OK or the failure (identical in every thread; also left in VAR_STATUS).
+  CTC_HD int step(const StepIn &in, bool last, bool stage = false, float stage_val = 0.f) {
     select_beams();
     const Beam b = w.cur;
     const Beam nb = w.nxt;
@@ -720,12 +720,12 @@ struct Decoder {
             const uint32_t hw = w.hit[2 * i + (rn >> 5)];
             const int pch = b.ch[i];
             const float psc = b.score[i], pbp = b.bprev[i];
-            const bool exists = (hw >> (rn & 31)) & 1u;
+            const uint32_t live = 0u - (((hw >> (rn & 31)) & 1u) ^ 1u);  // all ones unless the child already exists
             const float ext = lp + psc, rep = pbp > CTC_NEG_MAX ? lp + pbp : CTC_NEG_MAX;  // :110-118
-            const uint32_t k = exists ? 0u : ord_f32(c == pch ? rep : ext);
+            const uint32_t k = ord_f32(c == pch ? rep : ext) & live;
             const int s = cs + rn;
             w.skey[s] = k;
-            w.sinfo[s] = exists ? kHoleInfo : (childinfo | (uint32_t)i);
+            w.sinfo[s] = ((childinfo | (uint32_t)i) & live) | (kHoleInfo & ~live);
             hist_add(wd, k);
           }
         }
@@ -824,54 +824,70 @@ struct Decoder {
     if (pool_count + n_new > pool_cap) {  // cannot happen when the pool is sized 1 + K*T
       if (tid == 0) w.vars[VAR_STATUS] = ST_POOL_OVERFLOW;
       x.sync_full();
-      return;
+      return ST_POOL_OVERFLOW;
     }
+    // Three independent parts per survivor -- its LCP with the previous survivor, its structural fields (+ the pool
+    // append), its probabilities -- go to three different sets of waves when the workgroup has them.
     uint32_t kloc = 0;
-    for (int k = tid; k < n_new; k += nt) {
-      const int s = surv[k];
-      const uint32_t inf = w.sinfo[s];
-      const uint32_t type = info_type(inf);
-      const int j = info_entry(inf);
-      // LCP with the previous survivor: the LCA depth of two candidates is the LCA depth of the entries they hang
-      // off (a brand-new child never lies on an existing path), capped by the depth of a revived interior node.
-      int l = -1;
-      if (k > 0) {
-        const uint32_t pinf = w.sinfo[surv[k - 1]];
-        const int pj = info_entry(pinf);
-        l = lca_depth(pj, j);
-        if (type == T_REVIVED) { const int dx = b.dep[w.anc[j]] + 1; l = dx < l ? dx : l; }
-        if (info_type(pinf) == T_REVIVED) { const int dx = b.dep[w.anc[pj]] + 1; l = dx < l ? dx : l; }
-      }
-      nb.lcp[k] = l;
-      if (type == T_SELF) {
-        nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = b.dep[j];
-        nb.via[k] = b.via[j]; nb.viaanc[k] = b.viaanc[j]; nb.viach[k] = b.viach[j]; nb.up[k] = b.up[j];
-        nb.bprev[k] = w.b_new[j]; nb.nbprev[k] = w.nb_new[j]; nb.score[k] = w.sc_new[j]; nb.lpc[k] = b.lpc[j];
-      } else {
-        const int c = info_ch(inf);
-        const int P = (type == T_CHILD) ? j : w.anc[j];
-        const float lp = w.clp[rank_of_char(in, c)];
-        const float logp = child_logp(P, c, lp);
-        int id;
-        float lpc;
-        if (type == T_CHILD) {  // path_trie.cpp:97-105; ids are handed out by beam position (gaps are harmless)
-          id = pool_count + k;
-          PoolNode pn; pn.parent = b.node[P]; pn.ch = c; pn.tstep = in.t; pn.lpc = lp;
-          pool[id] = pn;
-          const int upv = (b.dep[P] & (kExpress - 1)) == 0 ? pn.parent : b.up[P];
-          pool_up[id] = upv;
-          nb.up[k] = upv;
-          lpc = lp;
-        } else {                // path_trie.cpp:50-56 : revived, probabilities reset
-          id = b.via[j];
-          lpc = w.rev_lpc[j];
-          nb.up[k] = pool_up[id];
+    {
+      const int ne = (n_new + 63) & ~63;
+      const bool roles = nt >= 3 * ne;
+      const int role = roles ? tid / ne : -1;
+      const bool r_lcp = role <= 0, r_struct = role < 0 || role == 1, r_prob = role < 0 || role == 2;
+      for (int k = roles ? tid - role * ne : tid; k < n_new && role < 3; k += roles ? ne : nt) {
+        const int s = surv[k];
+        const uint32_t inf = w.sinfo[s];
+        const uint32_t type = info_type(inf);
+        const int j = info_entry(inf);
+        if (r_lcp) {
+          // LCP with the previous survivor: the LCA depth of two candidates is the LCA depth of the entries they hang
+          // off (a brand-new child never lies on an existing path), capped by the depth of a revived interior node.
+          int l = -1;
+          if (k > 0) {
+            const uint32_t pinf = w.sinfo[surv[k - 1]];
+            const int pj = info_entry(pinf);
+            l = lca_depth(pj, j);
+            if (type == T_REVIVED) { const int dx = b.dep[w.anc[j]] + 1; l = dx < l ? dx : l; }
+            if (info_type(pinf) == T_REVIVED) { const int dx = b.dep[w.anc[pj]] + 1; l = dx < l ? dx : l; }
+          }
+          nb.lcp[k] = l;
         }
-        nb.node[k] = id; nb.par[k] = b.node[P]; nb.ch[k] = c; nb.dep[k] = b.dep[P] + 1;
-        nb.viaanc[k] = -1;
-        nb.bprev[k] = CTC_NEG_MAX; nb.nbprev[k] = logp; nb.score[k] = logp; nb.lpc[k] = lpc;
+        if (type == T_SELF) {
+          if (r_struct) {
+            nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = b.dep[j];
+            nb.via[k] = b.via[j]; nb.viaanc[k] = b.viaanc[j]; nb.viach[k] = b.viach[j]; nb.up[k] = b.up[j];
+          }
+          if (r_prob) {
+            nb.bprev[k] = w.b_new[j]; nb.nbprev[k] = w.nb_new[j]; nb.score[k] = w.sc_new[j]; nb.lpc[k] = b.lpc[j];
+          }
+        } else {
+          const int c = info_ch(inf);
+          const int P = (type == T_CHILD) ? j : w.anc[j];
+          const float lp = w.clp[rank_of_char(in, c)];
+          if (r_struct) {
+            int id;
+            if (type == T_CHILD) {  // path_trie.cpp:97-105; ids are handed out by beam position (gaps are harmless)
+              id = pool_count + k;
+              PoolNode pn; pn.parent = b.node[P]; pn.ch = c; pn.tstep = in.t; pn.lpc = lp;
+              pool[id] = pn;
+              const int upv = (b.dep[P] & (kExpress - 1)) == 0 ? pn.parent : b.up[P];
+              pool_up[id] = upv;
+              nb.up[k] = upv;
+            } else {                // path_trie.cpp:50-56 : revived
+              id = b.via[j];
+              nb.up[k] = pool_up[id];
+            }
+            nb.node[k] = id; nb.par[k] = b.node[P]; nb.ch[k] = c; nb.dep[k] = b.dep[P] + 1;
+            nb.viaanc[k] = -1;
+          }
+          if (r_prob) {             // a new or revived prefix starts from its first path only (path_trie.cpp:52-56, 99-104)
+            const float logp = child_logp(P, c, lp);
+            nb.bprev[k] = CTC_NEG_MAX; nb.nbprev[k] = logp; nb.score[k] = logp;
+            nb.lpc[k] = type == T_CHILD ? lp : w.rev_lpc[j];
+          }
+        }
+        if (r_prob) kloc = w.skey[s] > kloc ? w.skey[s] : kloc;
       }
-      kloc = w.skey[s] > kloc ? w.skey[s] : kloc;
     }
     x.wave_max_to(&pv[P_NMAXKEY], kloc);
     if (last) {  // the order std::nth_element left the survivors in (identity when it was not called)
@@ -906,6 +922,7 @@ struct Decoder {
     x.dump(in.t, n_new, nb.node, nb.dep, nb.lcp, nb.score);
     x.mark(8);
     st_par ^= 1;
+    return ST_OK;
   }
 
   // == std::sort(v, v + n, before) of libstdc++ (stl_emul.h), element for element -- also where `before` ties.
@@ -1146,9 +1163,9 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       in.blank_rank = x.uni((int)w.rank_of[blank]);
     }
     x.mark(10);
-    dec.step(in, t == len - 1, stage, pre_lp);
+    const int st = dec.step(in, t == len - 1, stage, pre_lp);
     x.mark(12);
-    if (x.uni(w.vars[VAR_STATUS]) != ST_OK) return w.vars[VAR_STATUS];
+    if (st != ST_OK) return st;
   }
   if (ss) dec.save_state(*ss, t0 + len);
   if (!ss || ss->finish) dec.finish(t0 + len > 0, t0 + len, T_stride, out_tok, out_ts, out_score, out_len, n_results);

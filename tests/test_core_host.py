@@ -59,6 +59,13 @@ def _edge_cases():
     lp = ou.synth_logprobs(2, 40, 9, 8)
     lp[0, 10:20, :] = -3.0e38
     yield "near_minus_flt_max", lp, dict(beam=12)
+    # zeros of both signs (scores that are -0.0 / +0.0 compare equal), positive "log-probabilities", a denormal
+    lp = np.zeros((2, 30, 5), np.float32)
+    lp[:, :, 1] = -0.0
+    lp[:, ::2, 2] = 0.25
+    lp[:, 1::3, 3] = -1e-40
+    lp[1, :, 0] = -0.0
+    yield "signed_zeros_and_positive_values", lp, dict(beam=16)
 
 
 EDGE = list(_edge_cases())
