@@ -99,7 +99,7 @@ enum {
 constexpr int kBins = 1024;     // histogram buckets of the select
 constexpr int kBinsLog = 10;
 constexpr int kListCap = 128;   // exact-rank list (one bucket's keys)
-constexpr int kSerialCut = 96;  // introselect ranges at most this long are finished by one lane
+constexpr int kSerialCut = 24;  // introselect ranges at most this long are finished by one lane
 // Express pointers for the final back-trace: every pool node X (depth d >= 1) also records up(X) = its ancestor at
 // depth ((d - 1) / kExpress) * kExpress, so a label sequence of length d is read back as d / kExpress + 1 independent
 // segments of at most kExpress parent hops each instead of one chain of d dependent loads.
