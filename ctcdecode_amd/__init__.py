@@ -64,6 +64,10 @@ class CTCBeamDecoder(object):
     def set_threads(self, n):
         _native.check(_native.lib.ctcd_set_threads(self._handle, int(n)))
 
+    def set_fixed_layout(self, on=True):
+        """Test hook: False forces the run-time workspace layout also for small shapes (identical results)."""
+        _native.check(_native.lib.ctcd_debug_set_fixed_layout(self._handle, 1 if on else 0))
+
     def set_timing(self, on=True):
         _native.check(_native.lib.ctcd_set_timing(self._handle, 1 if on else 0))
 

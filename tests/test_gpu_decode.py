@@ -20,7 +20,7 @@ def torch_mod():
 
 
 def _decode(torch, probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, log_input=True, threads=None,
-            host_entry=False):
+            host_entry=False, fixed_layout=True):
     import ctcdecode_amd
 
     V = probs.shape[2]
@@ -28,6 +28,8 @@ def _decode(torch, probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n
                                        beam_width=beam, blank_id=blank_id, log_probs_input=log_input, device="cuda:0")
     if threads:
         dec.set_threads(threads)
+    if not fixed_layout:
+        dec.set_fixed_layout(False)
     try:
         out, sc, ts, ln = dec.decode(torch.from_numpy(np.ascontiguousarray(probs)),
                                      torch.from_numpy(seq_lens) if seq_lens is not None else None)
@@ -390,3 +392,15 @@ def test_device_math_bit_exact_vs_host_libm(torch_mod):
     x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
     n.check(n.lib.ctcd_debug_math_check(dec._handle, 2, 0, 0, 1, x.ctypes.data, y.ctypes.data, N, ctypes.byref(chk), ctypes.byref(bad)))
     assert chk.value == N and bad.value == 0
+
+
+@pytest.mark.parametrize("threads", [256, 1024])
+def test_both_workspace_layouts(torch_mod, threads):
+    """Small shapes normally run the kernel variant with compile-time LDS addresses; the run-time layout (used by wide
+    beams / large vocabularies) must give the same, oracle-identical, results on them."""
+    for seed, (B, T, V, K, top_n) in enumerate([(3, 150, 29, 100, 40), (2, 90, 8, 128, 3), (2, 60, 32, 17, 40), (2, 200, 29, 64, 40)]):
+        lp = ou.synth_logprobs(B, T, V, 900 + seed, quant=[None, 0.5, None, 1.0][seed])
+        want = ou.decode(lp, beam=K, cutoff_top_n=top_n)
+        for fixed in (True, False):
+            got = _decode(torch_mod, lp, beam=K, cutoff_top_n=top_n, threads=threads, fixed_layout=fixed)
+            ou.assert_same(_with_nres(got, want), want, "layout fixed=%s B%d T%d V%d K%d" % (fixed, B, T, V, K))

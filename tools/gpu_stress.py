@@ -49,6 +49,8 @@ def main():
         if it % 2 == 0:
             dec = ctcdecode_amd.CTCBeamDecoder(labels, cutoff_top_n=top_n, cutoff_prob=cutoff, beam_width=K, blank_id=blank, log_probs_input=True)
             dec.set_threads(threads)
+            if it % 4 == 2:
+                dec.set_fixed_layout(False)
             out, sc, ts, ln = dec.decode(torch.from_numpy(lp), torch.from_numpy(sl) if sl is not None else None)
             got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy(), nres=want["nres"])
         else:  # streaming with random chunk boundaries
