@@ -209,7 +209,10 @@ CTC_HD int ceil_log2_u64(uint64_t v) {  // smallest s with (1 << s) >= v, v >= 1
   return v <= 1 ? 0 : 64 - __builtin_clzll(v - 1);
 }
 
-template <class X>
+// IDENT: the utterance is decoded without vocabulary pruning (candidate r of every frame is label r).  A compile-time
+// switch: the two modes keep different things in flight across a frame (next row vs. next candidate list), and mixing
+// them in one instantiation makes the compiler wait for the prefetch where the other mode's registers are written.
+template <class X, bool IDENT>
 struct Decoder {
   X &x;
   Work &w;
@@ -320,7 +323,7 @@ struct Decoder {
 
   CTC_HD int rank_of_char(const StepIn &in, int c) const {
     if (c < 0) return -1;
-    if (in.identity) return c < in.Vc ? c : -1;
+    if (IDENT) return c < in.Vc ? c : -1;
     return w.rank_of[c];
   }
 
@@ -711,7 +714,7 @@ struct Decoder {
         const int sh = ceil_log2_u64((uint64_t)lp2);
         if (rn < Vnb && (t2 >> sh) < ng) {
           const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
-          const int c = in.identity ? r : w.cch[r];
+          const int c = IDENT ? r : w.cch[r];
           const float lp = w.clp[r];
           const uint32_t childinfo = mk_info(c, T_CHILD, 0);
           for (int i = t2 >> sh; i < n; i += ng) {
@@ -733,7 +736,7 @@ struct Decoder {
         for (int idx = t2; idx < n * Vnb; idx += nt2) {
           const int i = idx / Vnb, rn = idx - i * Vnb;
           const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
-          const int c = in.identity ? r : w.cch[r];
+          const int c = IDENT ? r : w.cch[r];
           const int s = w.cstart[i] + rn;
           const bool exists = small_vocab && ((w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u);
           const uint32_t k = exists ? 0u : ord_f32(child_logp(i, c, w.clp[r]));
@@ -895,7 +898,7 @@ struct Decoder {
     }
     // un-register this step's candidates from the rank table -- only once every wave has finished emitting (the emit
     // loop above still looks characters up in it)
-    if (!in.identity) {
+    if (!IDENT) {
       x.sync();
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
     }
@@ -1098,30 +1101,30 @@ struct PrunedRows {
 };
 
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
-template <class X>
+template <bool IDENT, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, int T_stride, int32_t *out_tok,
                             int32_t *out_ts, float *out_score, int32_t *out_len, int32_t *n_results,
                             const StreamState *ss = nullptr) {
-  Decoder<X> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl);
+  Decoder<X, IDENT> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   if (t0 > 0) dec.load_state(*ss); else dec.init();
   const int tid = x.tid(), nt = x.nt();
   // Prefetch: the candidates of step t+1 are requested from HBM before step t runs, so the latency hides behind it.
-  const int width = pr ? pr->stride : d.V;
+  const int width = IDENT ? d.V : pr->stride;
   const bool prefetch = width <= nt;
   float pre_lp = 0.f;
   int pre_ch = 0, pre_cnt = 0;
   if (prefetch && len > 0) {
-    if (pr) {
+    if (!IDENT) {
       pre_cnt = pr->cnt[0];
       if (tid < width) { pre_ch = pr->ch[tid]; pre_lp = pr->lp[tid]; }
     } else if (tid < width) {
       pre_lp = rows[tid];
     }
   }
-  if (pr == nullptr && prefetch && len > 0) {  // frame 0 goes straight to LDS; from then on step() stages frame t+1
+  if (IDENT && prefetch && len > 0) {  // frame 0 goes straight to LDS; from then on step() stages frame t+1
     if (tid < d.V) w.clpbuf[(t0 & 1) * d.Vc_max + tid] = pre_lp;
     x.sync();
   }
@@ -1129,7 +1132,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     StepIn in;
     in.t = t0 + t;
     bool stage = false;
-    if (pr == nullptr) {
+    if (IDENT) {
       in.Vc = d.V;
       in.identity = 1;
       in.blank_rank = blank;

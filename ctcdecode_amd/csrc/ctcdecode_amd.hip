@@ -332,7 +332,8 @@ constexpr int kFixedK = 128, kFixedV = 32;
 __host__ __device__ constexpr Dims fixed_layout_dims() { return Dims{kFixedK, kFixedV, kFixedV, 1}; }
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
 
-template <bool PROF, bool BIG, int LAYOUT>
+// PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
+template <bool PROF, bool BIG, int LAYOUT, bool PRUNED>
 __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   __syncthreads();
   if (PROF) x.last = (long long)wall_clock64();
   PrunedRows prow;
-  if (a.pr_cnt) {
+  if (PRUNED) {
     prow.cnt = a.pr_cnt + (size_t)b * a.T;
     prow.ch = a.pr_ch + (size_t)b * a.T * a.pr_stride;
     prow.lp = a.pr_lp + (size_t)b * a.T * a.pr_stride;
@@ -370,8 +371,8 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
     pool_up = (int *)(pool + pool_cap);
   }
   const size_t ko = (size_t)a.K * a.out_T;
-  const int st = decode_utterance(x, w, a.dims, a.blank, a.pr_cnt ? nullptr : a.probs + (size_t)b * a.T * a.V,
-                                  a.pr_cnt ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, a.out_T,
+  const int st = decode_utterance<!PRUNED>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
+                                  PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, a.out_T,
                                   a.out_tok + (size_t)b * ko, a.out_ts + (size_t)b * ko, a.out_score + (size_t)b * a.K,
                                   a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr,
                                   a.st_base ? &ss : (const StreamState *)nullptr);
@@ -1036,13 +1037,14 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     a.prof = (long long *)d->prof.p;
   }
   a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
+  const bool pruned_mode = a.pr_cnt != nullptr;
   const void *fn;
-  if (d->profile)
-    fn = big ? (const void *)ctc_beam_decode_kernel<true, true, 0>
-             : (fixed ? (const void *)ctc_beam_decode_kernel<true, false, 1> : (const void *)ctc_beam_decode_kernel<true, false, 0>);
-  else
-    fn = big ? (const void *)ctc_beam_decode_kernel<false, true, 0>
-             : (fixed ? (const void *)ctc_beam_decode_kernel<false, false, 1> : (const void *)ctc_beam_decode_kernel<false, false, 0>);
+#define CTC_PICK(PROF_)                                                                                                  \
+  (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, true, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, true, 0, false>)    \
+       : fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, false, 1, true> : (const void *)ctc_beam_decode_kernel<PROF_, false, 1, false>) \
+               : (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, false, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, false, 0, false>))
+  fn = d->profile ? CTC_PICK(true) : CTC_PICK(false);
+#undef CTC_PICK
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
   void *kargs[] = {&a};

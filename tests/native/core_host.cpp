@@ -148,7 +148,11 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
       PrunedRows pr{pcnt.data(), pch.data(), plp.data(), d.Vc_max};
       if (pruned)
         for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
-      int st = decode_utterance(x, w, d, blank_id, pruned ? nullptr : rows, pruned ? &pr : nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+int st;
+      if (pruned) st = decode_utterance<false>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T, out_timesteps + (size_t)b * beam * T,
+                                out_scores + (size_t)b * beam, out_lens + (size_t)b * beam, n_results + b);
+      else st = decode_utterance<true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                 ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T, out_timesteps + (size_t)b * beam * T,
                                 out_scores + (size_t)b * beam, out_lens + (size_t)b * beam, n_results + b);
       if (st != ST_OK) bad = st;
@@ -184,7 +188,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       carve<false>(w, mem.data(), nullptr, d, nullptr);
       HostX x;
       StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
-      int st = decode_utterance(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
+      int st = decode_utterance<true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
                                 pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T,
                                 out_timesteps + (size_t)b * beam * T, out_scores + (size_t)b * beam, out_lens + (size_t)b * beam,
                                 n_results + b, &ss);
