@@ -375,9 +375,9 @@ struct Decoder {
     for (;;) {
       // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
       //    [2] #keys in the window, [3] #keys in b*.  Two-level: the coarse buckets locate the group of 16 fine ones.
-      //    Ends with a barrier; the histogram is cleared afterwards (next frame / next round needs it empty).
+      //    Ends with a barrier.  The histogram is cleared before another round; after the last one step() clears it
+      //    (with the other per-frame resets, on waves that are idle while the next beam is emitted).
       x.find_bucket(w.bins, need, &w.vars[VAR_FB0]);
-      for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
       int fb[4];
       x.uni4(&w.vars[VAR_FB0], fb);
       const int bstar = fb[0], above = fb[1], total = fb[2], inb = fb[3];
@@ -443,6 +443,7 @@ struct Decoder {
       }
       // another histogram round over [lo, hi)
       first = false;
+      for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
       x.sync();  // the histogram has been cleared by every thread
       const uint64_t width = hi - lo;
       shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
@@ -491,17 +492,18 @@ struct Decoder {
     const Beam &b = w.cur;
     if (ja == jb) return b.dep[ja];
     const int lo = ja < jb ? ja : jb, hi = ja < jb ? jb : ja;
+    // eight independent loads per trip (indices past the range are clamped onto its last element: harmless for a
+    // minimum); consecutive survivors are rarely further apart, so this is one LDS round trip
     int m = kIntMax;
-    int i = lo + 1;
-    for (; i + 3 <= hi; i += 4) {  // four independent loads per trip
-      const int l0 = b.lcp[i], l1 = b.lcp[i + 1], l2 = b.lcp[i + 2], l3 = b.lcp[i + 3];
-      const int m01 = l0 < l1 ? l0 : l1, m23 = l2 < l3 ? l2 : l3;
-      const int mm = m01 < m23 ? m01 : m23;
+    for (int i = lo + 1; i <= hi; i += 8) {
+      const int i1 = i + 1 < hi ? i + 1 : hi, i2 = i + 2 < hi ? i + 2 : hi, i3 = i + 3 < hi ? i + 3 : hi;
+      const int i4 = i + 4 < hi ? i + 4 : hi, i5 = i + 5 < hi ? i + 5 : hi, i6 = i + 6 < hi ? i + 6 : hi, i7 = i + 7 < hi ? i + 7 : hi;
+      const int l0 = b.lcp[i], l1 = b.lcp[i1], l2 = b.lcp[i2], l3 = b.lcp[i3];
+      const int l4 = b.lcp[i4], l5 = b.lcp[i5], l6 = b.lcp[i6], l7 = b.lcp[i7];
+      const int m01 = l0 < l1 ? l0 : l1, m23 = l2 < l3 ? l2 : l3, m45 = l4 < l5 ? l4 : l5, m67 = l6 < l7 ? l6 : l7;
+      const int ma = m01 < m23 ? m01 : m23, mb = m45 < m67 ? m45 : m67;
+      const int mm = ma < mb ? ma : mb;
       m = mm < m ? mm : m;
-    }
-    for (; i <= hi; ++i) {
-      const int l = b.lcp[i];
-      m = l < m ? l : m;
     }
     return m;
   }
@@ -588,6 +590,7 @@ struct Decoder {
     // range) and in acnt[] the number of in-beam ancestors.  Cost is bounded even for deeply nested beams.
     w.anc = w.ancbuf + (in.t & 1) * K;
     int *acnt = w.acntbuf + (in.t & 1) * K;
+    x.tick();
     {
       const int grp = x.group(), ngr = x.ngroups();
       const int mine = grp < n ? (n - grp + ngr - 1) / ngr : 0;  // entries grp, grp + ngr, ... belong to this group
@@ -615,6 +618,7 @@ struct Decoder {
         }
       }
     }
+    x.tick();
     x.sync();
     // ---- A2: Euler-tour slot offsets; which children of in-beam parents already exist
     int npin = 0;
@@ -765,12 +769,6 @@ struct Decoder {
     const int N = n * (1 + Vnb) - x.uni(pv[P_NPIN]);
     uint32_t tau = 0, tauc = 0;
     bool exact = false, have_bitmap = false;
-    if (tid == 0) reset_pvars(pvars(in.t + 1));  // the other parity set: free since the end of the previous step
-    for (int i = tid; i < 2 * n; i += nt) w.hit[i] = 0;  // all readers of hit[] are behind the barrier above
-    {
-      int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;  // next step's paint buffers
-      for (int i = tid; i < K; i += nt) { oa[i] = -1; oc[i] = 0; }
-    }
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
       have_bitmap = select_kth(S, K, pv);
       int tv[4];
@@ -783,9 +781,6 @@ struct Decoder {
         else exact = true;  // the boundary splits a group of equivalent prefixes
       }
       if (last) exact = true;  // decode() sorts the array exactly as nth_element left it (:164-190)
-    } else {
-      // nothing to prune; the histogram was filled for nothing: clear it for the next step
-      for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
     }
     x.mark(5);
 
@@ -837,6 +832,20 @@ struct Decoder {
       const bool roles = nt >= 3 * ne;
       const int role = roles ? tid / ne : -1;
       const bool r_lcp = role <= 0, r_struct = role < 0 || role == 1, r_prob = role < 0 || role == 2;
+      // Per-frame resets for the next step, on the threads that have no part in the emission (all of them otherwise):
+      // the select histogram, the existing-children masks (last read in phase B), the paint buffers and counters of
+      // the other parity.
+      {
+        const bool spare = roles && nt > 3 * ne;
+        if (!spare || tid >= 3 * ne) {
+          const int t0 = spare ? tid - 3 * ne : tid, tstep = spare ? nt - 3 * ne : nt;
+          for (int i = t0; i < kBins + kBins / 16; i += tstep) w.bins[i] = 0;
+          for (int i = t0; i < 2 * n; i += tstep) w.hit[i] = 0;
+          int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;
+          for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }
+          if (t0 == 0) reset_pvars(pvars(in.t + 1));
+        }
+      }
       for (int k = roles ? tid - role * ne : tid; k < n_new && role < 3; k += roles ? ne : nt) {
         const int s = surv[k];
         const uint32_t inf = w.sinfo[s];
@@ -922,6 +931,7 @@ struct Decoder {
       st_n = n_new;
       st_pool = pool_count + n_new;
     }
+    x.tick();
     x.dump(in.t, n_new, nb.node, nb.dep, nb.lcp, nb.score);
     x.mark(8);
     st_par ^= 1;
@@ -1131,6 +1141,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   for (int t = 0; t < len; ++t) {
     StepIn in;
     in.t = t0 + t;
+    x.trace_frame(in.t);
     bool stage = false;
     if (IDENT) {
       in.Vc = d.V;
@@ -1165,6 +1176,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       x.sync();
       in.blank_rank = x.uni((int)w.rank_of[blank]);
     }
+    x.tick();
     x.mark(10);
     const int st = dec.step(in, t == len - 1, stage, pre_lp);
     x.mark(12);

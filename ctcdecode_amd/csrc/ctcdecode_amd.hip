@@ -84,10 +84,25 @@ struct DevX {
   // LDS-only barrier: waits for this wave's LDS traffic, not for outstanding global loads/stores (the row prefetch
   // and the pool appends stay in flight across phases).  sync_full() is the fence that also drains global memory.
   __device__ void sync() {
+    if (PROF && tl_on) tl_rec();
     if (FAR) __syncthreads();
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (PROF && tl_on) tl_rec();
   }
-  __device__ void sync_full() { __syncthreads(); }
+  __device__ void sync_full() {
+    if (PROF && tl_on) tl_rec();
+    __syncthreads();
+    if (PROF && tl_on) tl_rec();
+  }
+  // Barrier timeline (profiling build, tools/barrier_timeline.py): during a few chosen frames of batch item 0 every
+  // wave stores the shader clock when it arrives at, and when it leaves, each barrier.
+  long long *tl; int tl_cap, tl_f0, tl_nf, tl_n, tl_on;
+  __device__ void tl_rec() {
+    if ((threadIdx.x & 63) == 0 && tl_n < tl_cap) tl[(size_t)(threadIdx.x >> 6) * tl_cap + tl_n] = (long long)clock64();
+    ++tl_n;
+  }
+  __device__ void tick() { if (PROF && tl_on) tl_rec(); }  // extra stamp between barriers
+  __device__ void trace_frame(int t) { tl_on = PROF && tl != nullptr && t >= tl_f0 && t < tl_f0 + tl_nf; }
   // a value every thread of the workgroup holds identically -> scalar register (branches/loops on it become scalar)
   __device__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   // four consecutive, 16-byte aligned LDS words every thread reads identically: one ds_read_b128
@@ -297,6 +312,8 @@ struct DevX {
   }
 };
 
+constexpr int kTimelineCap = 1024;  // barrier timeline entries per wave
+
 struct KernelArgs {
   const float *probs;       // [B, T, V] log-probabilities
   const int32_t *seq_lens;  // [B] or null
@@ -311,6 +328,8 @@ struct KernelArgs {
   int32_t *status;          // [B]
   long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
   int *dbg;                 // profiling build: beam of item 0 after every frame, [T][1 + 4K] (or null)
+  long long *tl;            // profiling build: barrier timeline of item 0, [waves][tl_cap] (or null)
+  int tl_cap, tl_f0, tl_nf;
   char *far;                // BIG layout: per-utterance HBM scratch, far_stride bytes each
   long long far_stride;
   // streaming (ctcd_stream_decode): per item, the HBM block that holds its parked beam + node pool
@@ -345,7 +364,8 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
   __shared__ long long prof[16];
   if (PROF && threadIdx.x < 16) prof[threadIdx.x] = 0;
-  DevX<PROF, BIG> x{red, 0, prof, 0, (PROF && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K};
+  DevX<PROF, BIG> x{red, 0, prof, 0, (PROF && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
+                    (PROF && b == 0) ? a.tl : nullptr, a.tl_cap, a.tl_f0, a.tl_nf, 0, 0};
   int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();
@@ -711,7 +731,9 @@ struct ctcd_decoder {
   bool timing = false;
   bool profile = false, dbg_on = false;
   bool no_fixed_layout = false;  // debugging: always use the run-time workspace layout
-  Buf prof, dbg;
+  Buf prof, dbg, tl;
+  int tl_f0 = 0, tl_nf = 0;
+  bool tl_armed = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
 };
@@ -834,6 +856,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
+  d->dbg.release(); d->tl.release();
   delete d;
 }
 
@@ -1028,6 +1051,12 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   }
   a.prof = nullptr;
   a.dbg = nullptr;
+  a.tl = nullptr; a.tl_cap = kTimelineCap; a.tl_f0 = d->tl_f0; a.tl_nf = d->tl_nf;
+  if (d->profile && d->tl_armed) {
+    if ((rc = d->tl.ensure((size_t)16 * kTimelineCap * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(d->tl.p, 0, (size_t)16 * kTimelineCap * 8, stream));
+    a.tl = (long long *)d->tl.p;
+  }
   if (d->profile && d->dbg_on) {
     if ((rc = d->dbg.ensure((size_t)(T + 1) * (1 + 4 * (size_t)beam) * 4))) return rc;
     a.dbg = (int *)d->dbg.p;
@@ -1206,6 +1235,20 @@ int ctcd_debug_set_profile(ctcd_decoder *d, int on) {
 int ctcd_debug_set_fixed_layout(ctcd_decoder *d, int on) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   d->no_fixed_layout = on == 0;
+  return CTCD_OK;
+}
+
+// Barrier timeline of batch item 0 (profiling build): call with out == NULL to arm frames [frame0, frame0 + nframes) of
+// the following decodes, with out != NULL (int64 [16][ctcd_debug_timeline_cap()]) to fetch: per wave, the shader clock
+// at arrival at / departure from each barrier, in program order.
+int ctcd_debug_timeline_cap(void) { return kTimelineCap; }
+int ctcd_debug_timeline(ctcd_decoder *d, int frame0, int nframes, long long *out) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  if (!out) { d->tl_f0 = frame0; d->tl_nf = nframes; d->tl_armed = nframes > 0; return CTCD_OK; }
+  if (!d->tl.p) return fail(CTCD_EINVAL, "no timeline recorded");
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d->tl.p, (size_t)16 * kTimelineCap * 8, hipMemcpyDeviceToHost));
   return CTCD_OK;
 }
 

@@ -97,6 +97,11 @@ int ctcd_debug_get_profile(ctcd_decoder *dec, long long *out, int B);
 /* Test hook: 1 (default) = beams <= 128 over <= 32 labels run the kernel variant with a compile-time workspace layout,
  * 0 = always the run-time layout (identical results). */
 int ctcd_debug_set_fixed_layout(ctcd_decoder *dec, int on);
+/* Tuning aid (instrumented build): per-wave shader-clock stamps at every workgroup barrier of batch item 0 during frames
+ * [frame0, frame0 + nframes).  out == NULL arms the following decodes; out != NULL (int64 [16][ctcd_debug_timeline_cap()])
+ * fetches the stamps, arrival and departure alternating, in program order (tools/barrier_timeline.py). */
+int ctcd_debug_timeline_cap(void);
+int ctcd_debug_timeline(ctcd_decoder *dec, int frame0, int nframes, long long *out);
 /* Debug aid (instrumented build): beam of batch item 0 after every frame, int32 [T][1 + 4*beam] = n, then
  * (node, depth, lcp, score bits) per entry.  Call with on=1 before a decode, then with out != NULL to fetch. */
 int ctcd_debug_beam_dump(ctcd_decoder *dec, int on, int *out, int T, int beam);

@@ -36,6 +36,8 @@ struct HostX {
   void atomic_max(int *p, int v) { *p = std::max(*p, v); }
   float unif(float v) const { return v; }
   void mark(int) {}
+  void trace_frame(int) {}
+  void tick() {}
   void dump(int, int, const int *, const int *, const int *, const float *) {}
   uint32_t scan_excl(uint32_t *a, int n) {
     uint32_t run = 0;
