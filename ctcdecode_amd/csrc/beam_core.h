@@ -205,6 +205,11 @@ struct StepIn {
 };
 
 
+// v / d and ceil(v / d) for d > 0 that is almost always a power of two (wave counts, lanes per group): the GPU has no
+// integer divide, a generic run-time division is ~25 instructions on every wave.
+CTC_HD int div_p2(int v, int d) { return (d & (d - 1)) == 0 ? v >> __builtin_ctz((unsigned)d) : v / d; }
+CTC_HD int ceil_div_p2(int v, int d) { return div_p2(v + d - 1, d); }
+
 CTC_HD int ceil_log2_u64(uint64_t v) {  // smallest s with (1 << s) >= v, v >= 1
   return v <= 1 ? 0 : 64 - __builtin_clzll(v - 1);
 }
@@ -593,7 +598,7 @@ struct Decoder {
     x.tick();
     {
       const int grp = x.group(), ngr = x.ngroups();
-      const int mine = grp < n ? (n - grp + ngr - 1) / ngr : 0;  // entries grp, grp + ngr, ... belong to this group
+      const int mine = grp < n ? ceil_div_p2(n - grp, ngr) : 0;  // entries grp, grp + ngr, ... belong to this group
       for (int k0 = 0; k0 < mine; k0 += x.lanes()) {
         // leaves (the next entry is not a descendant) are settled one per lane; only entries with in-beam
         // descendants need the wave-wide search and the painting
@@ -714,7 +719,7 @@ struct Decoder {
       while (lp2 < Vnb) lp2 <<= 1;                   // lanes per parent (power of two >= Vnb)
       if (small_vocab && nt2 >= lp2) {               // a group of lp2 lanes per parent, one lane per character
         const int rn = t2 & (lp2 - 1);
-        const int ng = nt2 / lp2;
+        const int ng = nt2 >> ceil_log2_u64((uint64_t)lp2);  // lp2 is a power of two
         const int sh = ceil_log2_u64((uint64_t)lp2);
         if (rn < Vnb && (t2 >> sh) < ng) {
           const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
@@ -830,7 +835,7 @@ struct Decoder {
     {
       const int ne = (n_new + 63) & ~63;
       const bool roles = nt >= 3 * ne;
-      const int role = roles ? tid / ne : -1;
+      const int role = roles ? (tid >= ne) + (tid >= 2 * ne) + (tid >= 3 * ne) : -1;  // 3 = no part
       const bool r_lcp = role <= 0, r_struct = role < 0 || role == 1, r_prob = role < 0 || role == 2;
       // Per-frame resets for the next step, on the threads that have no part in the emission (all of them otherwise):
       // the select histogram, the existing-children masks (last read in phase B), the paint buffers and counters of

@@ -147,7 +147,7 @@ struct DevX {
   __device__ void mark_slots(int S, uint32_t *bitmap, Pred pred) {
     const int lane = (int)threadIdx.x & 63, nw = ((int)blockDim.x + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int rounds = (S + 64 * nw - 1) / (64 * nw);
+    const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
     const int first = wave * rounds * 64;
     if (rounds <= 4) {  // common case: straight-line, the four predicates (and their LDS reads) issued together
       const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
@@ -202,7 +202,7 @@ struct DevX {
   __device__ void compact_slots(int S, int *out, Pred pred) {
     const int lane = (int)threadIdx.x & 63, nw = ((int)blockDim.x + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int rounds = (S + 64 * nw - 1) / (64 * nw);
+    const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
     const int first = wave * rounds * 64;
     int *row = red + parity * 16;
     parity ^= 1;
@@ -285,7 +285,7 @@ struct DevX {
   // In-place exclusive prefix sum of a[0, n) in LDS; returns the total.  Each thread owns a contiguous chunk.
   __device__ uint32_t scan_excl(uint32_t *a, int n) {
     const int nthreads = (int)blockDim.x, t = (int)threadIdx.x;
-    const int chunk = ((n + nthreads - 1) / nthreads) | 1;  // odd stride: no LDS bank conflicts across lanes
+    const int chunk = ctcbeam::ceil_div_p2(n, nthreads) | 1;  // odd stride: no LDS bank conflicts across lanes
     const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
     uint32_t sum = 0;
     for (int i = lo; i < hi; ++i) sum += a[i];
