@@ -55,14 +55,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 // FAR: part of the workspace lives in HBM (BIG layout): every barrier must then also drain global memory traffic.
-template <bool PROF, bool FAR>
+// PROF: 0 = product build; 1 = per-phase timers (mark) and the beam dump; 2 = barrier timeline only (no timers: the
+// timers' mutable state would put this object into scratch memory and distort the timeline).
+template <int PROF, bool FAR>
 struct DevX {
   int *red;  // 2 x 16 ints of LDS
   int parity;
   long long *prof;   // PROF: per-phase cycle accumulators (LDS), written by thread 0
   long long last;
-  __device__ void mark(int id) {
-    if (PROF && threadIdx.x == 0) {
+  __device__ __forceinline__ void mark(int id) {
+    if (PROF == 1 && threadIdx.x == 0) {
       const long long now = (long long)wall_clock64();
       prof[id] += now - last;
       last = now;
@@ -70,8 +72,8 @@ struct DevX {
   }
   // debugging aid (profiling build only): the beam after every frame -> dbg[t][0] = n, then (node, dep, lcp, score bits) per entry
   int *dbg; int dbg_stride;
-  __device__ void dump(int t, int n, const int *node, const int *dep, const int *lcp, const float *score) {
-    if (PROF && dbg) {
+  __device__ __forceinline__ void dump(int t, int n, const int *node, const int *dep, const int *lcp, const float *score) {
+    if (PROF == 1 && dbg) {
       int *o = dbg + (size_t)t * dbg_stride;
       if (threadIdx.x == 0) o[0] = n;
       for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -79,49 +81,60 @@ struct DevX {
       }
     }
   }
-  __device__ int tid() const { return (int)threadIdx.x; }
-  __device__ int nt() const { return (int)blockDim.x; }
+  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+  __device__ __forceinline__ int nt() const { return (int)blockDim.x; }
   // LDS-only barrier: waits for this wave's LDS traffic, not for outstanding global loads/stores (the row prefetch
   // and the pool appends stay in flight across phases).  sync_full() is the fence that also drains global memory.
-  __device__ void sync() {
-    if (PROF && tl_on) tl_rec();
+  __device__ __forceinline__ void sync() {
+    if (PROF == 2 && tl) tl_rec();
     if (FAR) __syncthreads();
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (PROF && tl_on) tl_rec();
+    if (PROF == 2 && tl) tl_rec();
   }
-  __device__ void sync_full() {
-    if (PROF && tl_on) tl_rec();
+  __device__ __forceinline__ void sync_full() {
+    if (PROF == 2 && tl) tl_rec();
     __syncthreads();
-    if (PROF && tl_on) tl_rec();
+    if (PROF == 2 && tl) tl_rec();
   }
   // Barrier timeline (profiling build, tools/barrier_timeline.py): during a few chosen frames of batch item 0 every
   // wave stores the shader clock when it arrives at, and when it leaves, each barrier.
-  long long *tl; int tl_cap, tl_f0, tl_nf, tl_n, tl_on;
-  __device__ void tl_rec() {
-    if ((threadIdx.x & 63) == 0 && tl_n < tl_cap) tl[(size_t)(threadIdx.x >> 6) * tl_cap + tl_n] = (long long)clock64();
-    ++tl_n;
+  // (stamps go to LDS -- a global store per stamp would make the compiler's memory waits part of the measurement --
+  // and are copied out when the kernel ends)
+  // The only mutable state, the per-wave record counters, lives in LDS (tlcnt): mutable members would push this whole
+  // object into scratch memory.  A counter at or beyond tl_cap means "not recording".
+  long long *tl; int *tlcnt; int tl_cap, tl_f0, tl_nf;
+  __device__ __forceinline__ void tl_rec() {
+    if ((threadIdx.x & 63) == 0) {
+      const int i = atomicAdd(&tlcnt[threadIdx.x >> 6], 1);
+      if (i < tl_cap) tl[(threadIdx.x >> 6) * tl_cap + i] = (long long)clock64();
+    }
   }
-  __device__ void tick() { if (PROF && tl_on) tl_rec(); }  // extra stamp between barriers
-  __device__ void trace_frame(int t) { tl_on = PROF && tl != nullptr && t >= tl_f0 && t < tl_f0 + tl_nf; }
+  __device__ __forceinline__ void tick() { if (PROF == 2 && tl) tl_rec(); }  // extra stamp between barriers
+  __device__ __forceinline__ void trace_frame(int t) {
+    if (PROF == 2 && tl && (threadIdx.x & 63) == 0) {
+      if (t == tl_f0) tlcnt[threadIdx.x >> 6] = 0;
+      if (t == tl_f0 + tl_nf) tlcnt[threadIdx.x >> 6] = tl_cap;
+    }
+  }
   // a value every thread of the workgroup holds identically -> scalar register (branches/loops on it become scalar)
-  __device__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+  __device__ __forceinline__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   // four consecutive, 16-byte aligned LDS words every thread reads identically: one ds_read_b128
-  __device__ void uni4(const int *p, int *out) const {
+  __device__ __forceinline__ void uni4(const int *p, int *out) const {
     const int4 v = *reinterpret_cast<const int4 *>(p);
     out[0] = __builtin_amdgcn_readfirstlane(v.x); out[1] = __builtin_amdgcn_readfirstlane(v.y);
     out[2] = __builtin_amdgcn_readfirstlane(v.z); out[3] = __builtin_amdgcn_readfirstlane(v.w);
   }
-  __device__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-  __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
-  __device__ void atomic_max(int *p, int v) { atomicMax(p, v); }
+  __device__ __forceinline__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+  __device__ __forceinline__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+  __device__ __forceinline__ void atomic_max(int *p, int v) { atomicMax(p, v); }
   // a "group" = one wave: work items that the 64 lanes search / paint together
-  __device__ int group() const { return __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); }
-  __device__ int ngroups() const { return ((int)blockDim.x + 63) >> 6; }
-  __device__ int lane() const { return (int)threadIdx.x & 63; }
-  __device__ int lanes() const { return 64; }
-  __device__ unsigned long long ballot(bool p) const { return __ballot(p); }
+  __device__ __forceinline__ int group() const { return __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); }
+  __device__ __forceinline__ int ngroups() const { return ((int)blockDim.x + 63) >> 6; }
+  __device__ __forceinline__ int lane() const { return (int)threadIdx.x & 63; }
+  __device__ __forceinline__ int lanes() const { return 64; }
+  __device__ __forceinline__ unsigned long long ballot(bool p) const { return __ballot(p); }
   // first q in [from, n) with arr[q] < bound (n if none); arguments uniform across the wave
-  __device__ int first_below(const int *arr, int from, int n, int bound) const {
+  __device__ __forceinline__ int first_below(const int *arr, int from, int n, int bound) const {
     for (int base = from; base < n; base += 64) {
       const int q = base + ((int)threadIdx.x & 63);
       const unsigned long long m = __ballot(q < n && arr[q] < bound);
@@ -129,14 +142,14 @@ struct DevX {
     }
     return n;
   }
-  __device__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+  __device__ __forceinline__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
   // one LDS atomic per wave
-  __device__ void wave_add(int *p, int v) {
+  __device__ __forceinline__ void wave_add(int *p, int v) {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
   }
 
-  __device__ void wave_max_to(int *p, uint32_t v) {
+  __device__ __forceinline__ void wave_max_to(int *p, uint32_t v) {
     v = wave_max_u32(v);
     if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
   }
@@ -144,7 +157,7 @@ struct DevX {
   // bit s of bitmap = pred(s), for every slot s in [0, S): each wave owns a contiguous range of slots (the same mapping
   // as compact_slots), so one ballot is one 64-bit word of the bitmap.  pred may have side effects (list appends).
   template <class Pred>
-  __device__ void mark_slots(int S, uint32_t *bitmap, Pred pred) {
+  __device__ __forceinline__ void mark_slots(int S, uint32_t *bitmap, Pred pred) {
     const int lane = (int)threadIdx.x & 63, nw = ((int)blockDim.x + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
@@ -173,7 +186,7 @@ struct DevX {
     }
   }
   // out[r] = s for the r-th set bit s of the bitmap (ascending); one wave, the others wait at the closing barrier.
-  __device__ void expand_bitmap(const uint32_t *bitmap, int nwords64, int *out) {
+  __device__ __forceinline__ void expand_bitmap(const uint32_t *bitmap, int nwords64, int *out) {
     if (threadIdx.x < 64) {
       const int lane = (int)threadIdx.x;
       int running = 0;
@@ -199,7 +212,7 @@ struct DevX {
   // (survivors in lower waves) + (survivors in this wave's earlier rounds) + (set ballot bits below the lane):
   // no atomics, no sorting.  Starts and ends with a barrier-consistent state (caller synced before; syncs after).
   template <class Pred>
-  __device__ void compact_slots(int S, int *out, Pred pred) {
+  __device__ __forceinline__ void compact_slots(int S, int *out, Pred pred) {
     const int lane = (int)threadIdx.x & 63, nw = ((int)blockDim.x + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
@@ -258,7 +271,7 @@ struct DevX {
   // bucket holding the need-th largest key: a suffix scan over the 64 coarse buckets (one per lane) picks the group,
   // a 16-lane suffix scan inside it picks the bucket.  Everyone gets out[0..3] = {bucket or -1, #keys above it, #keys
   // total, #keys in it} after the closing barrier.
-  __device__ void find_bucket(const int *bins, int need, int *out) {
+  __device__ __forceinline__ void find_bucket(const int *bins, int need, int *out) {
     if (threadIdx.x < 64) {
       const int lane = (int)threadIdx.x;
       const int c = 63 - lane;  // lane 0 owns the TOP coarse bucket: a prefix scan over lanes is a suffix sum over buckets
@@ -283,7 +296,7 @@ struct DevX {
   }
 
   // In-place exclusive prefix sum of a[0, n) in LDS; returns the total.  Each thread owns a contiguous chunk.
-  __device__ uint32_t scan_excl(uint32_t *a, int n) {
+  __device__ __forceinline__ uint32_t scan_excl(uint32_t *a, int n) {
     const int nthreads = (int)blockDim.x, t = (int)threadIdx.x;
     const int chunk = ctcbeam::ceil_div_p2(n, nthreads) | 1;  // odd stride: no LDS bank conflicts across lanes
     const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
@@ -312,7 +325,7 @@ struct DevX {
   }
 };
 
-constexpr int kTimelineCap = 1024;  // barrier timeline entries per wave
+constexpr int kTimelineCap = 128;  // barrier timeline entries per wave (16 KB of LDS in the profiling build)
 
 struct KernelArgs {
   const float *probs;       // [B, T, V] log-probabilities
@@ -352,7 +365,7 @@ __host__ __device__ constexpr Dims fixed_layout_dims() { return Dims{kFixedK, kF
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
 
 // PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
-template <bool PROF, bool BIG, int LAYOUT, bool PRUNED>
+template <int PROF, bool BIG, int LAYOUT, bool PRUNED>
 __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -363,13 +376,18 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   if (LAYOUT == 1) carve<false>(w, smem, nullptr, fixed_layout_dims(), nullptr);
   else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
   __shared__ long long prof[16];
-  if (PROF && threadIdx.x < 16) prof[threadIdx.x] = 0;
-  DevX<PROF, BIG> x{red, 0, prof, 0, (PROF && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
-                    (PROF && b == 0) ? a.tl : nullptr, a.tl_cap, a.tl_f0, a.tl_nf, 0, 0};
+  __shared__ long long tlbuf[PROF == 2 ? 16 * kTimelineCap : 1];
+  __shared__ int tlcnt[16];
+  if (PROF == 2 && threadIdx.x < 16) tlcnt[threadIdx.x] = kTimelineCap;
+  if (PROF == 2 && a.tl && b == 0)
+    for (int i = threadIdx.x; i < 16 * kTimelineCap; i += blockDim.x) tlbuf[i] = 0;
+  if (PROF == 1 && threadIdx.x < 16) prof[threadIdx.x] = 0;
+  DevX<PROF, BIG> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
+                    (PROF == 2 && b == 0 && a.tl) ? tlbuf : nullptr, tlcnt, kTimelineCap, a.tl_f0, a.tl_nf};
   int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();
-  if (PROF) x.last = (long long)wall_clock64();
+  if (PROF == 1) x.last = (long long)wall_clock64();
   PrunedRows prow;
   if (PRUNED) {
     prow.cnt = a.pr_cnt + (size_t)b * a.T;
@@ -397,7 +415,11 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
                                   a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr,
                                   a.st_base ? &ss : (const StreamState *)nullptr);
   if (threadIdx.x == 0) a.status[b] = st;
-  if (PROF && threadIdx.x < 16) a.prof[(size_t)b * 16 + threadIdx.x] = prof[threadIdx.x];
+  if (PROF == 2 && a.tl && b == 0) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * kTimelineCap; i += blockDim.x) a.tl[i] = tlbuf[i];
+  }
+  if (PROF == 1 && threadIdx.x < 16) a.prof[(size_t)b * 16 + threadIdx.x] = prof[threadIdx.x];
 }
 
 // prob -> log-prob exactly as decoder_utils.cpp:42 : float(log(double(p) + FLT_MIN)).  The device log() is within
@@ -1072,7 +1094,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, true, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, true, 0, false>)    \
        : fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, false, 1, true> : (const void *)ctc_beam_decode_kernel<PROF_, false, 1, false>) \
                : (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, false, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, false, 0, false>))
-  fn = d->profile ? CTC_PICK(true) : CTC_PICK(false);
+  fn = d->profile ? CTC_PICK(1) : CTC_PICK(0);
+  if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes only
+    if (big || !fixed || pruned_mode) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels, no pruning");
+    fn = (const void *)ctc_beam_decode_kernel<2, false, 1, false>;
+  }
 #undef CTC_PICK
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));

@@ -9,11 +9,14 @@ dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=V, b
 _native.check(_native.lib.ctcd_debug_set_profile(dec._handle, 1))
 NF=6; REC=int(sys.argv[1]) if len(sys.argv)>1 else 20
 _native.check(_native.lib.ctcd_debug_timeline(dec._handle, 500, NF, None))
+dec.set_timing(True)
 dec.decode_device(lp); torch.cuda.synchronize()
+dec.decode_device(lp); torch.cuda.synchronize()
+print('timeline build kernel ms', dec.last_kernel_ms())
 cap=_native.lib.ctcd_debug_timeline_cap()
 buf=np.zeros((16,cap),np.int64)
 _native.check(_native.lib.ctcd_debug_timeline(dec._handle,0,0,buf.ctypes.data_as(ctypes.c_void_p)))
-n=int((buf[0]!=0).sum()); print("records per wave", n, "per frame", n/NF)
+n=int((buf[0]!=0).sum()); print('clocks first->last record', buf[0,n-1]-buf[0,0]); print("records per wave", n, "per frame", n/NF)
 t=buf[:, :n].astype(np.float64)
 d=np.diff(t,axis=1)   # [16, n-1]
 per=n//NF
