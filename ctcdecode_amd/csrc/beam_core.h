@@ -598,23 +598,30 @@ struct Decoder {
     x.tick();
     {
       const int grp = x.group(), ngr = x.ngroups();
-      const int mine = grp < n ? ceil_div_p2(n - grp, ngr) : 0;  // entries grp, grp + ngr, ... belong to this group
-      for (int k0 = 0; k0 < mine; k0 += x.lanes()) {
+      // Entry j = row * ngr + column; in row r this group takes column (grp - r) mod ngr.  (A plain "column = grp"
+      // split is badly unbalanced: interior entries tend to come with a fixed number of leaf children each, so they
+      // sit at a fixed residue of j and would all land on the same few groups.)
+      const int rows = ceil_div_p2(n, ngr);
+      const bool p2 = (ngr & (ngr - 1)) == 0;
+      auto entry_of = [=](int r) { const int c = grp - r; return r * ngr + (p2 ? (c & (ngr - 1)) : ((c % ngr) + ngr) % ngr); };
+      for (int k0 = 0; k0 < rows; k0 += x.lanes()) {
         // leaves (the next entry is not a descendant) are settled one per lane; only entries with in-beam
         // descendants need the wave-wide search and the painting
         const int k = k0 + x.lane();
-        const int j = grp + k * ngr;
+        const int j = entry_of(k);
         bool internal = false;
-        if (k < mine) {
-          internal = j + 1 < n && b.lcp[j + 1] >= b.dep[j];
+        int dj = 0;
+        if (k < rows && j < n) {
+          dj = b.dep[j];
+          internal = j + 1 < n && b.lcp[j + 1] >= dj;
           if (!internal) w.e[j] = j + 1;
         }
         unsigned long long todo = x.ballot(internal);
         while (todo) {
           const int kk = __builtin_ctzll(todo);
           todo &= todo - 1;
-          const int jj = grp + (k0 + kk) * ngr;
-          const int q = x.first_below(b.lcp, jj + 2, n, x.uni(b.dep[jj]));
+          const int jj = entry_of(k0 + kk);
+          const int q = x.first_below(b.lcp, jj + 2, n, x.pick(dj, kk));  // the entry's depth sits in lane kk
           if (x.lane() == 0) w.e[jj] = q;
           for (int c = jj + 1 + x.lane(); c < q; c += x.lanes()) {
             x.atomic_max(&w.anc[c], jj);

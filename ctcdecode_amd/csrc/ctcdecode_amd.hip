@@ -125,6 +125,8 @@ struct DevX {
     out[2] = __builtin_amdgcn_readfirstlane(v.z); out[3] = __builtin_amdgcn_readfirstlane(v.w);
   }
   __device__ __forceinline__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+  // the value lane `idx` holds (idx uniform)
+  __device__ __forceinline__ int pick(int v, int idx) const { return __builtin_amdgcn_readlane(v, idx); }
   __device__ __forceinline__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ __forceinline__ void atomic_max(int *p, int v) { atomicMax(p, v); }
   // a "group" = one wave: work items that the 64 lanes search / paint together

@@ -35,6 +35,7 @@ struct HostX {
   }
   void atomic_max(int *p, int v) { *p = std::max(*p, v); }
   float unif(float v) const { return v; }
+  int pick(int v, int) const { return v; }  // the value lane `idx` holds (one lane here)
   void mark(int) {}
   void trace_frame(int) {}
   void tick() {}
