@@ -370,9 +370,8 @@ struct Decoder {
   // records, one bit per slot, every key ABOVE the bucket; the ranking threads add the bucket's own survivors; the
   // caller then only expands that bitmap (in slot = DFS order).  Returns true when the bitmap is complete (the caller
   // must still discard it if several candidates tie on the K-th SCORE).  Precondition: pv[P_LCOUNT] == 0.
-  CTC_HD bool select_kth(int S, int K, int *pv) {
+  CTC_HD bool select_kth(int S, int K, int *pv, const Window &wd) {
     const int tid = x.tid(), nt = x.nt();
-    const Window wd = first_window();
     uint64_t lo = wd.lo, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
     int shift = wd.shift;
     int need = K, gbase = 0;
@@ -583,7 +582,6 @@ struct Decoder {
     const int Vc = in.Vc, brank = in.blank_rank;
     const int Vnb = Vc - (brank >= 0 ? 1 : 0);
     const int S = n * (2 + Vnb);
-    const float lp_blank = brank >= 0 ? x.unif(w.clp[brank]) : CTC_NEG_MAX;
     const bool small_vocab = Vnb <= 64;  // existing children fit a 64-bit mask per parent
     int *pv = pvars(in.t);
     int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
@@ -664,7 +662,7 @@ struct Decoder {
       w.revr[j] = rr;
       npin += pr >= 0;
     }
-    x.wave_add(&pv[P_NPIN], npin);
+    if (x.group() * x.lanes() < n) x.wave_add(&pv[P_NPIN], npin);  // (the other waves had no entry: skip the reduction)
     x.sync();
     x.mark(0);
 
@@ -674,6 +672,7 @@ struct Decoder {
     const int n1 = (n + 63) & ~63;
     const bool split = nt - n1 >= 128;
     if (!split || tid < n1) {
+      const float lp_blank = brank >= 0 ? w.clp[brank] : CTC_NEG_MAX;
       for (int j = tid; j < n; j += (split ? n1 : nt)) {
         const int c = b.ch[j];
         const int r = rank_of_char(in, c);
@@ -782,7 +781,7 @@ struct Decoder {
     uint32_t tau = 0, tauc = 0;
     bool exact = false, have_bitmap = false;
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
-      have_bitmap = select_kth(S, K, pv);
+      have_bitmap = select_kth(S, K, pv, wd);
       int tv[4];
       x.uni4(&w.vars[VAR_TAU], tv);
       tau = (uint32_t)tv[0];
@@ -839,11 +838,13 @@ struct Decoder {
     // Three independent parts per survivor -- its LCP with the previous survivor, its structural fields (+ the pool
     // append), its probabilities -- go to three different sets of waves when the workgroup has them.
     uint32_t kloc = 0;
+    bool r_prob_any = true;
     {
       const int ne = (n_new + 63) & ~63;
       const bool roles = nt >= 3 * ne;
       const int role = roles ? (tid >= ne) + (tid >= 2 * ne) + (tid >= 3 * ne) : -1;  // 3 = no part
       const bool r_lcp = role <= 0, r_struct = role < 0 || role == 1, r_prob = role < 0 || role == 2;
+      r_prob_any = r_prob;
       // Per-frame resets for the next step, on the threads that have no part in the emission (all of them otherwise):
       // the select histogram, the existing-children masks (last read in phase B), the paint buffers and counters of
       // the other parity.
@@ -913,7 +914,7 @@ struct Decoder {
         if (r_prob) kloc = w.skey[s] > kloc ? w.skey[s] : kloc;
       }
     }
-    x.wave_max_to(&pv[P_NMAXKEY], kloc);
+    if (x.uni((int)r_prob_any)) x.wave_max_to(&pv[P_NMAXKEY], kloc);  // only the waves that handled probabilities
     if (last) {  // the order std::nth_element left the survivors in (identity when it was not called)
       for (int q = tid; q < n_new; q += nt) w.fin[q] = exact ? rk[q] : q;
     }
