@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Per-wave barrier timeline of a few frames of one utterance (instrumented kernel build): when every wave arrives at
-and leaves each workgroup barrier, in shader clocks.  Shows, per barrier interval, how long the slowest wave worked and
-which wave it was -- the critical path of a frame.
+"""Per-wave timeline of a few frames of one utterance (timeline build of the kernel, ctcd_debug_timeline): the shader
+clock every wave stamps when it arrives at / leaves each workgroup barrier and at a few extra points of a frame.
+Prints, per stamp, the clocks until the next stamp for every wave (averaged over the recorded frames): the rows between
+a "leave" and the next "arrive" are work, the rows between an "arrive" and its "leave" are waiting for the slowest wave.
 
-    python tools/barrier_timeline.py [--frame0 500 --frames 4 --threads 0] [--out profiles/x_timeline.json]
+    python tools/barrier_timeline.py [--frame0 500 --frames 6 --threads 0] [--out profiles/x_timeline.json]
 """
 import argparse
 import ctypes
@@ -12,6 +13,13 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+# stamps of one frame on the common path (beam_core.h: x.tick() calls and the barriers of step())
+LABELS = ["loop top (row prefetch issued) -> step prologue", "A1 subtree ends + painting", "(tick -> barrier)", "wait: A1 barrier",
+          "A2 slot offsets, existing children", "wait: A2 barrier", "B score candidates + histogram", "wait: B barrier",
+          "C1 find bucket (wave 0)", "wait: C1 barrier", "C2 list bucket + survivor bitmap", "wait: C2 barrier",
+          "C3 rank in bucket (wave 0)", "wait: C3 barrier", "D expand bitmap (wave 0)", "wait: D barrier",
+          "E emit next beam (+ resets on idle waves)", "wait: end-of-frame barrier", "state update", "loop back-edge"]
 
 
 def main():
@@ -22,7 +30,7 @@ def main():
     ap.add_argument("--beam", type=int, default=100)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--frame0", type=int, default=500)
-    ap.add_argument("--frames", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=6)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import numpy as np
@@ -36,44 +44,43 @@ def main():
     dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(a.V)], cutoff_top_n=a.V, beam_width=a.beam, log_probs_input=True)
     if a.threads:
         dec.set_threads(a.threads)
+    dec.set_timing(True)
     _native.check(_native.lib.ctcd_debug_set_profile(dec._handle, 1))
     _native.check(_native.lib.ctcd_debug_timeline(dec._handle, a.frame0, a.frames, None))
     dec.decode_device(lp)
     torch.cuda.synchronize()
+    dec.decode_device(lp)
+    torch.cuda.synchronize()
+    kernel_ms = dec.last_kernel_ms()
     cap = _native.lib.ctcd_debug_timeline_cap()
     buf = np.zeros((16, cap), np.int64)
     _native.check(_native.lib.ctcd_debug_timeline(dec._handle, 0, 0, buf.ctypes.data_as(ctypes.c_void_p)))
     nw = int((buf[:, 0] != 0).sum())
     n = int((buf[0] != 0).sum())
+    per = n // a.frames
     t = buf[:nw, :n].astype(np.float64)
-    arrive, leave = t[:, 0::2], t[:, 1::2]
-    nb = min(arrive.shape[1], leave.shape[1])
-    arrive, leave = arrive[:, :nb], leave[:, :nb]
-    per_frame = nb // a.frames
+    d = np.diff(t, axis=1)
+    acc = np.zeros((nw, per))
+    cnt = 0
+    for f in range(1, a.frames - 1):  # whole frames only
+        acc += d[:, f * per:(f + 1) * per]
+        cnt += 1
+    acc /= max(cnt, 1)
+    clocks_per_frame = float((t[0, (a.frames - 1) * per] - t[0, per]) / max(a.frames - 2, 1))
+    print("timeline build: kernel %.3f ms; %d waves, %d stamps per frame, %.0f clocks per frame (%.2f GHz if every frame takes kernel/T)"
+          % (kernel_ms, nw, per, clocks_per_frame, clocks_per_frame / (kernel_ms * 1e3 / a.T) / 1e3))
+    overhead = float(acc[:, 2].mean()) if per == len(LABELS) else 0.0
+    print("one stamp costs about %.0f clocks (row 2 has nothing else in it)" % overhead)
     rows = []
-    # interval i: from the release of barrier i-1 (max over waves of `leave`) to the last arrival at barrier i
-    for i in range(1, nb):
-        start = leave[:, i - 1].min()
-        work = arrive[:, i] - leave[:, i - 1]          # per wave: time between leaving the previous barrier and arriving here
-        rows.append({"barrier": i, "in_frame": i % per_frame if per_frame else i, "span": float(arrive[:, i].max() - start),
-                     "slowest_wave": int(work.argmax()), "slowest_work": float(work.max()), "median_work": float(np.median(work)),
-                     "barrier_latency": float(leave[:, i].min() - arrive[:, i].max()), "work_per_wave": [float(x) for x in work]})
-    total = float(arrive[:, nb - 1].max() - leave[:, 0].min())
-    res = {"waves": nw, "barriers_recorded": nb, "barriers_per_frame": per_frame, "frames": a.frames, "clocks_total": total,
-           "clocks_per_frame": total / max(1, a.frames - 1.0 / max(per_frame, 1)), "intervals": rows}
-    print("waves %d, %d barriers (%d per frame); %.0f clocks per frame" % (nw, nb, per_frame, res["clocks_per_frame"]))
-    # average the intervals with the same position in the frame
-    if per_frame:
-        print("%-4s %8s %8s %8s %8s  %s" % ("pos", "span", "slowest", "median", "barrier", "slowest wave (per frame)"))
-        for pos in range(per_frame):
-            sel = [r for r in rows if r["in_frame"] == pos]
-            if not sel:
-                continue
-            print("%-4d %8.0f %8.0f %8.0f %8.0f  %s" % (pos, np.mean([r["span"] for r in sel]), np.mean([r["slowest_work"] for r in sel]),
-                                                   np.mean([r["median_work"] for r in sel]), np.mean([r["barrier_latency"] for r in sel]),
-                                                   [r["slowest_wave"] for r in sel]))
+    for i in range(per):
+        lab = LABELS[i] if per == len(LABELS) else "stamp %d" % i
+        rows.append({"stamp": i, "what": lab, "max": float(acc[:, i].max()), "median": float(np.median(acc[:, i])), "min": float(acc[:, i].min()),
+                     "per_wave": [float(v) for v in acc[:, i]]})
+        print("%2d %-52s max %5.0f  med %5.0f  min %5.0f | %s" % (i, lab[:52], acc[:, i].max(), np.median(acc[:, i]), acc[:, i].min(),
+                                                                 " ".join("%4.0f" % v for v in acc[:, i])))
     if a.out:
-        json.dump(res, open(a.out, "w"))
+        json.dump({"kernel_ms_timeline_build": kernel_ms, "waves": nw, "stamps_per_frame": per, "clocks_per_frame": clocks_per_frame,
+                   "stamp_overhead_clocks": overhead, "frames_averaged": cnt, "frame0": a.frame0, "rows": rows}, open(a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":
