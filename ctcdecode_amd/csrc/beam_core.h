@@ -370,22 +370,76 @@ struct Decoder {
   // records, one bit per slot, every key ABOVE the bucket; the ranking threads add the bucket's own survivors; the
   // caller then only expands that bitmap (in slot = DFS order).  Returns true when the bitmap is complete (the caller
   // must still discard it if several candidates tie on the K-th SCORE).  Precondition: pv[P_LCOUNT] == 0.
+  // The keys of one histogram bucket [b32, b32 + bspan] are listed and ranked exactly: leaves tau = the `want`-th largest
+  // of them (VAR_TAU), G = gsum + #bucket keys above tau, E = #keys equal to tau.  `direct` (first round only): the
+  // listing pass also records, one bit per slot, every key ABOVE the bucket, and the ranking threads add the bucket's
+  // own survivors, so the caller only has to expand the bitmap.  inb = #keys in the bucket (<= kListCap).
+  CTC_HD void rank_bucket(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb) {
+    const int tid = x.tid(), nt = x.nt();
+    {
+      const uint32_t *skey = w.skey;
+      uint32_t *list = w.list;
+      int *lslot = w.lslot, *lcount = &pv[P_LCOUNT];
+      X &xx = x;
+      // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
+      x.mark_slots(S, w.bitmap, [=, &xx](int s) -> bool {
+        const uint32_t k = skey[s];
+        if (k < b32) return false;
+        const uint32_t dk = k - b32;
+        if (dk > bspan) return direct;
+        const int li = xx.atomic_add(lcount, 1);
+        list[li] = dk + 1u;
+        lslot[li] = s;
+        return false;
+      });
+    }
+    for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
+    x.sync();
+    x.mark(14);
+    for (int q = tid; q < inb; q += nt) {
+      const uint32_t mine = w.list[q];
+      int g = 0, e = 0;
+      for (int r = 0; r < inb; r += 4) {
+        const uint32_t o0 = w.list[r], o1 = w.list[r + 1], o2 = w.list[r + 2], o3 = w.list[r + 3];
+        g += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
+        e += (o0 == mine) + (o1 == mine) + (o2 == mine) + (o3 == mine);
+      }
+      if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
+        w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gsum + g; w.vars[VAR_E] = e;
+      }
+      if (direct && g < want) {  // key >= tau: survives (unless equal scores straddle the boundary -- caller's business)
+        const int sl = w.lslot[q];
+        x.atomic_or(&w.bitmap[sl >> 5], 1u << (sl & 31));
+      }
+    }
+    x.sync();
+  }
+
   CTC_HD bool select_kth(int S, int K, int *pv, const Window &wd) {
     const int tid = x.tid(), nt = x.nt();
+    // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
+    //    [2] #keys in the window, [3] #keys in b*.  Two-level: the coarse buckets locate the group of 16 fine ones.
+    //    Ends with a barrier.  The histogram is cleared before another round; after the last one step() clears it
+    //    (with the other per-frame resets, on waves that are idle while the next beam is emitted).
+    x.find_bucket(w.bins, K, &w.vars[VAR_FB0]);
+    int fb[4];
+    x.uni4(&w.vars[VAR_FB0], fb);
+    x.mark(13);
+    // The usual outcome: the first histogram isolates a bucket with a handful of keys, several values wide.  Everything
+    // about it fits 32-bit arithmetic (the window's top is the previous best key, below 2^32).
+    if (fb[0] >= 0 && fb[3] <= kListCap && (wd.shift != 0 || fb[0] == kBins - 1)) {
+      const uint32_t b32 = wd.lo + ((uint32_t)fb[0] << wd.shift);
+      const uint32_t bspan = fb[0] == kBins - 1 ? 0xFFFFFFFFu - b32 : (1u << wd.shift) - 1u;
+      rank_bucket(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3]);
+      return true;
+    }
+    // Rare: the K-th key lies below the window, the bucket is crowded, or it is a single key value.
     uint64_t lo = wd.lo, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
     int shift = wd.shift;
     int need = K, gbase = 0;
     bool first = true;
     for (;;) {
-      // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
-      //    [2] #keys in the window, [3] #keys in b*.  Two-level: the coarse buckets locate the group of 16 fine ones.
-      //    Ends with a barrier.  The histogram is cleared before another round; after the last one step() clears it
-      //    (with the other per-frame resets, on waves that are idle while the next beam is emitted).
-      x.find_bucket(w.bins, need, &w.vars[VAR_FB0]);
-      int fb[4];
-      x.uni4(&w.vars[VAR_FB0], fb);
       const int bstar = fb[0], above = fb[1], total = fb[2], inb = fb[3];
-      x.mark(13);
       uint64_t blo = 0, bhi = 0;
       bool again = true;
       if (bstar < 0) {  // the K-th key lies below the window: look at everything under it
@@ -403,47 +457,8 @@ struct Decoder {
         else { gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
       }
       if (!again) {  // exact rank inside the bucket, on offsets from its base
-        const uint32_t b32 = (uint32_t)blo, bspan = (uint32_t)(bhi - blo - 1);
-        const bool direct = first;
-        {
-          const uint32_t *skey = w.skey;
-          uint32_t *list = w.list;
-          int *lslot = w.lslot, *lcount = &pv[P_LCOUNT];
-          X &xx = x;
-          // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
-          x.mark_slots(S, w.bitmap, [=, &xx](int s) -> bool {
-            const uint32_t k = skey[s];
-            if (k < b32) return false;
-            const uint32_t dk = k - b32;
-            if (dk > bspan) return direct;
-            const int li = xx.atomic_add(lcount, 1);
-            list[li] = dk + 1u;
-            lslot[li] = s;
-            return false;
-          });
-        }
-        for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
-        x.sync();
-        x.mark(14);
-        const int want = need - above;  // rank (1-based, descending) of tau inside the bucket
-        for (int q = tid; q < inb; q += nt) {
-          const uint32_t mine = w.list[q];
-          int g = 0, e = 0;
-          for (int r = 0; r < inb; r += 4) {
-            const uint32_t o0 = w.list[r], o1 = w.list[r + 1], o2 = w.list[r + 2], o3 = w.list[r + 3];
-            g += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
-            e += (o0 == mine) + (o1 == mine) + (o2 == mine) + (o3 == mine);
-          }
-          if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
-            w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gbase + above + g; w.vars[VAR_E] = e;
-          }
-          if (direct && g < want) {  // key >= tau: survives (unless equal scores straddle the boundary -- caller's business)
-            const int sl = w.lslot[q];
-            x.atomic_or(&w.bitmap[sl >> 5], 1u << (sl & 31));
-          }
-        }
-        x.sync();
-        return direct;
+        rank_bucket(S, pv, (uint32_t)blo, (uint32_t)(bhi - blo - 1), first, need - above, gbase + above, inb);
+        return first;
       }
       // another histogram round over [lo, hi)
       first = false;
@@ -462,6 +477,8 @@ struct Decoder {
         }
       }
       x.sync();
+      x.find_bucket(w.bins, need, &w.vars[VAR_FB0]);
+      x.uni4(&w.vars[VAR_FB0], fb);
     }
   }
 
