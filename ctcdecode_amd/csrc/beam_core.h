@@ -214,6 +214,16 @@ CTC_HD int ceil_log2_u64(uint64_t v) {  // smallest s with (1 << s) >= v, v >= 1
   return v <= 1 ? 0 : 64 - __builtin_clzll(v - 1);
 }
 
+// Where the results of a batch go (binding.cpp:79-99): read only once per utterance, at the very end -- handed over by
+// address so that the six values need not stay in registers through the frame loop (X::fresh re-reads them there).
+struct OutRefs {
+  int32_t *tok, *ts;     // [B][K][T_stride]
+  float *score;          // [B][K]
+  int32_t *len;          // [B][K]
+  int32_t *n_results;    // [B] or null
+  int K, T_stride;
+};
+
 // IDENT: the utterance is decoded without vocabulary pruning (candidate r of every frame is label r).  A compile-time
 // switch: the two modes keep different things in flight across a frame (next row vs. next candidate list), and mixing
 // them in one instantiation makes the compiler wait for the prefetch where the other mode's registers are written.
@@ -1025,8 +1035,14 @@ struct Decoder {
   // DecoderState::decode() + get_beam_search_result + binding.cpp:85-99 for one utterance.
   // `had_steps`: false when the utterance has no frames (fin is then just the root); `max_depth`: bound on the length
   // of a label sequence (the number of frames fed).
-  CTC_HD void finish(bool had_steps, int max_depth, int T_stride, int32_t *out_tok, int32_t *out_ts, float *out_score, int32_t *out_len,
-                     int32_t *n_results) {
+  CTC_HD void finish(bool had_steps, int max_depth, const OutRefs *outs, int item) {
+    const OutRefs o = *x.fresh(outs);
+    const int T_stride = o.T_stride;
+    const size_t ko = (size_t)o.K * (size_t)o.T_stride;
+    int32_t *out_tok = o.tok + (size_t)item * ko, *out_ts = o.ts + (size_t)item * ko;
+    float *out_score = o.score + (size_t)item * o.K;
+    int32_t *out_len = o.len + (size_t)item * o.K;
+    int32_t *n_results = o.n_results ? o.n_results + item : nullptr;
     select_beams();
     const Beam &b = w.cur;
     const int tid = x.tid(), nt = x.nt();
@@ -1143,8 +1159,7 @@ struct PrunedRows {
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
 template <bool IDENT, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
-                            PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, int T_stride, int32_t *out_tok,
-                            int32_t *out_ts, float *out_score, int32_t *out_len, int32_t *n_results,
+                            PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr) {
   Decoder<X, IDENT> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
@@ -1213,7 +1228,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     if (st != ST_OK) return st;
   }
   if (ss) dec.save_state(*ss, t0 + len);
-  if (!ss || ss->finish) dec.finish(t0 + len > 0, t0 + len, T_stride, out_tok, out_ts, out_score, out_len, n_results);
+  if (!ss || ss->finish) dec.finish(t0 + len > 0, t0 + len, outs, item);
   x.sync();
   x.mark(11);
   return ST_OK;

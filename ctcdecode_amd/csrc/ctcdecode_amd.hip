@@ -125,6 +125,12 @@ struct DevX {
     out[2] = __builtin_amdgcn_readfirstlane(v.z); out[3] = __builtin_amdgcn_readfirstlane(v.w);
   }
   __device__ __forceinline__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+  // a pointer the compiler must treat as new: what it points to is (re)loaded after this point, not kept live before it
+  template <class P>
+  __device__ __forceinline__ const P *fresh(const P *p) const {
+    asm volatile("" : "+s"(p));
+    return p;
+  }
   // the value lane `idx` holds (idx uniform)
   __device__ __forceinline__ int pick(int v, int idx) const { return __builtin_amdgcn_readlane(v, idx); }
   __device__ __forceinline__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
@@ -338,8 +344,7 @@ struct KernelArgs {
   int *pool_up;             // [B, pool_stride] express pointers (beam_core.h kExpress)
   long long pool_stride;
   const uint64_t *tables;   // 64 words (exact_math.h)
-  int32_t *out_tok, *out_ts, *out_len, *n_results;
-  float *out_score;
+  OutRefs outs;             // result tensors; read through the kernel-argument segment at the end of an utterance
   int32_t *status;          // [B]
   long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
   int *dbg;                 // profiling build: beam of item 0 after every frame, [T][1 + 4K] (or null)
@@ -352,7 +357,6 @@ struct KernelArgs {
   const int *st_poolcap;    // [B] nodes the pool of each stream can hold
   const unsigned char *st_eos;  // [B] 1: this call ends the stream (run decode())
   long long st_pool_off;    // byte offset of the node pool inside a stream block
-  int out_T;                // row stride of out_tok / out_ts (== T for the one-shot call)
   const int *pr_cnt;        // pruned mode: [B, T] candidates per frame (null in identity mode)
   const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
   const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
@@ -410,11 +414,14 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
     pool_cap = a.st_poolcap[b];
     pool_up = (int *)(pool + pool_cap);
   }
-  const size_t ko = (size_t)a.K * a.out_T;
+  // the result pointers stay in the kernel-argument segment until the utterance ends (finish() reads them from there)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const OutRefs *outs = (const OutRefs *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernelArgs, outs));
+#else
+  const OutRefs *outs = &a.outs;
+#endif
   const int st = decode_utterance<!PRUNED>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
-                                  PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, a.out_T,
-                                  a.out_tok + (size_t)b * ko, a.out_ts + (size_t)b * ko, a.out_score + (size_t)b * a.K,
-                                  a.out_len + (size_t)b * a.K, a.n_results ? a.n_results + b : nullptr,
+                                  PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr);
   if (threadIdx.x == 0) a.status[b] = st;
   if (PROF == 2 && a.tl && b == 0) {
@@ -1064,10 +1071,10 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   a.pool = (PoolNode *)d->pool.p; a.pool_stride = pool_stride;
   a.pool_up = (int *)(a.pool + (size_t)B * pool_stride);
   a.tables = (const uint64_t *)d->tables.p;
-  a.out_tok = out_tok; a.out_ts = out_ts; a.out_len = out_len; a.n_results = n_results; a.out_score = out_sc;
+  a.outs.tok = out_tok; a.outs.ts = out_ts; a.outs.len = out_len; a.outs.n_results = n_results; a.outs.score = out_sc;
+  a.outs.K = beam; a.outs.T_stride = out_T;
   a.status = (int32_t *)d->status.p;
   a.st_base = st_base; a.st_poolcap = st_cap; a.st_eos = st_eos; a.st_pool_off = (long long)stream_pool_offset(beam);
-  a.out_T = out_T;
   a.pr_cnt = nullptr; a.pr_ch = nullptr; a.pr_lp = nullptr; a.pr_stride = 0;
   if (dims.use_rank_table) {
     a.pr_cnt = (const int *)d->pr_cnt.p; a.pr_ch = (const int *)d->pr_ch.p; a.pr_lp = (const float *)d->pr_lp.p;

@@ -38,6 +38,7 @@ struct HostX {
   int pick(int v, int) const { return v; }  // the value lane `idx` holds (one lane here)
   void mark(int) {}
   void trace_frame(int) {}
+  template <class P> const P *fresh(const P *p) const { return p; }
   void tick() {}
   void dump(int, int, const int *, const int *, const int *, const float *) {}
   uint32_t scan_excl(uint32_t *a, int n) {
@@ -152,12 +153,11 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
       if (pruned)
         for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
 int st;
+      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T};
       if (pruned) st = decode_utterance<false>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
-                                ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T, out_timesteps + (size_t)b * beam * T,
-                                out_scores + (size_t)b * beam, out_lens + (size_t)b * beam, n_results + b);
+                                ctcmath::host_tables().w, &outs, b);
       else st = decode_utterance<true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
-                                ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T, out_timesteps + (size_t)b * beam * T,
-                                out_scores + (size_t)b * beam, out_lens + (size_t)b * beam, n_results + b);
+                                ctcmath::host_tables().w, &outs, b);
       if (st != ST_OK) bad = st;
     }
   };
@@ -191,10 +191,9 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       carve<false>(w, mem.data(), nullptr, d, nullptr);
       HostX x;
       StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
+      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T};
       int st = decode_utterance<true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
-                                pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, T, out_tokens + (size_t)b * beam * T,
-                                out_timesteps + (size_t)b * beam * T, out_scores + (size_t)b * beam, out_lens + (size_t)b * beam,
-                                n_results + b, &ss);
+                                pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss);
       if (st != ST_OK) return -st;
     }
   }
