@@ -355,14 +355,14 @@ struct Decoder {
   // Window of the first histogram round: [lo, 2^32) in score-key units, buckets of 2^shift keys, top bucket open.
   struct Window { uint32_t lo; int shift; };
   CTC_HD Window first_window() const {
+    // width = 2^st_wlog keys ending at the previous best key (st_wlog is kept in [kBinsLog, 32]); all of it fits 32 bits
     Window wd;
-    uint64_t lo = 1, width = (uint64_t)1 << 32;
+    wd.lo = 1u;
+    wd.shift = st_wlog - kBinsLog;
     if (st_wlog < 32) {
-      width = (uint64_t)1 << st_wlog;
-      if (width <= (uint64_t)st_maxkey) lo = (uint64_t)st_maxkey - width + 1;
+      const uint32_t width = 1u << st_wlog;
+      if (width <= st_maxkey) wd.lo = st_maxkey - width + 1u;
     }
-    wd.lo = (uint32_t)lo;
-    wd.shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
     return wd;
   }
   CTC_HD void hist_add(const Window &wd, uint32_t key) const {  // first-round histogram contribution of one candidate
@@ -692,6 +692,7 @@ struct Decoder {
     if (x.group() * x.lanes() < n) x.wave_add(&pv[P_NPIN], npin);  // (the other waves had no entry: skip the reduction)
     x.sync();
     x.mark(0);
+    const int npin_total = pv[P_NPIN];  // final since the barrier above; requested here so that phase C does not wait for it
 
     // ---- B: score every candidate, lay it out in DFS (Euler-tour) slot order and count it into the select histogram.
     // B1 (beam entries themselves + revived children) and B2 (brand-new children) are independent: with enough
@@ -804,7 +805,7 @@ struct Decoder {
     x.mark(2);
 
     // ---- C: the K-th best key.  #candidates = beam entries + new children - children that already exist as entries
-    const int N = n * (1 + Vnb) - x.uni(pv[P_NPIN]);
+    const int N = n * (1 + Vnb) - x.uni(npin_total);
     uint32_t tau = 0, tauc = 0;
     bool exact = false, have_bitmap = false;
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
