@@ -210,6 +210,9 @@ struct StepIn {
 CTC_HD int div_p2(int v, int d) { return (d & (d - 1)) == 0 ? v >> __builtin_ctz((unsigned)d) : v / d; }
 CTC_HD int ceil_div_p2(int v, int d) { return div_p2(v + d - 1, d); }
 
+CTC_HD int ceil_log2_u32(uint32_t v) {  // smallest s with (1 << s) >= v, v >= 1
+  return v <= 1u ? 0 : 32 - __builtin_clz(v - 1u);
+}
 CTC_HD int ceil_log2_u64(uint64_t v) {  // smallest s with (1 << s) >= v, v >= 1
   return v <= 1 ? 0 : 64 - __builtin_clzll(v - 1);
 }
@@ -749,12 +752,11 @@ struct Decoder {
     x.mark(1);
     if (!split || tid >= n1) {
       const int t2 = split ? tid - n1 : tid, nt2 = split ? nt - n1 : nt;
-      int lp2 = 1;
-      while (lp2 < Vnb) lp2 <<= 1;                   // lanes per parent (power of two >= Vnb)
+      const int sh = ceil_log2_u32((uint32_t)(Vnb > 1 ? Vnb : 1));
+      const int lp2 = 1 << sh;                       // lanes per parent (power of two >= Vnb)
       if (small_vocab && nt2 >= lp2) {               // a group of lp2 lanes per parent, one lane per character
         const int rn = t2 & (lp2 - 1);
-        const int ng = nt2 >> ceil_log2_u64((uint64_t)lp2);  // lp2 is a power of two
-        const int sh = ceil_log2_u64((uint64_t)lp2);
+        const int ng = nt2 >> sh;
         if (rn < Vnb && (t2 >> sh) < ng) {
           const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
           const int c = IDENT ? r : w.cch[r];
@@ -964,7 +966,7 @@ struct Decoder {
       int wl = 32;
       if (N > K) {
         const uint32_t gap = st_maxkey > tau ? st_maxkey - tau : 0;
-        wl = ceil_log2_u64((uint64_t)gap + 1) + 1;
+        wl = (gap ? 32 - __builtin_clz(gap) : 0) + 1;  // = ceil(log2(gap + 1)) + 1
         wl = wl < 10 ? 10 : (wl > 32 ? 32 : wl);
       }
       st_wlog = wl;
