@@ -205,9 +205,10 @@ struct StepIn {
 };
 
 
-// v / d and ceil(v / d) for d > 0 that is almost always a power of two (wave counts, lanes per group): the GPU has no
-// integer divide, a generic run-time division is ~25 instructions on every wave.
-CTC_HD int div_p2(int v, int d) { return (d & (d - 1)) == 0 ? v >> __builtin_ctz((unsigned)d) : v / d; }
+// v / d and ceil(v / d) for a divisor that IS a power of two (wave counts, lanes per group; the workgroup size is
+// restricted to powers of two for this): the GPU has no integer divide, a run-time division costs ~25 instructions on
+// every wave, and a "shift if power of two, else divide" form makes the compiler evaluate both.
+CTC_HD int div_p2(int v, int d) { return v >> __builtin_ctz((unsigned)d); }
 CTC_HD int ceil_div_p2(int v, int d) { return div_p2(v + d - 1, d); }
 
 CTC_HD int ceil_log2_u32(uint32_t v) {  // smallest s with (1 << s) >= v, v >= 1
@@ -630,8 +631,7 @@ struct Decoder {
       // split is badly unbalanced: interior entries tend to come with a fixed number of leaf children each, so they
       // sit at a fixed residue of j and would all land on the same few groups.)
       const int rows = ceil_div_p2(n, ngr);
-      const bool p2 = (ngr & (ngr - 1)) == 0;
-      auto entry_of = [=](int r) { const int c = grp - r; return r * ngr + (p2 ? (c & (ngr - 1)) : ((c % ngr) + ngr) % ngr); };
+      auto entry_of = [=](int r) { return r * ngr + ((grp - r) & (ngr - 1)); };  // ngr is a power of two
       for (int k0 = 0; k0 < rows; k0 += x.lanes()) {
         // leaves (the next entry is not a descendant) are settled one per lane; only entries with in-beam
         // descendants need the wave-wide search and the painting

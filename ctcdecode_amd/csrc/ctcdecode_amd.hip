@@ -892,7 +892,7 @@ void ctcd_destroy(ctcd_decoder *d) {
 }
 
 int ctcd_set_threads(ctcd_decoder *d, int t) {
-  if (!d || t < 0 || t > 1024 || (t & 63)) return fail(CTCD_EINVAL, "threads must be 0 (automatic) or a multiple of 64 in [64, 1024]");
+  if (!d || t < 0 || t > 1024 || (t && (t < 64 || (t & (t - 1))))) return fail(CTCD_EINVAL, "threads must be 0 (automatic) or a power of two in [64, 1024]");
   d->threads = t;
   return CTCD_OK;
 }

@@ -107,7 +107,7 @@ int ctcd_debug_timeline(ctcd_decoder *dec, int frame0, int nframes, long long *o
 int ctcd_debug_beam_dump(ctcd_decoder *dec, int on, int *out, int T, int beam);
 
 /* Tuning / introspection. */
-int ctcd_set_threads(ctcd_decoder *dec, int threads_per_workgroup); /* 0 = automatic (default); else 64..1024, multiple of 64 */
+int ctcd_set_threads(ctcd_decoder *dec, int threads_per_workgroup); /* 0 = automatic (default); else a power of two in [64, 1024] */
 int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob); /* LDS one utterance needs */
 const char *ctcd_last_error(void);
 const char *ctcd_version(void);
