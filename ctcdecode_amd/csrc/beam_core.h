@@ -231,7 +231,9 @@ struct OutRefs {
 // IDENT: the utterance is decoded without vocabulary pruning (candidate r of every frame is label r).  A compile-time
 // switch: the two modes keep different things in flight across a frame (next row vs. next candidate list), and mixing
 // them in one instantiation makes the compiler wait for the prefetch where the other mode's registers are written.
-template <class X, bool IDENT>
+// SMALLV: the caller guarantees at most 64 candidate characters per frame (the fixed workspace layout does): the paths
+// for larger candidate sets are compiled out.
+template <class X, bool IDENT, bool SMALLV = false>
 struct Decoder {
   X &x;
   Work &w;
@@ -613,7 +615,7 @@ struct Decoder {
     const int Vc = in.Vc, brank = in.blank_rank;
     const int Vnb = Vc - (brank >= 0 ? 1 : 0);
     const int S = n * (2 + Vnb);
-    const bool small_vocab = Vnb <= 64;  // existing children fit a 64-bit mask per parent
+    const bool small_vocab = SMALLV || Vnb <= 64;  // existing children fit a 64-bit mask per parent
     int *pv = pvars(in.t);
     int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
     const Window wd = first_window();
@@ -1160,11 +1162,11 @@ struct PrunedRows {
 };
 
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
-template <bool IDENT, class X>
+template <bool IDENT, bool SMALLV = false, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr) {
-  Decoder<X, IDENT> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl);
+  Decoder<X, IDENT, SMALLV> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   if (t0 > 0) dec.load_state(*ss); else dec.init();

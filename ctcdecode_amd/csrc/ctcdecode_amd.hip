@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
 #else
   const OutRefs *outs = &a.outs;
 #endif
-  const int st = decode_utterance<!PRUNED>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
+  const int st = decode_utterance<!PRUNED, LAYOUT == 1>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr);
   if (threadIdx.x == 0) a.status[b] = st;

@@ -152,12 +152,19 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
       PrunedRows pr{pcnt.data(), pch.data(), plp.data(), d.Vc_max};
       if (pruned)
         for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
-int st;
+      int st;
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T};
-      if (pruned) st = decode_utterance<false>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
-                                ctcmath::host_tables().w, &outs, b);
-      else st = decode_utterance<true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
-                                ctcmath::host_tables().w, &outs, b);
+      if (beam <= 128 && V <= 32) {  // the shapes the device runs with its fixed layout
+        if (pruned) st = decode_utterance<false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
+        else st = decode_utterance<true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
+      } else {
+        if (pruned) st = decode_utterance<false>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
+        else st = decode_utterance<true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
+      }
       if (st != ST_OK) bad = st;
     }
   };
