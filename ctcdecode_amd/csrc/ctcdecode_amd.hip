@@ -57,7 +57,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // FAR: part of the workspace lives in HBM (BIG layout): every barrier must then also drain global memory traffic.
 // PROF: 0 = product build; 1 = per-phase timers (mark) and the beam dump; 2 = barrier timeline only (no timers: the
 // timers' mutable state would put this object into scratch memory and distort the timeline).
-template <int PROF, bool FAR>
+// NT: the workgroup size when it is known at compile time (0 = read blockDim): wave counts, the role split of a frame
+// and the slot-to-wave assignment then fold to constants.
+template <int PROF, bool FAR, int NT = 0>
 struct DevX {
   int *red;  // 2 x 16 ints of LDS
   int parity;
@@ -76,13 +78,13 @@ struct DevX {
     if (PROF == 1 && dbg) {
       int *o = dbg + (size_t)t * dbg_stride;
       if (threadIdx.x == 0) o[0] = n;
-      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      for (int i = threadIdx.x; i < n; i += nt()) {
         o[1 + 4 * i] = node[i]; o[2 + 4 * i] = dep[i]; o[3 + 4 * i] = lcp[i]; o[4 + 4 * i] = __float_as_int(score[i]);
       }
     }
   }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
-  __device__ __forceinline__ int nt() const { return (int)blockDim.x; }
+  __device__ __forceinline__ int nt() const { return NT ? NT : (int)blockDim.x; }
   // LDS-only barrier: waits for this wave's LDS traffic, not for outstanding global loads/stores (the row prefetch
   // and the pool appends stay in flight across phases).  sync_full() is the fence that also drains global memory.
   __device__ __forceinline__ void sync() {
@@ -137,7 +139,7 @@ struct DevX {
   __device__ __forceinline__ void atomic_max(int *p, int v) { atomicMax(p, v); }
   // a "group" = one wave: work items that the 64 lanes search / paint together
   __device__ __forceinline__ int group() const { return __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); }
-  __device__ __forceinline__ int ngroups() const { return ((int)blockDim.x + 63) >> 6; }
+  __device__ __forceinline__ int ngroups() const { return (nt() + 63) >> 6; }
   __device__ __forceinline__ int lane() const { return (int)threadIdx.x & 63; }
   __device__ __forceinline__ int lanes() const { return 64; }
   __device__ __forceinline__ unsigned long long ballot(bool p) const { return __ballot(p); }
@@ -166,7 +168,7 @@ struct DevX {
   // as compact_slots), so one ballot is one 64-bit word of the bitmap.  pred may have side effects (list appends).
   template <class Pred>
   __device__ __forceinline__ void mark_slots(int S, uint32_t *bitmap, Pred pred) {
-    const int lane = (int)threadIdx.x & 63, nw = ((int)blockDim.x + 63) >> 6;
+    const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
     const int first = wave * rounds * 64;
@@ -221,7 +223,7 @@ struct DevX {
   // no atomics, no sorting.  Starts and ends with a barrier-consistent state (caller synced before; syncs after).
   template <class Pred>
   __device__ __forceinline__ void compact_slots(int S, int *out, Pred pred) {
-    const int lane = (int)threadIdx.x & 63, nw = ((int)blockDim.x + 63) >> 6;
+    const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
     const int first = wave * rounds * 64;
@@ -305,7 +307,7 @@ struct DevX {
 
   // In-place exclusive prefix sum of a[0, n) in LDS; returns the total.  Each thread owns a contiguous chunk.
   __device__ __forceinline__ uint32_t scan_excl(uint32_t *a, int n) {
-    const int nthreads = (int)blockDim.x, t = (int)threadIdx.x;
+    const int nthreads = nt(), t = (int)threadIdx.x;
     const int chunk = ctcbeam::ceil_div_p2(n, nthreads) | 1;  // odd stride: no LDS bank conflicts across lanes
     const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
     uint32_t sum = 0;
@@ -371,7 +373,7 @@ __host__ __device__ constexpr Dims fixed_layout_dims() { return Dims{kFixedK, kF
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
 
 // PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
-template <int PROF, bool BIG, int LAYOUT, bool PRUNED>
+template <int PROF, bool BIG, int LAYOUT, bool PRUNED, int NT = 0>
 __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   if (PROF == 2 && a.tl && b == 0)
     for (int i = threadIdx.x; i < 16 * kTimelineCap; i += blockDim.x) tlbuf[i] = 0;
   if (PROF == 1 && threadIdx.x < 16) prof[threadIdx.x] = 0;
-  DevX<PROF, BIG> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
+  DevX<PROF, BIG, NT> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
                     (PROF == 2 && b == 0 && a.tl) ? tlbuf : nullptr, tlcnt, kTimelineCap, a.tl_f0, a.tl_nf};
   int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
@@ -1098,12 +1100,18 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   }
   a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
   const bool pruned_mode = a.pr_cnt != nullptr;
+  // workgroup size (measured): 1024 threads for the usual shapes; below ~1300 candidate slots 512 is marginally better
+  // (fewer idle waves), fewer than that is always slower (the new-children phase wants its own waves)
+  int threads = d->threads;
+  if (threads == 0) threads = dims.S_max() <= 1300 ? 512 : 1024;
   const void *fn;
 #define CTC_PICK(PROF_)                                                                                                  \
   (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, true, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, true, 0, false>)    \
        : fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, false, 1, true> : (const void *)ctc_beam_decode_kernel<PROF_, false, 1, false>) \
                : (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, false, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, false, 0, false>))
   fn = d->profile ? CTC_PICK(1) : CTC_PICK(0);
+  if (!d->profile && fixed && !big && threads == 1024)  // the usual case: workgroup size folded into the code
+    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<0, false, 1, false, 1024>;
   if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes only
     if (big || !fixed || pruned_mode) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels, no pruning");
     fn = (const void *)ctc_beam_decode_kernel<2, false, 1, false>;
@@ -1112,10 +1120,6 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
   void *kargs[] = {&a};
-  // workgroup size (measured): 1024 threads for the usual shapes; below ~1300 candidate slots 512 is marginally better
-  // (fewer idle waves), fewer than that is always slower (the new-children phase wants its own waves)
-  int threads = d->threads;
-  if (threads == 0) threads = dims.S_max() <= 1300 ? 512 : 1024;
   HIP_TRY(hipLaunchKernel(fn, dim3(B), dim3(threads), kargs, lds, stream));
   HIP_TRY(hipGetLastError());
   if (d->timing) HIP_TRY(hipEventRecord(d->ev1, stream));
