@@ -231,8 +231,15 @@ struct OutRefs {
 // IDENT: the utterance is decoded without vocabulary pruning (candidate r of every frame is label r).  A compile-time
 // switch: the two modes keep different things in flight across a frame (next row vs. next candidate list), and mixing
 // them in one instantiation makes the compiler wait for the prefetch where the other mode's registers are written.
-// SMALLV: the caller guarantees at most 64 candidate characters per frame (the fixed workspace layout does): the paths
-// for larger candidate sets are compiled out.
+// SMALLV: the caller guarantees beam <= kSmallK and at most kSmallV labels (the class of shapes of the fixed workspace
+// layout): the paths for larger candidate sets are compiled out and the bounds are told to the optimiser.
+constexpr int kSmallK = 128, kSmallV = 32;
+#if defined(__clang__)
+#define CTC_ASSUME(c) __builtin_assume(c)
+#else
+#define CTC_ASSUME(c) do { if (!(c)) __builtin_unreachable(); } while (0)
+#endif
+
 template <class X, bool IDENT, bool SMALLV = false>
 struct Decoder {
   X &x;
@@ -613,6 +620,7 @@ struct Decoder {
     const int n = st_n, pool_count = st_pool;
     const int K = d.K;
     const int Vc = in.Vc, brank = in.blank_rank;
+    if (SMALLV) { CTC_ASSUME(n >= 1 && n <= kSmallK); CTC_ASSUME(Vc >= 1 && Vc <= kSmallV); CTC_ASSUME(d.K <= kSmallK); }
     const int Vnb = Vc - (brank >= 0 ? 1 : 0);
     const int S = n * (2 + Vnb);
     const bool small_vocab = SMALLV || Vnb <= 64;  // existing children fit a 64-bit mask per parent

@@ -368,7 +368,7 @@ struct KernelArgs {
 // LAYOUT: 0 = the workspace is laid out for the call's own beam width / vocabulary (array bases are run-time values);
 // 1 = fixed layout for beam <= kFixedK, vocabulary <= kFixedV: every LDS array sits at a compile-time address, which
 // frees the scalar registers the bases would occupy and folds them into the instructions' offset fields.
-constexpr int kFixedK = 128, kFixedV = 32;
+constexpr int kFixedK = ctcbeam::kSmallK, kFixedV = ctcbeam::kSmallV;
 __host__ __device__ constexpr Dims fixed_layout_dims() { return Dims{kFixedK, kFixedV, kFixedV, 1}; }
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
 
