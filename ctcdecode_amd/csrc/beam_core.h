@@ -1060,6 +1060,7 @@ struct Decoder {
     const Beam &b = w.cur;
     const int tid = x.tid(), nt = x.nt();
     const int n = st_n;
+    if (SMALLV) { CTC_ASSUME(n >= 1 && n <= kSmallK); CTC_ASSUME(d.K <= kSmallK); }
     const int nres = n < d.K ? n : d.K;
     if (!had_steps)
       for (int k = tid; k < nres; k += nt) w.fin[k] = k;
@@ -1174,6 +1175,7 @@ template <bool IDENT, bool SMALLV = false, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr) {
+  if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
   Decoder<X, IDENT, SMALLV> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
