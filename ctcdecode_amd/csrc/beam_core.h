@@ -369,6 +369,7 @@ struct Decoder {
   struct Window { uint32_t lo; int shift; };
   CTC_HD Window first_window() const {
     // width = 2^st_wlog keys ending at the previous best key (st_wlog is kept in [kBinsLog, 32]); all of it fits 32 bits
+    CTC_ASSUME(st_wlog >= kBinsLog && st_wlog <= 32);
     Window wd;
     wd.lo = 1u;
     wd.shift = st_wlog - kBinsLog;
@@ -399,6 +400,7 @@ struct Decoder {
   // own survivors, so the caller only has to expand the bitmap.  inb = #keys in the bucket (<= kListCap).
   CTC_HD void rank_bucket(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb) {
     const int tid = x.tid(), nt = x.nt();
+    CTC_ASSUME(inb >= 1 && inb <= kListCap);
     {
       const uint32_t *skey = w.skey;
       uint32_t *list = w.list;

@@ -404,3 +404,14 @@ def test_both_workspace_layouts(torch_mod, threads):
         for fixed in (True, False):
             got = _decode(torch_mod, lp, beam=K, cutoff_top_n=top_n, threads=threads, fixed_layout=fixed)
             ou.assert_same(_with_nres(got, want), want, "layout fixed=%s B%d T%d V%d K%d" % (fixed, B, T, V, K))
+
+
+def test_workgroup_size_must_be_a_power_of_two(torch_mod):
+    import ctcdecode_amd
+
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(5)], beam_width=4, log_probs_input=True, device="cuda:0")
+    for ok in (0, 64, 128, 256, 512, 1024):
+        dec.set_threads(ok)
+    for bad in (32, 96, 768, 2048, -64):
+        with pytest.raises(ValueError):
+            dec.set_threads(bad)
