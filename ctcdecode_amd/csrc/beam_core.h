@@ -39,6 +39,10 @@
 
 #include "exact_math.h"
 #include "stl_emul.h"
+#if defined(CTC_ASSUME_CHECKED)
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace ctcbeam {
 
@@ -234,7 +238,9 @@ struct OutRefs {
 // SMALLV: the caller guarantees beam <= kSmallK and at most kSmallV labels (the class of shapes of the fixed workspace
 // layout): the paths for larger candidate sets are compiled out and the bounds are told to the optimiser.
 constexpr int kSmallK = 128, kSmallV = 32;
-#if defined(__clang__)
+#if defined(CTC_ASSUME_CHECKED)  // the host build of the tests verifies every assumption instead of exploiting it
+#define CTC_ASSUME(c) do { if (!(c)) { std::fprintf(stderr, "beam_core.h:%d: assumption violated: %s\n", __LINE__, #c); std::abort(); } } while (0)
+#elif defined(__clang__)
 #define CTC_ASSUME(c) __builtin_assume(c)
 #else
 #define CTC_ASSUME(c) do { if (!(c)) __builtin_unreachable(); } while (0)
