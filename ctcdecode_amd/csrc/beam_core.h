@@ -427,6 +427,7 @@ struct Decoder {
     for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
     x.sync();
     x.mark(14);
+    if (tid < inb) x.template prio<3>();
     for (int q = tid; q < inb; q += nt) {
       const uint32_t mine = w.list[q];
       int g = 0, e = 0;
@@ -443,6 +444,7 @@ struct Decoder {
         x.atomic_or(&w.bitmap[sl >> 5], 1u << (sl & 31));
       }
     }
+    x.template prio<0>();
     x.sync();
   }
 
@@ -769,6 +771,7 @@ struct Decoder {
     }
     x.mark(1);
     if (!split || tid >= n1) {
+      if (split) x.template prio<2>();
       const int t2 = split ? tid - n1 : tid, nt2 = split ? nt - n1 : nt;
       const int sh = ceil_log2_u32((uint32_t)(Vnb > 1 ? Vnb : 1));
       const int lp2 = 1 << sh;                       // lanes per parent (power of two >= Vnb)
@@ -809,6 +812,7 @@ struct Decoder {
         }
       }
     }
+    if (split) x.template prio<0>();
     x.sync();
     if (!small_vocab) {  // children that already exist leave a hole in their parent's group; then the histogram
       for (int j = tid; j < n; j += nt) {

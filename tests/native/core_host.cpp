@@ -38,6 +38,7 @@ struct HostX {
   int pick(int v, int) const { return v; }  // the value lane `idx` holds (one lane here)
   void mark(int) {}
   void trace_frame(int) {}
+  template <int P> void prio() const {}
   template <class P> const P *fresh(const P *p) const { return p; }
   void tick() {}
   void dump(int, int, const int *, const int *, const int *, const float *) {}
