@@ -16,8 +16,8 @@
 //     subtree range, a_i the number of in-beam proper ancestors and Vnb the number of non-blank candidates.
 //     Children that already exist (in the beam: "hit"; alive but not in the beam: "revive") leave a hole.
 //   * Pruning = exact K-th largest of the 48-bit keys (score desc, character asc) = prefix_compare
-//     (decoder_utils.cpp:122-132), found by a histogram select (256 buckets over a window below the best score,
-//     then an exact rank inside the one bucket that holds the K-th key).  If the K boundary cuts through a group of
+//     (decoder_utils.cpp:122-132), found by a histogram select (1024 + 64 buckets over a window below the best
+//     score, then an exact rank inside the one bucket that holds the K-th key).  If the K boundary cuts through a group of
 //     EQUAL keys -- structural at long T, SURVEY.md 7.3-H2 -- or on the last step (whose permutation feeds the final
 //     sorts), the workgroup replays libstdc++'s std::nth_element on the DFS-ordered candidate list (Hoare partitions
 //     done in parallel, the small tail by one lane with stl_emul.h), so the same prefixes survive as in the
@@ -26,11 +26,18 @@
 //     their parents' entries), which keeps the DFS-order invariant without ever scanning the dropped candidates.
 //   * Trie nodes that survive a step are appended to a per-utterance pool in HBM {parent, char, timestep,
 //     log_prob_c}; nothing transient is ever materialised (the reference news/deletes ~2.8k nodes per step).
-//     The pool is read back only for (rare) dead-interior lookups and for the final back-trace.
+//     The pool is read back only for (rare) dead-interior lookups and for the final back-trace, which reads every
+//     label once (entry j only what it does not share with its DFS predecessor, in 32-label segments reached through
+//     per-node express pointers) and copies the shared parts row to row.  The two final std::sorts are replayed
+//     exactly too (sort_like_std), one pending introsort range per lane.
 //   * Scores use the bit-exact float32 log_sum_exp of exact_math.h.
+//   * Work inside a frame is split by WAVE ROLE where it is narrow (entries || new children in the scoring phase;
+//     LCP || structure || probabilities || per-frame resets in the emission), and everything every wave executes is
+//     kept scalar-cheap: with 16 waves on 4 SIMDs one instruction executed by all of them costs four issue slots.
+//     For the usual class of shapes (beam <= 128, <= 32 labels: SMALLV) the bounds are given to the optimiser.
 //
 // The code is written against an execution policy X (thread id, thread count, barrier, block reductions):
-// kernels.hip instantiates it with one workgroup per utterance; tests/native/core_host.cpp instantiates it with a
+// ctcdecode_amd.hip instantiates it with one workgroup per utterance; tests/native/core_host.cpp instantiates it with a
 // single sequential "thread" so the very same source is differential-tested against the oracle on the CPU
 // (test infrastructure only -- the product has no CPU path).
 #pragma once
