@@ -18,7 +18,7 @@ def _load():
     path = _build.LIB_PATH
     if not os.path.exists(path):
         raise ImportError("ctcdecode_amd: HIP library %s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(or `python -m ctcdecode_amd._build`). There is no CPU fallback." % path)
+                          "(or `python ctcdecode_amd/_build.py`). There is no CPU fallback." % path)
     import torch  # noqa: F401  (loads the HIP runtime the library must share with PyTorch-ROCm)
 
     lib = ctypes.CDLL(path)
