@@ -936,39 +936,48 @@ struct Decoder {
           }
           nb.lcp[k] = l;
         }
-        if (type == T_SELF) {
-          if (r_struct) {
-            nb.node[k] = b.node[j]; nb.par[k] = b.par[j]; nb.ch[k] = b.ch[j]; nb.dep[k] = b.dep[j];
-            nb.via[k] = b.via[j]; nb.viaanc[k] = b.viaanc[j]; nb.viach[k] = b.viach[j]; nb.up[k] = b.up[j];
+        // An entry that stays (T_SELF) and a brand-new child (T_CHILD, of entry j) both draw everything from entry j:
+        // one batch of loads, then selects -- no divergence between the two kinds, which share waves.  A revived
+        // interior node (rare) hangs off the nearest in-beam ancestor of j instead and overrides afterwards.
+        const bool self = type == T_SELF, child = type == T_CHILD;
+        const int c = self ? -1 : info_ch(inf);
+        if (r_struct) {
+          const int node_j = b.node[j], par_j = b.par[j], ch_j = b.ch[j], dep_j = b.dep[j];
+          const int via_j = b.via[j], viaanc_j = b.viaanc[j], viach_j = b.viach[j], up_j = b.up[j];
+          const int id = pool_count + k;                                              // ids by beam position (gaps are harmless)
+          const int upv = (dep_j & (kExpress - 1)) == 0 ? node_j : up_j;
+          int o_node = self ? node_j : id, o_par = self ? par_j : node_j, o_ch = self ? ch_j : c;
+          int o_dep = self ? dep_j : dep_j + 1, o_viaanc = self ? viaanc_j : -1, o_up = self ? up_j : upv;
+          if (child) {                                                                // path_trie.cpp:97-105
+            PoolNode pn; pn.parent = node_j; pn.ch = c; pn.tstep = in.t; pn.lpc = w.clp[rank_of_char(in, c)];
+            pool[id] = pn;
+            pool_up[id] = upv;
+          } else if (!self) {                                                         // path_trie.cpp:50-56 : revived
+            const int P = w.anc[j];
+            o_node = via_j; o_par = b.node[P]; o_dep = b.dep[P] + 1; o_up = pool_up[via_j];
           }
-          if (r_prob) {
-            nb.bprev[k] = w.b_new[j]; nb.nbprev[k] = w.nb_new[j]; nb.score[k] = w.sc_new[j]; nb.lpc[k] = b.lpc[j];
-          }
-        } else {
-          const int c = info_ch(inf);
-          const int P = (type == T_CHILD) ? j : w.anc[j];
-          const float lp = w.clp[rank_of_char(in, c)];
-          if (r_struct) {
-            int id;
-            if (type == T_CHILD) {  // path_trie.cpp:97-105; ids are handed out by beam position (gaps are harmless)
-              id = pool_count + k;
-              PoolNode pn; pn.parent = b.node[P]; pn.ch = c; pn.tstep = in.t; pn.lpc = lp;
-              pool[id] = pn;
-              const int upv = (b.dep[P] & (kExpress - 1)) == 0 ? pn.parent : b.up[P];
-              pool_up[id] = upv;
-              nb.up[k] = upv;
-            } else {                // path_trie.cpp:50-56 : revived
-              id = b.via[j];
-              nb.up[k] = pool_up[id];
+          nb.node[k] = o_node; nb.par[k] = o_par; nb.ch[k] = o_ch; nb.dep[k] = o_dep;
+          nb.via[k] = via_j; nb.viaanc[k] = o_viaanc; nb.viach[k] = viach_j; nb.up[k] = o_up;  // via/viach: only read when viaanc matches
+        }
+        if (r_prob) {
+          const float b_n = w.b_new[j], nb_n = w.nb_new[j], sc_n = w.sc_new[j], lpc_j = b.lpc[j];
+          const int ch_j = b.ch[j];
+          const float score_j = b.score[j], bprev_j = b.bprev[j];
+          float o_b = b_n, o_nb = nb_n, o_sc = sc_n, o_lpc = lpc_j;
+          if (!self) {              // a new or revived prefix starts from its first path only (path_trie.cpp:52-56, 99-104)
+            const float lp = w.clp[rank_of_char(in, c)];
+            float logp;
+            if (child) {                                                              // ctc_beam_search_decoder.cpp:110-118
+              const float rep = bprev_j > CTC_NEG_MAX ? lp + bprev_j : CTC_NEG_MAX;
+              logp = c == ch_j ? rep : lp + score_j;
+              o_lpc = lp;
+            } else {
+              logp = child_logp(w.anc[j], c, lp);
+              o_lpc = w.rev_lpc[j];
             }
-            nb.node[k] = id; nb.par[k] = b.node[P]; nb.ch[k] = c; nb.dep[k] = b.dep[P] + 1;
-            nb.viaanc[k] = -1;
+            o_b = CTC_NEG_MAX; o_nb = logp; o_sc = logp;
           }
-          if (r_prob) {             // a new or revived prefix starts from its first path only (path_trie.cpp:52-56, 99-104)
-            const float logp = child_logp(P, c, lp);
-            nb.bprev[k] = CTC_NEG_MAX; nb.nbprev[k] = logp; nb.score[k] = logp;
-            nb.lpc[k] = type == T_CHILD ? lp : w.rev_lpc[j];
-          }
+          nb.bprev[k] = o_b; nb.nbprev[k] = o_nb; nb.score[k] = o_sc; nb.lpc[k] = o_lpc;
         }
         if (r_prob) kloc = w.skey[s] > kloc ? w.skey[s] : kloc;
       }
