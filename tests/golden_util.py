@@ -1,4 +1,4 @@
-"""Loader for the committed reference fixtures (tests/golden/*.npz, made by tools/make_golden.py)."""
+"""Loader for the committed reference fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py)."""
 import glob
 import os
 

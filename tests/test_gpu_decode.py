@@ -141,7 +141,7 @@ def test_vocabulary_pruning_against_oracle(torch_mod, c):
 
 @pytest.mark.parametrize("threads", [128, 256, 1024])
 def test_pruned_wide_beam_regression(torch_mod, threads):
-    """Found by tools/gpu_stress.py: with vocabulary pruning and more surviving beams than one wave emits, the rank table
+    """Found by tests/sweeps/gpu_stress.py: with vocabulary pruning and more surviving beams than one wave emits, the rank table
     was un-registered by the first wave while later waves were still emitting (wrong log_prob for beams >= 128)."""
     lp = ou.synth_logprobs(4, 61, 64, 7057, quant=2.0, blank_id=32)
     sl = np.array([11, 30, 32, 47], np.int32)
@@ -151,11 +151,11 @@ def test_pruned_wide_beam_regression(torch_mod, threads):
 
 
 def test_randomised_stress_subset(torch_mod):
-    """A slice of tools/gpu_stress.py (random shapes, pruning, ragged lengths, streaming, every workgroup size)."""
+    """A slice of tests/sweeps/gpu_stress.py (random shapes, pruning, ragged lengths, streaming, every workgroup size)."""
     import subprocess
     import sys as _sys
 
-    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_stress.py"),
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "sweeps", "gpu_stress.py"),
                         "--n", "120", "--seed", "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 

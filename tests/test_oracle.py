@@ -2,7 +2,7 @@
 
 (a) the reference's own golden strings (tests/test_decode.py:31-32 of the reference),
 (b) the survey's known-answer table,
-(c) the committed fixtures produced by the real reference build (tests/golden, tools/make_golden.py),
+(c) the committed fixtures produced by the real reference build (tests/golden, tests/golden/make_golden.py),
 (d) live differential runs against oracle/_ref when it is present (build container and GPU box).
 """
 import numpy as np
