@@ -207,3 +207,53 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
   }
   return 1;
 }
+
+// Small helpers of beam_core.h checked exhaustively / on random patterns (tests/test_core_host.py).  Returns the
+// number of violations found.
+extern "C" long long ctccore_check_helpers(unsigned long long seed, long long n_random) {
+  using namespace ctcbeam;
+  long long bad = 0;
+  auto bits_f = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+  // ord_f32: order-preserving on every pair of non-NaN floats, both zeros coincide (operator== / operator> of the reference)
+  auto check_pair = [&](uint32_t ua, uint32_t ub) {
+    const float a = bits_f(ua), b = bits_f(ub);
+    if (a != a || b != b) return;
+    const uint32_t ka = ord_f32(a), kb = ord_f32(b);
+    if ((a > b) != (ka > kb) || (a == b) != (ka == kb)) ++bad;
+  };
+  const uint32_t special[] = {0x00000000u, 0x80000000u, 0x00000001u, 0x80000001u, 0x007fffffu, 0x807fffffu, 0x00800000u, 0x80800000u,
+                              0x3f800000u, 0xbf800000u, 0x7f7fffffu, 0xff7fffffu, 0x7f800000u, 0xff800000u, 0xc4610000u, 0xc4610001u};
+  for (uint32_t a : special)
+    for (uint32_t b : special) check_pair(a, b);
+  unsigned long long s = seed * 6364136223846793005ull + 1442695040888963407ull;
+  for (long long i = 0; i < n_random; ++i) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    const uint32_t ua = (uint32_t)(s >> 32);
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    uint32_t ub = (uint32_t)(s >> 32);
+    if (i & 1) ub = ua + (uint32_t)((s >> 8) & 7) - 3u;  // neighbours in bit space
+    check_pair(ua, ub);
+  }
+  // shifts that stand in for divisions
+  for (int d = 1; d <= 4096; d <<= 1)
+    for (int v = 0; v < 70000; v += (v < 300 ? 1 : 97)) {
+      if (div_p2(v, d) != v / d) ++bad;
+      if (ceil_div_p2(v, d) != (v + d - 1) / d) ++bad;
+    }
+  for (uint32_t v = 1; v < 100000; ++v) {
+    int sft = 0;
+    while ((1ull << sft) < v) ++sft;
+    if (ceil_log2_u32(v) != sft || ceil_log2_u64(v) != sft) ++bad;
+  }
+  if (ceil_log2_u32(0x80000000u) != 31 || ceil_log2_u32(0x80000001u) != 32 || ceil_log2_u32(0xFFFFFFFFu) != 32) ++bad;
+  // info words: round trip, and "character ascending" = larger top half first
+  for (int ch = -1; ch < 66000; ch += (ch < 70 ? 1 : 331))
+    for (uint32_t type = 0; type < 4; ++type)
+      for (int e = 0; e <= kMaxBeam; e += 4095) {
+        if (ch + 1 > 0xFFFF) continue;
+        const uint32_t inf = mk_info(ch, type, e);
+        if (info_ch(inf) != ch || info_type(inf) != type || info_entry(inf) != e) ++bad;
+        if (ch >= 0 && (mk_info(ch, 0, 0) >> 16) >= (mk_info(ch - 1, 0, 0) >> 16)) ++bad;
+      }
+  return bad;
+}

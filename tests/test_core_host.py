@@ -99,3 +99,13 @@ def test_core_streaming_equals_one_shot():
         lp = ou.synth_logprobs(2, T, V, 900 + it, quant=quant, blank_bias=float(rng.choice([0, 3])))
         bounds = sorted(set(int(x) for x in rng.integers(0, T + 1, size=int(rng.integers(0, 6)))))
         ou.assert_same(ou.decode(lp, beam=K), ou.decode_core_host_chunked(lp, bounds, beam=K), "chunks %s" % bounds)
+
+
+def test_core_helpers():
+    """ord_f32 (score -> sortable key), the shift forms of the divisions, log2 helpers, info-word packing."""
+    import ctypes
+
+    lib = ctypes.CDLL(ou.build_core_host())
+    lib.ctccore_check_helpers.restype = ctypes.c_longlong
+    lib.ctccore_check_helpers.argtypes = [ctypes.c_ulonglong, ctypes.c_longlong]
+    assert lib.ctccore_check_helpers(12345, 2_000_000) == 0
