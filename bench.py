@@ -4,11 +4,11 @@
 Workload (BASELINE.json configs[1], per GPU): B=256 utterances, T=1000 frames, V=29 labels, beam_width=100,
 cutoff_top_n=29 (no pruning), no LM; inputs are float32 log-softmax of N(0,1) logits, resident in HBM before the
 timed region.  A "step" = one decode of that whole batch through the product path (C ABI -> HIP kernel).  With N GPUs
-every rank decodes its own B utterances (weak scaling, no data-path collective) and rank 0 then gathers the four result
-tensors over RCCL (north_star's "trivial gather") inside the timed region; by default batch i's gather overlaps the
-decode of batch i+1 (ctcdecode_amd.distributed.ResultGatherer), all gathers complete before the clock stops.
+every rank decodes its own B utterances (weak scaling, no data-path collective) and rank 0 then gathers the results
+over RCCL (north_star's "trivial gather") inside the timed region; by default batch i's gather overlaps the decode of
+batch i+1 (ctcdecode_amd.distributed.ResultGatherer), all gathers complete before the clock stops.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: this process launches the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field).
@@ -16,11 +16,29 @@ Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of e
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# Critical-path floor of ONE frame of the decode kernel's phase structure, in shader clocks, from the primitives measured
+# on this GPU (tools/ubench): dependent LDS round trip 68, workgroup barrier at 1024 threads 78,
+# six-step DPP scan 100, LDS atomic 50, the dependent binary64 chain of one log_sum_exp ~300.
+FRAME_FLOOR = {
+    "A1 subtree ends + painting (2 LDS round trips, ballot search, atomics)": 250,
+    "A2 slot offsets (1 round trip)": 150,
+    "B score + histogram (1 round trip, log_sum_exp, atomic)": 420,
+    "C1 find bucket (2 round trips, 2 DPP scans)": 350,
+    "C2 list the bucket (1 round trip, atomic append)": 200,
+    "C3 rank inside the bucket (1 round trip, compare)": 200,
+    "D ordered compaction (1 round trip, DPP scan, scatter)": 250,
+    "E emit the next beam (4 dependent round trips)": 350,
+    "8 workgroup barriers": 8 * 78,
+}
+SHADER_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); the timeline tool measured ~2.3 GHz sustained
 
 
 def parse():
@@ -34,10 +52,15 @@ def parse():
     ap.add_argument("--beam", type=int, default=100)
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = library default)")
     ap.add_argument("--gather", choices=["overlap", "sync", "none"], default="overlap",
-                    help="N>1: gather the four result tensors to rank 0 inside the timed region; 'overlap' lets batch i's gather "
+                    help="N>1: gather the results to rank 0 inside the timed region; 'overlap' lets batch i's gather "
                          "run (RCCL streams) while batch i+1 is decoded, 'sync' finishes it before the next decode")
+    ap.add_argument("--gather-format", choices=["compact", "full"], default="full",
+                    help="what travels to rank 0: 'compact' = valid prefixes only, narrow integer types (expanded on rank 0); "
+                         "'full' = the four padded tensors")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the gather path even with one rank (self-test)")
+    ap.add_argument("--backend", default="", help="torch.distributed backend (default nccl = RCCL; gloo when ranks share a device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the e2e and other_configs measurements (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes of the decode kernel from a rocprofv3 --pmc pass (tools/rocprof_summary.py)")
@@ -67,8 +90,85 @@ def cpu_baseline(lp_np, beam, target_s):
             "sample": "%d of the %d utterances of one batch (same T, V, beam), num_processes=%d, %.1f s wall" % (n, lp_np.shape[0], cores, dt)}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks here (one process per GPU,
+    the same environment torch.distributed.run would set), pass rank 0's JSON line through, return the worst exit code."""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   CTCD_BENCH_VISIBLE_DEVICES=str(ndev))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def time_e2e(torch, dec, lp_cpu, reps=5, warm=2):
+    """SURVEY 8(d)'s primary definition: wall time of one drop-in decode() call -- CPU tensor in, four CPU tensors out."""
+    for _ in range(warm):
+        dec.decode(lp_cpu)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dec.decode(lp_cpu)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def other_configs(torch, ctcdecode_amd, dev):
+    """Kernel time of the other BASELINE.json configurations' per-GPU shapes (not bench lines: one or two launches each)."""
+    out = {}
+
+    def run(name, B, T, V, K, top_n=40, cutoff_prob=1.0, reps=2, **kw):
+        g = torch.Generator(device="cpu").manual_seed(7)
+        lp = torch.randn((B, T, V), generator=g).log_softmax(-1).to(dev)
+        dec = ctcdecode_amd.CTCBeamDecoder([str(i) if i != 1 else " " for i in range(V)], cutoff_top_n=top_n, cutoff_prob=cutoff_prob, beam_width=K,
+                                           log_probs_input=True, device=dev, **kw)
+        dec.set_timing(True)
+        ks, ps = [], []
+        for _ in range(reps + 1):
+            dec.decode_device(lp, None, check=True)
+            torch.cuda.synchronize()
+            ks.append(dec.last_kernel_ms())
+            if top_n < V or cutoff_prob < 1.0:
+                ps.append(dec.last_prune_ms())
+        r = {"B": B, "T": T, "V": V, "beam": K, "decode_kernel_ms": round(min(ks[1:]), 3), "us_per_frame": round(min(ks[1:]) * 1e3 / T, 3),
+             "utt_per_s_kernel": round(B / (min(ks[1:]) + (min(ps[1:]) if ps else 0.0)) * 1e3, 1)}
+        if ps:
+            r["prune_kernel_ms"] = round(min(ps[1:]), 3)
+            r["prune_GBps"] = round(B * T * V * 4 / (min(ps[1:]) * 1e-3) / 1e9, 1)
+            r["prune_host_rows"] = int(ctcdecode_amd._native.lib.ctcd_last_prune_host_rows(dec._handle))
+        out[name] = r
+        del dec, lp
+        torch.cuda.empty_cache()
+
+    run("configs[2] per-GPU shape (256 of 2048 utterances, beam 500, T 2000)", 256, 2000, 29, 500, reps=1)
+    run("configs[3] (V=10000, top_n 40, cutoff_prob 0.99)", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99)
+    run("configs[4] per-GPU shape without the LM (128 of 1024 utterances, T 1500)", 128, 1500, 29, 100)
+    arpa = os.path.join(ROOT, "tests", "data", "test.arpa")
+    if os.path.exists(arpa) and getattr(ctcdecode_amd, "HAVE_LM", False):
+        try:
+            run("configs[4] per-GPU shape with the LM scorer (tests/data/test.arpa, alpha 0.5, beta 1.0)", 128, 1500, 29, 100,
+                model_path=arpa, alpha=0.5, beta=1.0)
+        except Exception as e:  # the LM tier must not take the bench line down
+            out["configs[4] with the LM scorer"] = {"error": str(e)[:200]}
+    return out
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
     import numpy as np
     import torch
 
@@ -79,19 +179,25 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    shared = ndev < world  # fewer devices than ranks (single-GPU dry run of the N-rank path): ranks share devices
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
     dist = None
     use_dist = world > 1 or a.force_dist
     # RCCL prints a version banner on stdout; keep stdout for the ONE JSON line: everything else goes to stderr
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    backend = a.backend or ("gloo" if shared else "nccl")  # RCCL refuses two ranks on one device
     if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     B, T, V, K = a.batch, a.frames, a.vocab, a.beam
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -104,10 +210,9 @@ def main():
 
     gatherer = None
     if use_dist and a.gather != "none":
-        from ctcdecode_amd.distributed import ResultGatherer
+        from ctcdecode_amd.distributed import make_gatherer
 
-        shapes = [((B, K, T), torch.int32), ((B, K), torch.float32), ((B, K, T), torch.int32), ((B, K), torch.int32)]
-        gatherer = ResultGatherer(shapes, dev, dst=0, depth=2)
+        gatherer = make_gatherer(a.gather_format, B, K, T, V, dev, dst=0, depth=2)
 
     def step():
         res = dec.decode_device(lp, None, check=False)
@@ -134,7 +239,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # kernel duration of the last timed launch (HIP events on the launch stream); averaged over a few extra launches
@@ -152,32 +257,52 @@ def main():
     # (8 bytes per emitted label per beam) + scores and lengths (8 bytes per beam) + 4 (seq_len)
     alg_bytes = B * (T * V * 4 + 8 * K + 4) + 8 * int(out_len.sum().item())
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     if os.path.exists(a.traffic_json):
         try:
-            traffic = json.load(open(a.traffic_json)).get("hbm_bytes_per_launch")
+            tj = json.load(open(a.traffic_json))
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         except Exception:
             traffic = None
 
     if rank == 0:
+        floor = sum(FRAME_FLOOR.values())
+        frame_clocks = kern_ms * 1e-3 / T * SHADER_GHZ * 1e9
         line = {
             "metric": "utterances/sec at B=256 T=1000 V=29 beam=100",
             "value": round(world * B * a.steps / elapsed, 3),
             "unit": "utterances/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": min(world, ndev), "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: CTC prefix beam search, no LM, log-softmax of N(0,1) logits",
                        "utterances_per_gpu": B, "frames": T, "vocab": V, "beam_width": K, "cutoff_top_n": V,
-                       "global_batch": world * B, "parallelism": "batch-sharded x%d, gather=%s" % (world, a.gather if use_dist else "n/a"),
+                       "global_batch": world * B, "ranks": world,
+                       "parallelism": "batch-sharded x%d, gather=%s/%s, backend=%s" % (world, a.gather, a.gather_format, backend) if use_dist else "single GPU",
                        "threads_per_workgroup": a.threads or "default"},
             "kernel_ms": round(kern_ms, 4),
             "us_per_frame": round(kern_ms * 1e3 / T, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic,
+                         "traffic_source": ("constant from profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command), not measured in this run" % traffic_src) if traffic else None,
+                         "traffic_ratio": round(traffic / alg_bytes, 2) if traffic else None,
+                         "memset_bytes_outside_kernel": 2 * B * K * T * 4 + 2 * B * K * 4,
                          "kernel": "ctc_beam_decode_kernel", "algorithmic_bytes_per_launch": alg_bytes},
+            # the recurrence is latency-bound, not HBM-bound: distance from the critical-path floor of one frame
+            "latency": {"frame_clocks": round(frame_clocks), "floor_clocks": floor, "frame_over_floor": round(frame_clocks / floor, 2),
+                        "shader_ghz_assumed": SHADER_GHZ, "floor_terms": FRAME_FLOOR},
         }
+        if shared:
+            line["config"]["oversubscribed"] = "%d ranks on %d device(s): a dry run of the N-rank path, not a scaling number" % (world, ndev)
+        if world == 1 and not a.no_extras:
+            e2e = time_e2e(torch, dec, lp_cpu)
+            line["e2e"] = {"what": "drop-in decode(): CPU float32 tensor in, four CPU tensors out (SURVEY 8(d) primary definition)",
+                           "ms_per_batch": round(e2e * 1e3, 3), "value": round(B / e2e, 1), "unit": "utterances/s"}
+            try:
+                line["other_configs"] = other_configs(torch, ctcdecode_amd, dev)
+            except Exception as e:
+                line["other_configs"] = {"error": str(e)[:300]}
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(lp_cpu.numpy(), K, a.cpu_seconds)
         os.write(json_fd, (json.dumps(line) + "\n").encode())

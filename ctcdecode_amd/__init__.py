@@ -76,6 +76,11 @@ class CTCBeamDecoder(object):
         _native.check(_native.lib.ctcd_last_kernel_ms(self._handle, ctypes.byref(ms)))
         return float(ms.value)
 
+    def last_prune_ms(self):
+        ms = ctypes.c_float()
+        _native.check(_native.lib.ctcd_last_prune_ms(self._handle, ctypes.byref(ms)))
+        return float(ms.value)
+
     def decode_device(self, probs, seq_lens=None, check=True):
         """``probs``: [B, T, V] tensor (any device / float dtype).  Returns (beam_results, beam_scores, timesteps,
         out_lens) as tensors in HBM on the decoder's device; asynchronous on the current stream when ``check`` is False."""

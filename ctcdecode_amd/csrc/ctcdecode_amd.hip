@@ -444,11 +444,17 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
 // prob -> log-prob exactly as decoder_utils.cpp:42 : float(log(double(p) + FLT_MIN)).  The device log() is within
 // 1 ulp of the correctly rounded double; the element is flagged (and later recomputed with the host C library the
 // reference binds to) whenever that uncertainty could change the float it rounds to, so the result is bit-exact.
-__global__ void prob_to_log_kernel(const float *in, float *out, size_t n, unsigned *n_flag, unsigned long long *flag_idx,
-                                   unsigned flag_cap) {
+__global__ void prob_to_log_kernel(const float *in, float *out, size_t n, const int32_t *seq_lens, int T, int V, unsigned *n_flag,
+                                   unsigned long long *flag_idx, unsigned flag_cap) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t tv = (size_t)T * V;
   for (; i < n; i += stride) {
+    if (seq_lens) {  // frames beyond the utterance's length are never read by the reference (binding.cpp:64-65)
+      const size_t b = i / tv;
+      const int t = (int)((i - b * tv) / (size_t)V);
+      if (t >= seq_lens[b]) continue;
+    }
     const double y = log((double)in[i] + (double)FLT_MIN);
     const float f = (float)y;
     const double eps = fabs(y) * 0x1p-50;
@@ -458,6 +464,15 @@ __global__ void prob_to_log_kernel(const float *in, float *out, size_t n, unsign
     }
     out[i] = f;
   }
+}
+// flagged elements: values to a contiguous buffer, host-computed logs back (one transfer each way per chunk)
+__global__ void gather_elems_kernel(const float *in, const unsigned long long *idx, unsigned n, float *out) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = in[idx[k]];
+}
+__global__ void scatter_elems_kernel(const float *vals, const unsigned long long *idx, unsigned n, float *out) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[idx[k]] = vals[k];
 }
 
 // ------------------------------------------------------------------------------------------------ vocabulary prune
@@ -739,6 +754,27 @@ int fail(int code, const std::string &msg) {
     if (e_ != hipSuccess) return fail(CTCD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
   } while (0)
 
+// Every C ABI entry point works on the decoder's device and puts the caller's current device back on exit (a process
+// that uses several GPUs must not find PyTorch's current device switched by a decode -- or by a destructor that the
+// garbage collector runs at an arbitrary time).
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != dev) prev = cur;
+    if (cur != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define CTC_ON_DEVICE(dev)  \
+  DeviceGuard guard_(dev);  \
+  HIP_TRY(guard_.err)
+
 struct Buf {
   void *p = nullptr;
   size_t cap = 0;
@@ -775,12 +811,15 @@ struct ctcd_decoder {
   Buf prof, dbg, tl;
   int tl_f0 = 0, tl_nf = 0;
   bool tl_armed = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // decode kernel | vocabulary-prune pass
+  bool prune_timed = false;
+  hipStream_t last_stream = nullptr;  // the stream of the last decode launch (ctcd_check_status reads the status words on it)
   std::mutex mu;
 };
 
 // One audio stream's parked decoder state (ctcd_stream_*): a single HBM block [header | beam arrays | node pool].
 struct ctcd_stream {
+  int device = 0;
   char *block = nullptr;
   size_t bytes = 0;
   int V = 0, beam = 0;
@@ -893,8 +932,8 @@ int ctcd_create(ctcd_decoder **out, int device_id) {
 
 void ctcd_destroy(ctcd_decoder *d) {
   if (!d) return;
-  (void)hipSetDevice(d->device);
-  if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
+  DeviceGuard guard_(d->device);
+  if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->ev3); }
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
   d->dbg.release(); d->tl.release();
@@ -919,7 +958,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(d->mu);
   hipStream_t stream = (hipStream_t)stream_;
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
   if (B == 0) return CTCD_OK;
   const Dims dims = make_dims(beam, V, cutoff_top_n, cutoff_prob);
   if (dims.S_max() > 65535)
@@ -958,6 +997,9 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   const long long pool_stride = (long long)beam * T + 1;
   if (!sc && (rc = d->pool.ensure((size_t)B * pool_stride * (sizeof(PoolNode) + sizeof(int))))) return rc;
   if ((rc = d->status.ensure((size_t)B * 4))) return rc;
+  // every status word starts as -1 ("no result"): a workgroup that never ran cannot read back as ST_OK
+  HIP_TRY(hipMemsetAsync(d->status.p, 0xff, (size_t)B * 4, stream));
+  d->last_stream = stream;
   // streaming: per-item block pointers, pool capacities and end-of-stream flags go to the device
   char **st_base = nullptr;
   int *st_cap = nullptr;
@@ -985,19 +1027,10 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     // vocabulary prune pass (also converts the kept probabilities to log space when log_input == 0)
     const long long rows = (long long)B * T;
     const int stride = dims.Vc_max;
-    const unsigned cap = 1u << 16;
+    unsigned cap = 1u << 16;
     if ((rc = d->pr_cnt.ensure((size_t)rows * 4))) return rc;
     if ((rc = d->pr_ch.ensure((size_t)rows * stride * 4))) return rc;
     if ((rc = d->pr_lp.ensure((size_t)rows * stride * 4))) return rc;
-    if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
-    unsigned *n_flag = (unsigned *)d->flags.p;
-    unsigned *flag_rows = (unsigned *)((char *)d->flags.p + 8);
-    HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
-    HIP_TRY(hipMemsetAsync(d->pr_cnt.p, 0, (size_t)rows * 4, stream));
-    PruneArgs pa;
-    pa.in = probs; pa.seq_lens = seq_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
-    pa.stride = stride; pa.rows = rows; pa.cutoff_prob = cutoff_prob; pa.cnt = (int *)d->pr_cnt.p; pa.ch = (int *)d->pr_ch.p;
-    pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
     const int wpb = 4;
     const size_t psm = (size_t)wpb * (3 * (size_t)stride + 2 * kPruneCand) * 4;
     if (psm > (size_t)d->max_lds) return fail(CTCD_EUNSUPPORTED, "cutoff_top_n too large for the prune pass");
@@ -1006,72 +1039,105 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
                     : V <= 1024 ? (const void *)prune_rows_kernel<16> : V <= 4096 ? (const void *)prune_rows_kernel<64>
                     : V <= 10240 ? (const void *)prune_rows_kernel<160> : (const void *)prune_rows_kernel<0>;
     HIP_TRY(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm));
-    void *pargs[] = {&pa};
-    HIP_TRY(hipLaunchKernel(pfn, dim3(blocks), dim3(wpb * 64), pargs, psm, stream));
-    HIP_TRY(hipGetLastError());
     unsigned nf = 0;
-    HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (nf > cap) return fail(CTCD_EUNSUPPORTED, "more than 65536 frames with tied / borderline values in one call");
-    if (nf) {  // toolchain-defined cases: let the toolchain decide (real std::sort, real libm) -- batched transfers
+    unsigned *n_flag = nullptr, *flag_rows = nullptr;
+    d->prune_timed = false;
+    for (int attempt = 0; attempt < 2; ++attempt) {  // (a second pass only when more frames were flagged than the list held)
+      if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
+      n_flag = (unsigned *)d->flags.p;
+      flag_rows = (unsigned *)((char *)d->flags.p + 8);
+      HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
+      HIP_TRY(hipMemsetAsync(d->pr_cnt.p, 0, (size_t)rows * 4, stream));
+      PruneArgs pa;
+      pa.in = probs; pa.seq_lens = seq_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
+      pa.stride = stride; pa.rows = rows; pa.cutoff_prob = cutoff_prob; pa.cnt = (int *)d->pr_cnt.p; pa.ch = (int *)d->pr_ch.p;
+      pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
+      void *pargs[] = {&pa};
+      if (d->timing) HIP_TRY(hipEventRecord(d->ev2, stream));
+      HIP_TRY(hipLaunchKernel(pfn, dim3(blocks), dim3(wpb * 64), pargs, psm, stream));
+      HIP_TRY(hipGetLastError());
+      if (d->timing) { HIP_TRY(hipEventRecord(d->ev3, stream)); d->prune_timed = true; }
+      HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (nf <= cap) break;
+      cap = nf;  // the set of flagged frames is a function of the input: the list now holds all of them
+    }
+    if (nf > cap) return fail(CTCD_EINTERNAL, "flagged-frame count changed between two passes over the same input");
+    if (nf) {  // toolchain-defined cases: let the toolchain decide (real std::sort, real libm) -- batched transfers, in
+               // chunks so that the staging memory stays bounded however many frames are flagged
       std::vector<unsigned> fr(nf);
       HIP_TRY(hipMemcpy(fr.data(), flag_rows, (size_t)nf * 4, hipMemcpyDeviceToHost));
       const size_t rec = 1 + 2 * (size_t)stride;  // per frame: count, labels, log-probs
-      if ((rc = d->prune_in.ensure((size_t)nf * V * 4))) return rc;
-      if ((rc = d->prune_out.ensure((size_t)nf * rec * 4))) return rc;
-      hipLaunchKernelGGL(gather_rows_kernel, dim3(nf), dim3(256), 0, stream, probs, flag_rows, V, (float *)d->prune_in.p);
-      HIP_TRY(hipGetLastError());
-      std::vector<float> rowsh((size_t)nf * V);
-      HIP_TRY(hipMemcpyAsync(rowsh.data(), d->prune_in.p, rowsh.size() * 4, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      std::vector<int32_t> recs((size_t)nf * rec, 0);
-      {  // the flagged frames are independent: one host thread each (up to the core count)
-        std::atomic<unsigned> next{0};
-        auto work = [&] {
-          for (;;) {
-            const unsigned k = next.fetch_add(1);
-            if (k >= nf) return;
-            int32_t *rr = recs.data() + (size_t)k * rec;
-            rr[0] = host_prune_row(rowsh.data() + (size_t)k * V, V, cutoff_prob, cutoff_top_n, log_input, rr + 1, (float *)(rr + 1 + stride));
-          }
-        };
-        const unsigned nth = std::min<unsigned>(nf, std::max(1u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> pool;
-        for (unsigned i = 1; i < nth; ++i) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
+      const unsigned chunk = (unsigned)std::max<size_t>(64, std::min<size_t>(nf, ((size_t)256 << 20) / ((size_t)V * 4)));
+      if ((rc = d->prune_in.ensure((size_t)chunk * V * 4))) return rc;
+      if ((rc = d->prune_out.ensure((size_t)chunk * rec * 4))) return rc;
+      std::vector<float> rowsh((size_t)chunk * V);
+      std::vector<int32_t> recs((size_t)chunk * rec);
+      for (unsigned c0 = 0; c0 < nf; c0 += chunk) {
+        const unsigned cn = std::min(chunk, nf - c0);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(cn), dim3(256), 0, stream, probs, flag_rows + c0, V, (float *)d->prune_in.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(rowsh.data(), d->prune_in.p, (size_t)cn * V * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::fill(recs.begin(), recs.begin() + (size_t)cn * rec, 0);
+        {  // the flagged frames are independent: one host thread each (up to the core count)
+          std::atomic<unsigned> next{0};
+          auto work = [&] {
+            for (;;) {
+              const unsigned k = next.fetch_add(1);
+              if (k >= cn) return;
+              int32_t *rr = recs.data() + (size_t)k * rec;
+              rr[0] = host_prune_row(rowsh.data() + (size_t)k * V, V, cutoff_prob, cutoff_top_n, log_input, rr + 1, (float *)(rr + 1 + stride));
+            }
+          };
+          const unsigned nth = std::min<unsigned>(cn, std::max(1u, std::thread::hardware_concurrency()));
+          std::vector<std::thread> pool;
+          for (unsigned i = 1; i < nth; ++i) pool.emplace_back(work);
+          work();
+          for (auto &t : pool) t.join();
+        }
+        HIP_TRY(hipMemcpyAsync(d->prune_out.p, recs.data(), (size_t)cn * rec * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(scatter_pruned_kernel, dim3(cn), dim3(64), 0, stream, (const int32_t *)d->prune_out.p, flag_rows + c0, stride,
+                           (int *)d->pr_cnt.p, (int *)d->pr_ch.p, (float *)d->pr_lp.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));  // recs (host memory) is reused by the next chunk
       }
-      HIP_TRY(hipMemcpyAsync(d->prune_out.p, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(scatter_pruned_kernel, dim3(nf), dim3(64), 0, stream, (const int32_t *)d->prune_out.p, flag_rows, stride,
-                         (int *)d->pr_cnt.p, (int *)d->pr_ch.p, (float *)d->pr_lp.p);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipStreamSynchronize(stream));  // recs (host memory) must outlive the copy
       d->prune_host_rows = nf;
     }
   } else if (!log_input && T > 0) {
     const size_t n = (size_t)B * T * V;
-    const unsigned cap = 1u << 16;
+    unsigned cap = 1u << 16;
     if ((rc = d->logp.ensure(n * 4))) return rc;
-    if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
-    unsigned *n_flag = (unsigned *)d->flags.p;
-    unsigned long long *idx = (unsigned long long *)((char *)d->flags.p + 8);
-    HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
-    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(prob_to_log_kernel, dim3(blocks), dim3(256), 0, stream, probs, (float *)d->logp.p, n, n_flag, idx, cap);
-    HIP_TRY(hipGetLastError());
     unsigned nf = 0;
-    HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (nf > cap) return fail(CTCD_EINTERNAL, "too many non-finite / borderline probabilities");
-    if (nf) {  // borderline roundings: recompute with the C library the reference binds to
-      std::vector<unsigned long long> hi(nf);
-      HIP_TRY(hipMemcpy(hi.data(), idx, (size_t)nf * 8, hipMemcpyDeviceToHost));
-      for (unsigned k = 0; k < nf; ++k) {
-        float p, v;
-        HIP_TRY(hipMemcpy(&p, probs + hi[k], 4, hipMemcpyDeviceToHost));
-        v = (float)std::log((double)p + (double)FLT_MIN);
-        HIP_TRY(hipMemcpy((float *)d->logp.p + hi[k], &v, 4, hipMemcpyHostToDevice));
-      }
+    unsigned *n_flag = nullptr;
+    unsigned long long *idx = nullptr;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
+      n_flag = (unsigned *)d->flags.p;
+      idx = (unsigned long long *)((char *)d->flags.p + 8);
+      HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
+      if (seq_lens) HIP_TRY(hipMemsetAsync(d->logp.p, 0, n * 4, stream));  // frames past an utterance's end stay defined
+      hipLaunchKernelGGL(prob_to_log_kernel, dim3(blocks), dim3(256), 0, stream, probs, (float *)d->logp.p, n, seq_lens, T, V, n_flag, idx, cap);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (nf <= cap) break;
+      cap = nf;
+    }
+    if (nf > cap) return fail(CTCD_EINTERNAL, "flagged-element count changed between two passes over the same input");
+    if (nf) {  // borderline roundings (and non-finite values): recompute with the C library the reference binds to
+      if ((rc = d->prune_in.ensure((size_t)nf * 4))) return rc;
+      std::vector<float> vals(nf);
+      hipLaunchKernelGGL(gather_elems_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, probs, idx, nf, (float *)d->prune_in.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(vals.data(), d->prune_in.p, (size_t)nf * 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      for (unsigned k = 0; k < nf; ++k) vals[k] = (float)std::log((double)vals[k] + (double)FLT_MIN);
+      HIP_TRY(hipMemcpyAsync(d->prune_in.p, vals.data(), (size_t)nf * 4, hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(scatter_elems_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, (const float *)d->prune_in.p, idx, nf, (float *)d->logp.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(stream));  // vals (host memory) must outlive the copy
     }
     logp = (const float *)d->logp.p;
   }
@@ -1144,8 +1210,9 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
 // ---- streaming: DecoderState kept between calls (ctcdecode/__init__.py:143-272, binding.cpp:153-265)
 int ctcd_stream_create(ctcd_decoder *d, ctcd_stream **out, int V, int beam, int frames_hint) {
   if (!d || !out || V <= 0 || beam <= 0 || beam > kMaxBeam) return fail(CTCD_EINVAL, "bad stream parameters");
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
   ctcd_stream *st = new ctcd_stream;
+  st->device = d->device;
   st->V = V;
   st->beam = beam;
   st->cap_frames = frames_hint > 0 ? frames_hint : 1024;
@@ -1160,7 +1227,7 @@ int ctcd_stream_create(ctcd_decoder *d, ctcd_stream **out, int V, int beam, int 
 
 void ctcd_stream_destroy(ctcd_decoder *d, ctcd_stream *st) {
   if (!st) return;
-  if (d) (void)hipSetDevice(d->device);
+  DeviceGuard guard_(st->device);
   if (st->block) (void)hipFree(st->block);
   delete st;
 }
@@ -1173,7 +1240,7 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
                        int32_t *out_len, int32_t *n_results, int out_T, void *stream_) {
   if (!d || !states || !is_eos || B < 0 || T < 0 || out_T < 0) return fail(CTCD_EINVAL, "bad arguments");
   if (B == 0) return CTCD_OK;
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
   hipStream_t stream = (hipStream_t)stream_;
   std::vector<int32_t> lens(B);
   for (int b = 0; b < B; ++b) {
@@ -1222,7 +1289,7 @@ int ctcd_beam_decode_host(ctcd_decoder *d, const float *probs, const int32_t *se
   int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, out_tok, out_ts, out_sc, out_len);
   if (rc) return rc;
   if (B == 0) return CTCD_OK;
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
   const size_t nin = (size_t)B * T * V * 4, kt = (size_t)B * beam * T * 4, kk = (size_t)B * beam * 4;
   const size_t off_sl = (nin + 15) / 16 * 16;
   if ((rc = d->stage_in.ensure(off_sl + (size_t)B * 4 + 16))) return rc;
@@ -1235,11 +1302,8 @@ int ctcd_beam_decode_host(ctcd_decoder *d, const float *probs, const int32_t *se
                         cutoff_prob, cutoff_top_n, blank_id, log_input, (int32_t *)dout, (int32_t *)(dout + o_ts),
                         (float *)(dout + o_sc), (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), nullptr);
   if (rc) return rc;
+  if ((rc = ctcd_check_status(d, B))) return rc;
   HIP_TRY(hipDeviceSynchronize());
-  std::vector<int32_t> st(B);
-  HIP_TRY(hipMemcpy(st.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost));
-  for (int b = 0; b < B; ++b)
-    if (st[b] != ST_OK) return fail(CTCD_EINTERNAL, "decoder status " + std::to_string(st[b]) + " for item " + std::to_string(b));
   if (kt) {
     HIP_TRY(hipMemcpy(out_tok, dout, kt, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_ts, dout + o_ts, kt, hipMemcpyDeviceToHost));
@@ -1253,10 +1317,12 @@ int ctcd_beam_decode_host(ctcd_decoder *d, const float *probs, const int32_t *se
 // HIP-event timing of the decode kernel alone, on the stream it is launched on (bench.py's roofline figure).
 int ctcd_set_timing(ctcd_decoder *d, int on) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
   if (on && !d->ev0) {
     HIP_TRY(hipEventCreate(&d->ev0));
     HIP_TRY(hipEventCreate(&d->ev1));
+    HIP_TRY(hipEventCreate(&d->ev2));
+    HIP_TRY(hipEventCreate(&d->ev3));
   }
   d->timing = on != 0;
   return CTCD_OK;
@@ -1266,6 +1332,15 @@ int ctcd_last_kernel_ms(ctcd_decoder *d, float *ms) {
   if (!d || !ms || !d->ev0) return fail(CTCD_EINVAL, "timing not enabled");
   HIP_TRY(hipEventSynchronize(d->ev1));
   HIP_TRY(hipEventElapsedTime(ms, d->ev0, d->ev1));
+  return CTCD_OK;
+}
+
+// Duration of the vocabulary-prune kernel of the last decode (pruned configurations only; timing must be on).
+int ctcd_last_prune_ms(ctcd_decoder *d, float *ms) {
+  if (!d || !ms || !d->ev2 || !d->prune_timed) return fail(CTCD_EINVAL, "no timed prune pass");
+  CTC_ON_DEVICE(d->device);
+  HIP_TRY(hipEventSynchronize(d->ev3));
+  HIP_TRY(hipEventElapsedTime(ms, d->ev2, d->ev3));
   return CTCD_OK;
 }
 
@@ -1293,7 +1368,7 @@ int ctcd_debug_timeline(ctcd_decoder *d, int frame0, int nframes, long long *out
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   if (!out) { d->tl_f0 = frame0; d->tl_nf = nframes; d->tl_armed = nframes > 0; return CTCD_OK; }
   if (!d->tl.p) return fail(CTCD_EINVAL, "no timeline recorded");
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, d->tl.p, (size_t)16 * kTimelineCap * 8, hipMemcpyDeviceToHost));
   return CTCD_OK;
@@ -1304,7 +1379,7 @@ int ctcd_debug_beam_dump(ctcd_decoder *d, int on, int *out, int T, int beam) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   d->dbg_on = on != 0;
   if (out && d->dbg.p) {
-    HIP_TRY(hipSetDevice(d->device));
+    CTC_ON_DEVICE(d->device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, d->dbg.p, (size_t)T * (1 + 4 * (size_t)beam) * 4, hipMemcpyDeviceToHost));
   }
@@ -1313,7 +1388,7 @@ int ctcd_debug_beam_dump(ctcd_decoder *d, int on, int *out, int T, int beam) {
 
 int ctcd_debug_get_profile(ctcd_decoder *d, long long *out, int B) {
   if (!d || !out || B <= 0 || !d->prof.p) return fail(CTCD_EINVAL, "no profile recorded");
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, d->prof.p, (size_t)B * 16 * 8, hipMemcpyDeviceToHost));
   return CTCD_OK;
@@ -1331,9 +1406,12 @@ long long ctcd_last_prune_host_rows(ctcd_decoder *d) { return d ? d->prune_host_
 int ctcd_check_status(ctcd_decoder *d, int B) {
   if (!d || B < 0) return fail(CTCD_EINVAL, "bad arguments");
   if (B == 0) return CTCD_OK;
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
+  if (!d->status.p || d->status.cap < (size_t)B * 4) return fail(CTCD_EINVAL, "no decode of that many items has been launched");
   std::vector<int32_t> st(B);
-  HIP_TRY(hipMemcpy(st.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+  // ordered after the kernel on the stream it was launched on (a null-stream copy would not wait for a non-blocking stream)
+  HIP_TRY(hipMemcpyAsync(st.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, d->last_stream));
+  HIP_TRY(hipStreamSynchronize(d->last_stream));
   for (int b = 0; b < B; ++b)
     if (st[b] != ST_OK) return fail(CTCD_EINTERNAL, "decoder status " + std::to_string(st[b]) + " for item " + std::to_string(b));
   return CTCD_OK;
@@ -1342,7 +1420,7 @@ int ctcd_check_status(ctcd_decoder *d, int B) {
 int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,
                           const float *ys, long long n_pairs, long long *checked, long long *mismatches) {
   if (!d || !checked || !mismatches || stride == 0) return fail(CTCD_EINVAL, "bad arguments");
-  HIP_TRY(hipSetDevice(d->device));
+  CTC_ON_DEVICE(d->device);
   int rc;
   if (!d->tables_ready) {
     if ((rc = d->tables.ensure(sizeof(ctcmath::Tables)))) return rc;

@@ -15,7 +15,7 @@
 // tools/extract_libm_tables.py).  All arithmetic is IEEE binary64 add/mul/fma,
 // which gfx950 implements exactly, so host and device agree by construction.
 // tests/test_exact_math.py checks the host build against libm exhaustively on
-// the log-sum-exp domain; tests/test_gpu_math.py does the same for the device
+// the log-sum-exp domain; tests/test_gpu_decode.py::test_device_math_bit_exact_vs_host_libm does the same for the device
 // build against the GPU box's own libm.
 //
 // Build note: compile with -ffp-contract=off.  Every fused operation below is

@@ -24,7 +24,10 @@ def gather_results(results, batch, dst=0, group=None):
     rank = dist.get_rank(group)
     per = (batch + world - 1) // world
     out = []
+    host_only = dist.get_backend(group) == "gloo"  # gloo gathers host tensors only
     for t in results:
+        if host_only and t.is_cuda:
+            t = t.cpu()
         if t.shape[0] < per:
             pad = torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             t = torch.cat([t, pad], 0)
@@ -63,6 +66,9 @@ class ResultGatherer(object):
         self.depth = max(1, depth)
         self._inflight = []
         self._recv = None
+        self._host_only = dist.get_backend(group) == "gloo"  # gloo gathers host tensors only (single-device dry runs)
+        if self._host_only:
+            device = torch.device("cpu")
         if self.rank == dst:
             self._recv = [[[torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world)] for shape, dtype in shard_shapes_dtypes]
                           for _ in range(self.depth)]
@@ -76,6 +82,8 @@ class ResultGatherer(object):
                 wk.wait()
         works = []
         for i, t in enumerate(results):
+            if self._host_only and t.is_cuda:
+                t = t.cpu()
             works.append(dist.gather(t.contiguous(), self._recv[slot][i] if self.rank == self.dst else None, dst=self.dst,
                                      group=self.group, async_op=True))
         self._inflight.append((works, results))  # keep the source tensors alive until the collective has read them
@@ -91,3 +99,11 @@ class ResultGatherer(object):
     def received(self, slot):
         """On ``dst``: the per-rank parts of the batch submitted into ``slot`` (valid after its gather completed)."""
         return self._recv[slot] if self._recv is not None else None
+
+
+def make_gatherer(fmt, B, K, T, V, device, dst=0, group=None, depth=2):
+    """The gatherer bench.py / a serving loop uses: ``fmt`` = "full" (the four padded tensors travel) or "compact"."""
+    if fmt == "full":
+        shapes = [((B, K, T), torch.int32), ((B, K), torch.float32), ((B, K, T), torch.int32), ((B, K), torch.int32)]
+        return ResultGatherer(shapes, device, dst=dst, group=group, depth=depth)
+    raise ValueError("unknown gather format %r" % (fmt,))

@@ -86,6 +86,7 @@ long long ctcd_last_prune_host_rows(ctcd_decoder *dec);
 /* HIP-event timing of the decode kernel alone (events recorded on the launch stream). */
 int ctcd_set_timing(ctcd_decoder *dec, int on);
 int ctcd_last_kernel_ms(ctcd_decoder *dec, float *ms);
+int ctcd_last_prune_ms(ctcd_decoder *dec, float *ms); /* the vocabulary-prune kernel of the same call (pruned configurations) */
 
 /* Test hook: device expf/logf/log_sum_exp (exact_math.h) vs the host C library over float bit patterns. */
 int ctcd_debug_math_check(ctcd_decoder *dec, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,

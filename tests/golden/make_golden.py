@@ -47,6 +47,14 @@ def cases():
     yield "topn_v64_n8_b2_t80_k20", dict(probs=ou.synth_logprobs(2, 80, 64, 6), beam=20, blank_id=0, log_input=True, cutoff_top_n=8, cutoff_prob=1.0)
     yield "ragged_b5_t60_k16", dict(probs=ou.synth_logprobs(5, 60, 29, 7), seq_lens=np.array([60, 0, 1, 37, 99], np.int32), beam=16, blank_id=0, log_input=True, cutoff_top_n=40, cutoff_prob=1.0)
     yield "tiny_b2_t2_v3_k50", dict(probs=ou.synth_logprobs(2, 2, 3, 8), beam=50, blank_id=1, log_input=True, cutoff_top_n=40, cutoff_prob=1.0)
+    # N4: the cumulative-probability cut where it really triggers, probability input with top_n, and the
+    # BASELINE.json configs[3] setting (top_n 40, cutoff_prob 0.99) at a four-digit vocabulary
+    yield "cutprob05_b2_t120_k24", dict(probs=ou.synth_logprobs(2, 120, 29, 10), beam=24, blank_id=0, log_input=True, cutoff_top_n=40, cutoff_prob=0.5)
+    yield "cutprob06_n10_b2_t120_k24", dict(probs=ou.synth_logprobs(2, 120, 29, 11), beam=24, blank_id=0, log_input=True, cutoff_top_n=10, cutoff_prob=0.6)
+    yield "probin_n6_v40_b2_t100_k16", dict(probs=np.exp(ou.synth_logprobs(2, 100, 40, 12)), beam=16, blank_id=0, log_input=False, cutoff_top_n=6, cutoff_prob=1.0)
+    yield "probin_cut055_v40_b2_t100_k16", dict(probs=np.exp(ou.synth_logprobs(2, 100, 40, 13)), beam=16, blank_id=0, log_input=False, cutoff_top_n=40, cutoff_prob=0.55)
+    yield "v1000_n40_cut099_b2_t60_k20", dict(probs=ou.synth_logprobs(2, 60, 1000, 14), beam=20, blank_id=0, log_input=True, cutoff_top_n=40, cutoff_prob=0.99)
+    yield "topn_ties_v64_n8_b2_t80_k20", dict(probs=ou.synth_logprobs(2, 80, 64, 15, quant=0.5), beam=20, blank_id=0, log_input=True, cutoff_top_n=8, cutoff_prob=1.0)
     yield "long_b1_t600_k60", dict(probs=ou.synth_logprobs(1, 600, 29, 9), beam=60, blank_id=0, log_input=True, cutoff_top_n=40, cutoff_prob=1.0)
 
 

@@ -63,3 +63,12 @@ def test_product_does_not_touch_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle/" not in text.replace("oracle/ (", "").replace("under oracle/", "") or f == "__init__.py", f
                 assert "libctcoracle" not in text and "libctcref" not in text, f
+
+
+def test_reference_import_name():
+    """README.md:22-38 of the reference: ``from ctcdecode import CTCBeamDecoder`` (+ the online classes) works unchanged."""
+    import ctcdecode
+    import ctcdecode_amd
+
+    assert ctcdecode.CTCBeamDecoder is ctcdecode_amd.CTCBeamDecoder
+    assert ctcdecode.OnlineCTCBeamDecoder is ctcdecode_amd.OnlineCTCBeamDecoder and ctcdecode.DecoderState is ctcdecode_amd.DecoderState

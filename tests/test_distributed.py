@@ -138,3 +138,72 @@ def test_pipelined_gatherer_gloo_world2():
         p.join(180)
         assert p.exitcode == 0
     assert dict(ret) == {0: True, 1: True}
+
+
+def _gpu_worker(rank, world, port, B, ret):
+    """Both ranks on cuda:0 (the GPU box has one device), gloo rendezvous: the per-rank decode is the real HIP path."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import oracle_util as ou
+
+    import ctcdecode_amd
+    from ctcdecode_amd import distributed as dd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, V, K = 120, 29, 24
+    lp_np = ou.synth_logprobs(B, T, V, 4242)
+    sl_np = np.array([(37 * i) % (T + 5) for i in range(B)], np.int32)
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], beam_width=K, log_probs_input=True, device="cuda:0")
+
+    def decode_fn(p, s):  # HIP decode of this rank's block; gloo gathers host tensors
+        return tuple(t.cpu() for t in dec.decode_device(p, s))
+
+    got = dd.decode_sharded(decode_fn, torch.from_numpy(lp_np), torch.from_numpy(sl_np), dst=0)
+    ok = got is None
+    if rank == 0:
+        want = ou.decode(lp_np, sl_np, beam=K)
+        mine = dict(tokens=got[0].numpy(), scores=got[1].numpy(), timesteps=got[2].numpy(), lens=got[3].numpy(), nres=want["nres"])
+        ou.assert_same(mine, want, "decode_sharded over 2 ranks")
+        ok = True
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [7, 2])
+def test_sharded_decode_real_hip_world2(B):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_gpu_worker, args=(r, 2, port, B, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (they share the one device
+    of this box over gloo -- a dry run of the N-rank path) and rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+                        "--frames", "200", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["config"]["ranks"] == 2 and d["value"] > 0 and d["config"]["global_batch"] == 64

@@ -63,6 +63,15 @@ CASES = [
     dict(B=2, T=150, V=29, K=20, seed=15, blank_bias=5.0),
     dict(B=2, T=60, V=200, K=16, seed=16, top_n=12),
     dict(B=1, T=500, V=29, K=100, seed=17),
+    # vocabulary pruning as implemented (decoder_utils.cpp:10-45): the cumulative cut really triggers below ln 2
+    dict(B=2, T=120, V=29, K=24, seed=18, top_n=40, cutoff_prob=0.5),
+    dict(B=2, T=120, V=29, K=24, seed=19, top_n=10, cutoff_prob=0.6),
+    dict(B=2, T=100, V=40, K=16, seed=20, top_n=6, prob_input=True),
+    dict(B=2, T=100, V=40, K=16, seed=21, top_n=40, cutoff_prob=0.55, prob_input=True),
+    dict(B=2, T=60, V=1000, K=20, seed=22, top_n=40, cutoff_prob=0.99),
+    dict(B=2, T=80, V=64, K=20, seed=23, top_n=8, quant=0.5),            # equal values at the cut: std::sort's order decides
+    dict(B=2, T=80, V=29, K=20, seed=24, top_n=40, cutoff_prob=0.6, quant=0.25),
+    dict(B=2, T=50, V=64, K=8, seed=25, top_n=1),
 ]
 
 
@@ -71,8 +80,9 @@ CASES = [
 def test_live_differential(c):
     blank = c.get("blank_id", 0)
     lp = ou.synth_logprobs(c["B"], c["T"], c["V"], c["seed"], quant=c.get("quant"), blank_bias=c.get("blank_bias", 0.0), blank_id=blank)
-    kw = dict(beam=c["K"], cutoff_top_n=c.get("top_n", 40), blank_id=blank, log_input=True)
-    ou.assert_same(ou.decode(lp, which="restated", **kw), ou.decode(lp, which="reference", **kw))
+    x = np.exp(lp) if c.get("prob_input") else lp
+    kw = dict(beam=c["K"], cutoff_top_n=c.get("top_n", 40), cutoff_prob=c.get("cutoff_prob", 1.0), blank_id=blank, log_input=not c.get("prob_input"))
+    ou.assert_same(ou.decode(x, which="restated", **kw), ou.decode(x, which="reference", **kw))
 
 
 def test_prob_and_log_input_agree_on_labels():
