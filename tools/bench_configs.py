@@ -35,19 +35,28 @@ def run(torch, ctcdecode_amd, name, B, T, V, K, top_n=40, cutoff_prob=1.0, blank
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="", help="digits of the BASELINE.json configs to run (e.g. 23); default all")
+    ap.add_argument("--reps", type=int, default=0)
     a = ap.parse_args()
     import torch
 
     import ctcdecode_amd
 
     out = []
-    out.append(run(torch, ctcdecode_amd, "configs[0] shape (log input)", 4, 100, 29, 10))
-    out.append(run(torch, ctcdecode_amd, "configs[1]", 256, 1000, 29, 100))
-    out.append(run(torch, ctcdecode_amd, "configs[1] blank-dominated (+6 on the blank logit)", 256, 1000, 29, 100, blank_bias=6.0))
-    out.append(run(torch, ctcdecode_amd, "configs[1] blank +3", 256, 1000, 29, 100, blank_bias=3.0))
-    out.append(run(torch, ctcdecode_amd, "configs[2] per-GPU shape (256 of 2048 utterances)", 256, 2000, 29, 500, reps=1))
-    out.append(run(torch, ctcdecode_amd, "configs[3]", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99))
-    out.append(run(torch, ctcdecode_amd, "configs[4] shape without the LM (128 of 1024 utterances)", 128, 1500, 29, 100))
+    want = lambda i: not a.only or str(i) in a.only  # noqa: E731
+    rp = lambda d: a.reps or d  # noqa: E731
+    if want(0):
+        out.append(run(torch, ctcdecode_amd, "configs[0] shape (log input)", 4, 100, 29, 10, reps=rp(3)))
+    if want(1):
+        out.append(run(torch, ctcdecode_amd, "configs[1]", 256, 1000, 29, 100, reps=rp(3)))
+        out.append(run(torch, ctcdecode_amd, "configs[1] blank-dominated (+6 on the blank logit)", 256, 1000, 29, 100, blank_bias=6.0, reps=rp(3)))
+        out.append(run(torch, ctcdecode_amd, "configs[1] blank +3", 256, 1000, 29, 100, blank_bias=3.0, reps=rp(3)))
+    if want(2):
+        out.append(run(torch, ctcdecode_amd, "configs[2] per-GPU shape (256 of 2048 utterances)", 256, 2000, 29, 500, reps=1))
+    if want(3):
+        out.append(run(torch, ctcdecode_amd, "configs[3]", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99, reps=rp(3)))
+    if want(4):
+        out.append(run(torch, ctcdecode_amd, "configs[4] shape without the LM (128 of 1024 utterances)", 128, 1500, 29, 100, reps=rp(3)))
     if a.out:
         json.dump(out, open(a.out, "w"), indent=1)
 
