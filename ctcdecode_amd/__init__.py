@@ -12,6 +12,29 @@ from . import _native
 from ._native import NativeError  # noqa: F401
 
 __all__ = ["CTCBeamDecoder", "OnlineCTCBeamDecoder", "DecoderState", "NativeError"]
+HAVE_LM = True  # the external-scorer tier (model_path / alpha / beta) is part of this build
+
+
+class _Scorer(object):
+    """ctypes owner of a ``ctcd_scorer`` (paddle_get_scorer / paddle_release_scorer, ctcdecode/__init__.py:47-50,138-140)."""
+
+    def __init__(self, alpha, beta, model_path, labels, device_index):
+        if isinstance(model_path, bytes):
+            model_path = model_path.decode("utf-8")
+        arr = (ctypes.c_char_p * len(labels))(*[str(x).encode("utf-8") for x in labels])
+        h = ctypes.c_void_p()
+        _native.check(_native.lib.ctcd_scorer_create(ctypes.byref(h), float(alpha), float(beta), str(model_path).encode("utf-8"), arr,
+                                                     len(labels), int(device_index)))
+        self.handle = h
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                _native.lib.ctcd_scorer_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
 
 
 def _to_host(tensors):
@@ -34,7 +57,8 @@ class CTCBeamDecoder(object):
       * ``device``: the MI355X to decode on (default: ``cuda:<current>``).
       * ``decode_device()`` returns the four tensors in HBM without the device->host copy.
       * positions the reference leaves uninitialised (``[b, p, out_len:]``, rows ``p >= #results``) are zero.
-      * a language model (``model_path``) is not part of this build: NotImplementedError.
+      * ``model_path`` must be an ARPA text model (binary kenlm files are not supported); the scorer's tables are mirrored
+        into HBM and queried inside the decode kernel (include/ctcdecode_amd.h, "LM tier").
     """
 
     def __init__(self, labels, model_path=None, alpha=0, beta=0, cutoff_top_n=40, cutoff_prob=1.0, beam_width=100,
@@ -48,8 +72,6 @@ class CTCBeamDecoder(object):
         self._blank_id = blank_id
         self._log_probs = 1 if log_probs_input else 0
         self._cutoff_prob = cutoff_prob
-        if model_path is not None:
-            raise NotImplementedError("ctcdecode_amd: the KenLM scorer tier (model_path) is not built; decode without a language model")
         if not torch.cuda.is_available():
             raise RuntimeError("ctcdecode_amd: no HIP device visible; this decoder has no CPU path")
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -60,6 +82,8 @@ class CTCBeamDecoder(object):
         h = ctypes.c_void_p()
         _native.check(_native.lib.ctcd_create(ctypes.byref(h), self._device.index))
         self._handle = h
+        if model_path is not None:  # ctcdecode/__init__.py:47-50
+            self._scorer = _Scorer(alpha, beta, model_path, self._labels, self._device.index)
 
     def set_threads(self, n):
         _native.check(_native.lib.ctcd_set_threads(self._handle, int(n)))
@@ -101,10 +125,16 @@ class CTCBeamDecoder(object):
             scores = torch.empty((B, K), dtype=torch.float32, device=self._device)
             out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
             stream = torch.cuda.current_stream(self._device).cuda_stream
-            _native.check(_native.lib.ctcd_beam_decode(
-                self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K,
-                self._num_processes, float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
-                output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), None, stream))
+            if self._scorer is not None:  # ctcdecode/__init__.py:87-104 (paddle_beam_decode_lm)
+                _native.check(_native.lib.ctcd_beam_decode_lm(
+                    self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K,
+                    self._num_processes, float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
+                    self._scorer.handle, output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), None, stream))
+            else:
+                _native.check(_native.lib.ctcd_beam_decode(
+                    self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K,
+                    self._num_processes, float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
+                    output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), None, stream))
             if check:
                 _native.check(_native.lib.ctcd_check_status(self._handle, B))
         return output, scores, timesteps, out_len
@@ -114,17 +144,18 @@ class CTCBeamDecoder(object):
         res = self.decode_device(probs, seq_lens)
         return _to_host(res)
 
-    def character_based(self):
-        return None  # ctcdecode/__init__.py:125-126 without a scorer
+    def character_based(self):  # ctcdecode/__init__.py:125-136: None without a scorer
+        return bool(_native.lib.ctcd_scorer_is_character_based(self._scorer.handle)) if self._scorer else None
 
     def max_order(self):
-        return None
+        return int(_native.lib.ctcd_scorer_max_order(self._scorer.handle)) if self._scorer else None
 
     def dict_size(self):
-        return None
+        return int(_native.lib.ctcd_scorer_dict_size(self._scorer.handle)) if self._scorer else None
 
     def reset_params(self, alpha, beta):
-        return None
+        if self._scorer is not None:
+            _native.check(_native.lib.ctcd_scorer_reset_params(self._scorer.handle, float(alpha), float(beta)))
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -152,8 +183,6 @@ class OnlineCTCBeamDecoder(object):
         self._blank_id = blank_id
         self._log_probs = 1 if log_probs_input else 0
         self._cutoff_prob = cutoff_prob
-        if model_path:
-            raise NotImplementedError("ctcdecode_amd: the KenLM scorer tier (model_path) is not built; decode without a language model")
         if not torch.cuda.is_available():
             raise RuntimeError("ctcdecode_amd: no HIP device visible; this decoder has no CPU path")
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -162,6 +191,8 @@ class OnlineCTCBeamDecoder(object):
         h = ctypes.c_void_p()
         _native.check(_native.lib.ctcd_create(ctypes.byref(h), self._device.index))
         self._handle = h
+        if model_path:  # ctcdecode/__init__.py:183-187
+            self._scorer = _Scorer(alpha, beta, model_path, self._labels, self._device.index)
 
     def decode(self, probs, states, is_eos_s, seq_lens=None):
         """Same contract as ctcdecode/__init__.py:189-238: returns CPU tensors (beam_results[B, R, L], beam_scores[B, K],
@@ -204,13 +235,17 @@ class OnlineCTCBeamDecoder(object):
         return _to_host((output[:, :R, :L].contiguous(), scores, timesteps[:, :R, :L].contiguous(), out_len))
 
     def character_based(self):
-        return None
+        return bool(_native.lib.ctcd_scorer_is_character_based(self._scorer.handle)) if self._scorer else None
 
     def max_order(self):
-        return None
+        return int(_native.lib.ctcd_scorer_max_order(self._scorer.handle)) if self._scorer else None
 
     def dict_size(self):
-        return None
+        return int(_native.lib.ctcd_scorer_dict_size(self._scorer.handle)) if self._scorer else None
+
+    def reset_params(self, alpha, beta):
+        if self._scorer is not None:
+            _native.check(_native.lib.ctcd_scorer_reset_params(self._scorer.handle, float(alpha), float(beta)))
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -229,7 +264,9 @@ class DecoderState(object):
     def __init__(self, decoder):
         self._decoder = decoder
         h = ctypes.c_void_p()
-        _native.check(_native.lib.ctcd_stream_create(decoder._handle, ctypes.byref(h), decoder._num_labels, decoder._beam_width, 0))
+        sc = getattr(decoder, "_scorer", None)  # ctcdecode/__init__.py:255-269: the state is created with the decoder's scorer
+        _native.check(_native.lib.ctcd_stream_create_lm(decoder._handle, ctypes.byref(h), decoder._num_labels, decoder._beam_width, 0,
+                                                        sc.handle if sc is not None else None))
         self.state = h
 
     def _ptr(self, decoder):

@@ -10,7 +10,9 @@ from . import _build
 _i32p = ctypes.POINTER(ctypes.c_int32)
 _f32p = ctypes.POINTER(ctypes.c_float)
 
-SYMBOLS = ["ctcd_create", "ctcd_destroy", "ctcd_beam_decode", "ctcd_beam_decode_host", "ctcd_check_status", "ctcd_stream_create", "ctcd_stream_destroy", "ctcd_stream_frames", "ctcd_stream_decode", "ctcd_last_prune_host_rows",
+SYMBOLS = ["ctcd_scorer_create", "ctcd_scorer_destroy", "ctcd_scorer_is_character_based", "ctcd_scorer_max_order", "ctcd_scorer_dict_size",
+           "ctcd_scorer_reset_params", "ctcd_scorer_cond_log_prob", "ctcd_beam_decode_lm", "ctcd_beam_decode_lm_host", "ctcd_stream_create_lm",
+           "ctcd_create", "ctcd_destroy", "ctcd_beam_decode", "ctcd_beam_decode_host", "ctcd_check_status", "ctcd_stream_create", "ctcd_stream_destroy", "ctcd_stream_frames", "ctcd_stream_decode", "ctcd_last_prune_host_rows",
            "ctcd_set_threads", "ctcd_set_timing", "ctcd_last_kernel_ms", "ctcd_last_prune_ms", "ctcd_debug_math_check", "ctcd_debug_set_profile", "ctcd_debug_set_fixed_layout", "ctcd_debug_timeline", "ctcd_debug_timeline_cap", "ctcd_debug_get_profile", "ctcd_debug_beam_dump", "ctcd_workgroup_lds_bytes", "ctcd_last_error", "ctcd_version"]
 
 
@@ -55,6 +57,19 @@ def _load():
               ctypes.c_void_p, ctypes.c_void_p]
     lib.ctcd_beam_decode.argtypes = common + [ctypes.c_void_p]
     lib.ctcd_beam_decode_host.argtypes = common
+    lm_common = common[:12] + [ctypes.c_void_p] + common[12:]  # `scorer` sits before the outputs (binding.cpp:122-140)
+    lib.ctcd_beam_decode_lm.argtypes = lm_common + [ctypes.c_void_p]
+    lib.ctcd_beam_decode_lm_host.argtypes = lm_common
+    lib.ctcd_scorer_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_double, ctypes.c_double, ctypes.c_char_p,
+                                       ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int]
+    lib.ctcd_scorer_destroy.argtypes = [ctypes.c_void_p]
+    lib.ctcd_scorer_destroy.restype = None
+    for name in ("ctcd_scorer_is_character_based", "ctcd_scorer_max_order", "ctcd_scorer_dict_size"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+    lib.ctcd_scorer_reset_params.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+    lib.ctcd_scorer_cond_log_prob.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+    lib.ctcd_scorer_cond_log_prob.restype = ctypes.c_double
+    lib.ctcd_stream_create_lm.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     return lib
 
 

@@ -45,6 +45,7 @@
 #include <stdint.h>
 
 #include "exact_math.h"
+#include "lm_tables.h"
 #include "stl_emul.h"
 #if defined(CTC_ASSUME_CHECKED)
 #include <cstdio>
@@ -73,6 +74,9 @@ CTC_HD uint32_t ord_f32(float f) {
   const uint32_t u = ctcmath::f32_to_bits(f + 0.0f);  // -0 + +0 = +0: both zeros get the same key; nothing else changes
   return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
+CTC_HD float unord_f32(uint32_t k) {  // inverse of ord_f32 (the key of either zero gives +0)
+  return ctcmath::bits_to_f32((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
 // info word: [31:16] 0xFFFF-(ch+1) (larger = earlier under "character asc"), [15:14] type, [13:0] beam entry
 CTC_HD uint32_t mk_info(int ch, uint32_t type, int entry) {
   return ((uint32_t)(0xFFFF - (ch + 1)) << 16) | (type << 14) | (uint32_t)entry;
@@ -87,13 +91,21 @@ struct Beam {  // struct-of-arrays, capacity K each
   int *node, *par, *ch, *dep, *lcp, *via, *viaanc, *viach;
   int *up;  // express pointer of the entry's node (see kExpress)
   float *bprev, *nbprev, *score, *lpc;
+  // LM tier only (Dims::lm): the scorer state every prefix carries (lm_tables.h)
+  int *lmst, *lmcl;           // n-gram automaton state, count of in-vocabulary tokens since the last unknown one
+  int *acc_lo, *acc_hi;       // double: sum of the windows' conditional log-probs so far (Scorer::get_log_prob, scorer.cpp:111-120)
+  int *dn, *dmlo, *dmhi, *dfc;  // word models: dictionary node, its label mask and first child
+  int *spc_lo, *spc_hi;       // double: get_log_cond_prob of the window that ends with the word spelled so far (valid when a word ends here)
+  int *spst, *spcl;           // automaton state / clean counter after that word
 };
+constexpr int kBeamArrays = 13, kBeamArraysLm = 12;
 
 struct Dims {
   int K;       // beam width
   int V;       // vocabulary size
   int Vc_max;  // most candidate characters a step can have (V, or cutoff_top_n when pruning)
   int use_rank_table;  // 1 when candidate lists are pruned (rank_of[] needed)
+  int lm;              // 1: decoding with the external scorer (the beam carries the LM arrays)
   CTC_HD int S_max() const { return K * (2 + Vc_max); }
 };
 
@@ -104,7 +116,7 @@ enum {
   VAR_FB0 = 4, VAR_FB1, VAR_FB2, VAR_FB3,   // 16-byte aligned groups: read back with one LDS access (X::uni4)
   VAR_TAU = 8, VAR_G, VAR_E, VAR_SPARE,
   VAR_PAR0 = 12,  // first per-parity set
-  P_NPIN = 0, P_LCOUNT, P_NMAXKEY, P_SIZE = 4,
+  P_NPIN = 0, P_LCOUNT, P_NMAXKEY, P_NMINKEY, P_NCAND, P_SIZE = 8,
   VAR_COUNT = VAR_PAR0 + 2 * P_SIZE
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
@@ -157,7 +169,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   char *p = base;
   const size_t K = (size_t)d.K, S = (size_t)d.S_max();
   Beam *bs[2] = {&w.cur, &w.nxt};
-  w.beam_blk = 13 * (((K * 4 + 15) / 16) * 16);
+  w.beam_blk = (size_t)(kBeamArrays + (d.lm ? kBeamArraysLm : 0)) * (((K * 4 + 15) / 16) * 16);
   for (int i = 0; i < 2; ++i) {
     Beam &b = *bs[i];
     b.node = carve_ptr<int>(p, K); b.par = carve_ptr<int>(p, K); b.ch = carve_ptr<int>(p, K);
@@ -165,6 +177,10 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
     b.viaanc = carve_ptr<int>(p, K); b.viach = carve_ptr<int>(p, K); b.up = carve_ptr<int>(p, K);
     b.bprev = carve_ptr<float>(p, K); b.nbprev = carve_ptr<float>(p, K); b.score = carve_ptr<float>(p, K);
     b.lpc = carve_ptr<float>(p, K);
+    const size_t Kl = d.lm ? K : 0;
+    b.lmst = carve_ptr<int>(p, Kl); b.lmcl = carve_ptr<int>(p, Kl); b.acc_lo = carve_ptr<int>(p, Kl); b.acc_hi = carve_ptr<int>(p, Kl);
+    b.dn = carve_ptr<int>(p, Kl); b.dmlo = carve_ptr<int>(p, Kl); b.dmhi = carve_ptr<int>(p, Kl); b.dfc = carve_ptr<int>(p, Kl);
+    b.spc_lo = carve_ptr<int>(p, Kl); b.spc_hi = carve_ptr<int>(p, Kl); b.spst = carve_ptr<int>(p, Kl); b.spcl = carve_ptr<int>(p, Kl);
   }
   w.beam0 = w.cur;
   w.e = carve_ptr<int>(p, K); w.ancbuf = carve_ptr<int>(p, 2 * K); w.acntbuf = carve_ptr<int>(p, 2 * K); w.anc = w.ancbuf;
@@ -205,14 +221,17 @@ struct StreamState {
   int *arrays;
   int finish;  // this call ends the stream: run DecoderState::decode()
 };
-enum { SH_FRAMES = 0, SH_N, SH_POOL, SH_WLOG, SH_MAXKEY, SH_FINVALID, SH_WORDS = 8 };
-constexpr int kStateArrays = 14;
+enum { SH_FRAMES = 0, SH_N, SH_POOL, SH_WLOG, SH_MAXKEY, SH_FINVALID, SH_MINKEY, SH_WORDS = 8 };
+constexpr int kStateArrays = 14;                               // without the LM tier
+constexpr int kStateArraysLm = kStateArrays + kBeamArraysLm;   // with it: the LM arrays follow fin
+CTC_HD int state_arrays(int lm) { return lm ? kStateArraysLm : kStateArrays; }
 
 struct StepIn {
   int t;           // absolute time step
   int Vc;          // number of candidate characters
   int blank_rank;  // rank of the blank among the candidates, -1 if it was pruned away
   int identity;    // 1: candidate r is character r (no pruning)
+  float blank_prob;  // LM tier: log-probability of the blank in this frame, as ctc_beam_search_decoder.cpp:78 takes it
 };
 
 
@@ -221,6 +240,14 @@ struct StepIn {
 // every wave, and a "shift if power of two, else divide" form makes the compiler evaluate both.
 CTC_HD int div_p2(int v, int d) { return v >> __builtin_ctz((unsigned)d); }
 CTC_HD int ceil_div_p2(int v, int d) { return div_p2(v + d - 1, d); }
+
+CTC_HD double ctc_log_f64(double v) {  // std::log on a double, host or device
+#if defined(__HIP_DEVICE_COMPILE__)
+  return log(v);
+#else
+  return __builtin_log(v);
+#endif
+}
 
 CTC_HD int ceil_log2_u32(uint32_t v) {  // smallest s with (1 << s) >= v, v >= 1
   return v <= 1u ? 0 : 32 - __builtin_clz(v - 1u);
@@ -253,7 +280,8 @@ constexpr int kSmallK = 128, kSmallV = 32;
 #define CTC_ASSUME(c) do { if (!(c)) __builtin_unreachable(); } while (0)
 #endif
 
-template <class X, bool IDENT, bool SMALLV = false>
+// LM: decode with the external scorer (ctc_beam_search_decoder.cpp:74-82,93-95,120-137,173-206; tables: lm_tables.h).
+template <class X, bool IDENT, bool SMALLV = false, bool LM = false>
 struct Decoder {
   X &x;
   Work &w;
@@ -263,15 +291,18 @@ struct Decoder {
   int *pool_up;  // up(X) per pool node
   const int pool_cap;
   const uint64_t *tbl;  // exact_math tables
+  const ctclm::LmView *lm;  // LM tier only
 
-  CTC_HD Decoder(X &x_, Work &w_, const Dims &d_, int blank_, PoolNode *pool_, int *pool_up_, int pool_cap_, const uint64_t *tbl_)
-      : x(x_), w(w_), d(d_), blank(blank_), pool(pool_), pool_up(pool_up_), pool_cap(pool_cap_), tbl(tbl_) {}
+  CTC_HD Decoder(X &x_, Work &w_, const Dims &d_, int blank_, PoolNode *pool_, int *pool_up_, int pool_cap_, const uint64_t *tbl_,
+                 const ctclm::LmView *lm_ = nullptr)
+      : x(x_), w(w_), d(d_), blank(blank_), pool(pool_), pool_up(pool_up_), pool_cap(pool_cap_), tbl(tbl_), lm(lm_) {}
 
   CTC_HD float lse(float a, float b) const { return ctcmath::lse(a, b, tbl); }
 
   // Step-to-step state, identical in every thread (kept in registers, not LDS)
   int st_n = 1, st_pool = 1, st_wlog = 32;
   uint32_t st_maxkey = 0;
+  uint32_t st_minkey = 0;  // LM tier: key of the worst score in the beam (min_cutoff, ctc_beam_search_decoder.cpp:79)
   int st_par = 0;  // which copy of the beam is current
 
   template <class P>
@@ -284,6 +315,11 @@ struct Decoder {
     r.lcp = shifted(o.lcp, off); r.via = shifted(o.via, off); r.viaanc = shifted(o.viaanc, off); r.viach = shifted(o.viach, off);
     r.up = shifted(o.up, off); r.bprev = shifted(o.bprev, off); r.nbprev = shifted(o.nbprev, off);
     r.score = shifted(o.score, off); r.lpc = shifted(o.lpc, off);
+    if (LM) {
+      r.lmst = shifted(o.lmst, off); r.lmcl = shifted(o.lmcl, off); r.acc_lo = shifted(o.acc_lo, off); r.acc_hi = shifted(o.acc_hi, off);
+      r.dn = shifted(o.dn, off); r.dmlo = shifted(o.dmlo, off); r.dmhi = shifted(o.dmhi, off); r.dfc = shifted(o.dfc, off);
+      r.spc_lo = shifted(o.spc_lo, off); r.spc_hi = shifted(o.spc_hi, off); r.spst = shifted(o.spst, off); r.spcl = shifted(o.spcl, off);
+    }
     return r;
   }
   CTC_HD void select_beams() { w.cur = beam_at(st_par); w.nxt = beam_at(st_par ^ 1); }
@@ -291,6 +327,87 @@ struct Decoder {
   CTC_HD int *pvars(int t) const { return w.vars + VAR_PAR0 + (t & 1) * P_SIZE; }
   CTC_HD void reset_pvars(int *pv) const {
     pv[P_NPIN] = 0; pv[P_LCOUNT] = 0; pv[P_NMAXKEY] = 0;
+    if (LM) { pv[P_NMINKEY] = -1; pv[P_NCAND] = 0; }
+  }
+
+  // ---- LM tier helpers -------------------------------------------------------------------------------------------
+  CTC_HD static double mk_f64(int lo, int hi) {
+    union { uint64_t u; double f; } cv;
+    cv.u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+    return cv.f;
+  }
+  CTC_HD static void put_f64(double v, int *lo, int *hi) {
+    union { uint64_t u; double f; } cv;
+    cv.f = v;
+    *lo = (int)(uint32_t)cv.u;
+    *hi = (int)(uint32_t)(cv.u >> 32);
+  }
+  // log_p += score * alpha; log_p += beta, with the reference's types (float score = double * double; float += double)
+  CTC_HD float lm_apply(float log_p, double cond) const {  // ctc_beam_search_decoder.cpp:131-136
+    float score = 0.0f;
+    score = (float)(cond * lm->alpha);
+    log_p += score;
+    log_p = (float)((double)log_p + lm->beta);
+    return log_p;
+  }
+  // does extending an entry with label c call the scorer?  (:121-122)
+  CTC_HD bool lm_scores(int c) const { return lm->char_based || c == lm->space_id; }
+  // get_log_cond_prob(make_ngram(.)) for "entry P of beam b extended by c" (:123-134).  Word model: the window ends with
+  // the word P spells (cached when P was created).  Character model: the window ends with c itself.
+  CTC_HD double lm_window(const Beam &b, int P, int c) const {
+    if (!lm->char_based) return mk_f64(b.spc_lo[P], b.spc_hi[P]);
+    uint32_t st = (uint32_t)b.lmst[P];
+    int cl = b.lmcl[P];
+    return ctclm::lm_cond(*lm, &st, &cl, lm->label_word[c]);
+  }
+  // may entry P be extended by c at all?  path_trie.cpp:59-70: only along the dictionary (word models)
+  CTC_HD bool lm_allows(const Beam &b, int P, int c) const {
+    if (lm->char_based) return true;
+    return c < 32 ? (((uint32_t)b.dmlo[P] >> c) & 1u) != 0u : (((uint32_t)b.dmhi[P] >> (c - 32)) & 1u) != 0u;
+  }
+  // The LM fields of a prefix: `from` = the entry it copies them from (self) or hangs off (child via label c >= 0).
+  CTC_HD void lm_emit(const Beam &src, int from, int c, const Beam &dst, int k) const {
+    uint32_t st = (uint32_t)src.lmst[from];
+    int cl = src.lmcl[from];
+    double acc = mk_f64(src.acc_lo[from], src.acc_hi[from]);
+    if (c < 0) {  // the entry stays: everything carries over
+      dst.lmst[k] = (int)st; dst.lmcl[k] = cl; dst.acc_lo[k] = src.acc_lo[from]; dst.acc_hi[k] = src.acc_hi[from];
+      dst.dn[k] = src.dn[from]; dst.dmlo[k] = src.dmlo[from]; dst.dmhi[k] = src.dmhi[from]; dst.dfc[k] = src.dfc[from];
+      dst.spc_lo[k] = src.spc_lo[from]; dst.spc_hi[k] = src.spc_hi[from]; dst.spst[k] = src.spst[from]; dst.spcl[k] = src.spcl[from];
+      return;
+    }
+    if (lm->char_based) {
+      acc += ctclm::lm_cond(*lm, &st, &cl, lm->label_word[c]);  // Scorer::get_log_prob sums the same windows (scorer.cpp:111-120)
+      dst.dn[k] = 0; dst.dmlo[k] = 0; dst.dmhi[k] = 0; dst.dfc[k] = 0; dst.spc_lo[k] = 0; dst.spc_hi[k] = 0; dst.spst[k] = 0; dst.spcl[k] = 0;
+    } else {
+      ctclm::DictNode info;
+      uint32_t node;
+      if (c == lm->space_id) {  // a word is complete: its window joins the sum, the speller restarts (path_trie.cpp:83-92)
+        acc += mk_f64(src.spc_lo[from], src.spc_hi[from]);
+        st = (uint32_t)src.spst[from];
+        cl = src.spcl[from];
+        node = 0;
+      } else {
+        ctclm::DictNode pin;
+        pin.mask_lo = (uint32_t)src.dmlo[from]; pin.mask_hi = (uint32_t)src.dmhi[from]; pin.first_child = (uint32_t)src.dfc[from]; pin.word = 0;
+        node = ctclm::dict_child(pin, c);
+      }
+      info = lm->dict[node];
+      dst.dn[k] = (int)node; dst.dmlo[k] = (int)info.mask_lo; dst.dmhi[k] = (int)info.mask_hi; dst.dfc[k] = (int)info.first_child;
+      // the window "…, word spelled so far": used when a space follows (:128) and for the last word in decode() (:173-185)
+      double cond = ctclm::kOovScore;
+      uint32_t st2 = 0;
+      int cl2 = 0;
+      if (info.word != ctclm::kNoWord) {
+        st2 = st;
+        cl2 = cl;
+        cond = ctclm::lm_cond(*lm, &st2, &cl2, info.word);
+      }
+      put_f64(cond, &dst.spc_lo[k], &dst.spc_hi[k]);
+      dst.spst[k] = (int)st2; dst.spcl[k] = cl2;
+    }
+    dst.lmst[k] = (int)st; dst.lmcl[k] = cl;
+    put_f64(acc, &dst.acc_lo[k], &dst.acc_hi[k]);
   }
 
   // ctc_beam_search_decoder.cpp:43-44 : root prefix, score = log_prob_b_prev = 0
@@ -302,6 +419,12 @@ struct Decoder {
       b.node[0] = 0; b.par[0] = -1; b.ch[0] = -1; b.dep[0] = 0; b.lcp[0] = -1;
       b.via[0] = -1; b.viaanc[0] = -1; b.viach[0] = -1; b.up[0] = 0;
       b.bprev[0] = 0.f; b.nbprev[0] = CTC_NEG_MAX; b.score[0] = 0.f; b.lpc[0] = CTC_NEG_MAX;
+      if (LM) {  // ctc_beam_search_decoder.cpp:46-52: the root starts at the dictionary's start state
+        const ctclm::DictNode info = lm->dict[0];
+        b.lmst[0] = (int)lm->s0; b.lmcl[0] = lm->clean0; b.acc_lo[0] = 0; b.acc_hi[0] = 0;
+        b.dn[0] = 0; b.dmlo[0] = (int)info.mask_lo; b.dmhi[0] = (int)info.mask_hi; b.dfc[0] = (int)info.first_child;
+        put_f64(ctclm::kOovScore, &b.spc_lo[0], &b.spc_hi[0]); b.spst[0] = 0; b.spcl[0] = 0;
+      }
       PoolNode r; r.parent = -1; r.ch = -1; r.tstep = 0; r.lpc = CTC_NEG_MAX;
       pool[0] = r;
       pool_up[0] = 0;
@@ -311,6 +434,7 @@ struct Decoder {
     }
     st_n = 1; st_pool = 1; st_wlog = 32;  // first select looks at the whole key range
     st_maxkey = ord_f32(0.f);
+    st_minkey = ord_f32(0.f);
     for (int i = x.tid(); i < kBins + kBins / 16; i += x.nt()) w.bins[i] = 0;
     for (int i = x.tid(); i < 2 * d.K; i += x.nt()) w.hit[i] = 0;
     for (int i = x.tid(); i < 2 * d.K; i += x.nt()) { w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
@@ -324,6 +448,7 @@ struct Decoder {
     const int tid = x.tid(), nt = x.nt(), K = d.K;
     st_n = x.uni(ss.hdr[SH_N]); st_pool = x.uni(ss.hdr[SH_POOL]); st_wlog = x.uni(ss.hdr[SH_WLOG]);
     st_maxkey = (uint32_t)x.uni(ss.hdr[SH_MAXKEY]);
+    st_minkey = (uint32_t)x.uni(ss.hdr[SH_MINKEY]);
     st_par = 0;
     select_beams();
     Beam &b = w.cur;
@@ -333,6 +458,10 @@ struct Decoder {
       for (int a = 0; a < 9; ++a) ia[a][i] = ss.arrays[a * K + i];
       for (int a = 0; a < 4; ++a) fa[a][i] = ctcmath::bits_to_f32((uint32_t)ss.arrays[(9 + a) * K + i]);
       w.fin[i] = ss.arrays[13 * K + i];
+      if (LM) {
+        int *la[kBeamArraysLm] = {b.lmst, b.lmcl, b.acc_lo, b.acc_hi, b.dn, b.dmlo, b.dmhi, b.dfc, b.spc_lo, b.spc_hi, b.spst, b.spcl};
+        for (int a = 0; a < kBeamArraysLm; ++a) la[a][i] = ss.arrays[(kStateArrays + a) * K + i];
+      }
     }
     if (tid == 0) {
       w.vars[VAR_STATUS] = ST_OK;
@@ -355,10 +484,14 @@ struct Decoder {
       for (int a = 0; a < 9; ++a) ss.arrays[a * K + i] = ia[a][i];
       for (int a = 0; a < 4; ++a) ss.arrays[(9 + a) * K + i] = (int)ctcmath::f32_to_bits(fa[a][i]);
       ss.arrays[13 * K + i] = w.fin[i];
+      if (LM) {
+        const int *la[kBeamArraysLm] = {b.lmst, b.lmcl, b.acc_lo, b.acc_hi, b.dn, b.dmlo, b.dmhi, b.dfc, b.spc_lo, b.spc_hi, b.spst, b.spcl};
+        for (int a = 0; a < kBeamArraysLm; ++a) ss.arrays[(kStateArrays + a) * K + i] = la[a][i];
+      }
     }
     if (tid == 0) {
       ss.hdr[SH_FRAMES] = frames; ss.hdr[SH_N] = st_n; ss.hdr[SH_POOL] = st_pool; ss.hdr[SH_WLOG] = st_wlog;
-      ss.hdr[SH_MAXKEY] = (int)st_maxkey;
+      ss.hdr[SH_MAXKEY] = (int)st_maxkey; ss.hdr[SH_MINKEY] = (int)st_minkey;
     }
   }
 
@@ -644,6 +777,18 @@ struct Decoder {
     int *pv = pvars(in.t);
     int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
     const Window wd = first_window();
+    // LM tier: candidates whose (prefix score + label log-prob) falls below the worst prefix's score plus the blank's
+    // log-prob (minus beta) are skipped once the beam is full (ctc_beam_search_decoder.cpp:74-82,93-95).  The prefixes
+    // are visited best first there and the loop breaks at the first miss; scores only fall from there on and float
+    // addition is monotone, so the break is the same as this per-candidate test.
+    float min_cutoff = CTC_NEG_MAX;
+    bool full_beam = false;
+    if (LM) {
+      const double bpos = lm->beta > 0.0 ? lm->beta : 0.0;  // std::max(0.0, beta)
+      min_cutoff = (float)((double)(unord_f32(st_minkey) + in.blank_prob) - bpos);
+      full_beam = n == K;
+    }
+    auto cut = [&](float lp, float prefix_score) { return LM && full_beam && lp + prefix_score < min_cutoff; };
 
     // ---- A1: per beam entry, from the LCP array alone: the end of its subtree range (first later entry whose LCP
     // with its predecessor is shallower than the entry), found by a wave-wide search; every entry then "paints" its
@@ -731,23 +876,28 @@ struct Decoder {
     const bool split = nt - n1 >= 128;
     if (!split || tid < n1) {
       const float lp_blank = brank >= 0 ? w.clp[brank] : CTC_NEG_MAX;
+      int ncand = 0;
       for (int j = tid; j < n; j += (split ? n1 : nt)) {
         const int c = b.ch[j];
         const int r = rank_of_char(in, c);
         const float sc = b.score[j], nbp = b.nbprev[j];
-        float bcur = brank >= 0 ? lp_blank + sc : CTC_NEG_MAX;             // :97-101
+        float bcur = (brank >= 0 && !cut(lp_blank, sc)) ? lp_blank + sc : CTC_NEG_MAX;             // :97-101
         float nbcur = CTC_NEG_MAX;
-        if (r >= 0) nbcur = w.clp[r] + nbp;  // :103-106 -- log_sum_exp(-FLT_MAX, y) returns y (decoder_utils.h:50)
+        if (r >= 0 && !cut(w.clp[r], sc)) nbcur = w.clp[r] + nbp;  // :103-106 -- log_sum_exp(-FLT_MAX, y) returns y (decoder_utils.h:50)
         const int P = w.anc[j];
         const int pr = w.pinr[j];
         if (pr >= 0) {
           const float lp = w.clp[pr];
-          if (b.lpc[j] < lp) {                                             // path_trie.cpp:42-45
-            b.lpc[j] = lp;
-            pool[b.node[j]].tstep = in.t;
-            pool[b.node[j]].lpc = lp;
+          if (!cut(lp, b.score[P])) {
+            if (b.lpc[j] < lp) {                                             // path_trie.cpp:42-45
+              b.lpc[j] = lp;
+              pool[b.node[j]].tstep = in.t;
+              pool[b.node[j]].lpc = lp;
+            }
+            float logp = child_logp(P, c, lp);
+            if (LM && lm_scores(c)) logp = lm_apply(logp, lm_window(b, P, c));  // :120-137
+            nbcur = lse(nbcur, logp);                                        // :138-139
           }
-          nbcur = lse(nbcur, child_logp(P, c, lp));                         // :138-139
         }
         w.b_new[j] = bcur;
         w.nb_new[j] = nbcur;
@@ -756,7 +906,7 @@ struct Decoder {
         const int s0 = w.ostart[j];
         uint32_t k0 = 0, i0 = kHoleInfo;
         const int rx = w.revr[j];
-        if (rx >= 0) {                                                      // path_trie.cpp:40-57: hit + revive
+        if (rx >= 0 && !cut(w.clp[rx], b.score[P])) {                       // path_trie.cpp:40-57: hit + revive
           const int cx = b.viach[j];
           const float lp = w.clp[rx];
           const int xn = b.via[j];
@@ -767,14 +917,19 @@ struct Decoder {
             pool[xn].lpc = lp;
           }
           w.rev_lpc[j] = xl;  // read back by whoever compacts the revived node (same step, other thread)
-          k0 = ord_f32(child_logp(P, cx, lp));
+          float logp = child_logp(P, cx, lp);
+          if (LM && lm_scores(cx)) logp = lm_apply(logp, lm_window(b, P, cx));
+          k0 = ord_f32(logp);
           i0 = mk_info(cx, T_REVIVED, j);
+          ++ncand;
         }
+        ++ncand;
         const uint32_t k1 = ord_f32(ns);
         w.skey[s0] = k0; w.sinfo[s0] = i0;
         w.skey[s0 + 1] = k1; w.sinfo[s0 + 1] = mk_info(c, T_SELF, j);
         if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
       }
+      if (LM) x.wave_add(&pv[P_NCAND], ncand);
     }
     x.mark(1);
     if (!split || tid >= n1) {
@@ -782,6 +937,7 @@ struct Decoder {
       const int t2 = split ? tid - n1 : tid, nt2 = split ? nt - n1 : nt;
       const int sh = ceil_log2_u32((uint32_t)(Vnb > 1 ? Vnb : 1));
       const int lp2 = 1 << sh;                       // lanes per parent (power of two >= Vnb)
+      int ncand = 0;
       if (small_vocab && nt2 >= lp2) {               // a group of lp2 lanes per parent, one lane per character
         const int rn = t2 & (lp2 - 1);
         const int ng = nt2 >> sh;
@@ -796,9 +952,15 @@ struct Decoder {
             const uint32_t hw = w.hit[2 * i + (rn >> 5)];
             const int pch = b.ch[i];
             const float psc = b.score[i], pbp = b.bprev[i];
-            const uint32_t live = 0u - (((hw >> (rn & 31)) & 1u) ^ 1u);  // all ones unless the child already exists
+            uint32_t live = 0u - (((hw >> (rn & 31)) & 1u) ^ 1u);  // all ones unless the child already exists
             const float ext = lp + psc, rep = pbp > CTC_NEG_MAX ? lp + pbp : CTC_NEG_MAX;  // :110-118
-            const uint32_t k = ord_f32(c == pch ? rep : ext) & live;
+            float logp = c == pch ? rep : ext;
+            if (LM) {
+              if (cut(lp, psc) || !lm_allows(b, i, c)) live = 0u;            // :93-95, path_trie.cpp:59-70
+              if (live && lm_scores(c)) logp = lm_apply(logp, lm_window(b, i, c));  // :120-137
+              ncand += live ? 1 : 0;
+            }
+            const uint32_t k = ord_f32(logp) & live;
             const int s = cs + rn;
             w.skey[s] = k;
             w.sinfo[s] = ((childinfo | (uint32_t)i) & live) | (kHoleInfo & ~live);
@@ -811,13 +973,27 @@ struct Decoder {
           const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
           const int c = IDENT ? r : w.cch[r];
           const int s = w.cstart[i] + rn;
-          const bool exists = small_vocab && ((w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u);
-          const uint32_t k = exists ? 0u : ord_f32(child_logp(i, c, w.clp[r]));
+          bool exists = small_vocab && ((w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u);
+          float logp = CTC_NEG_MAX;
+          if (LM) {
+            // (with more than 64 candidate labels the children that already exist are punched out afterwards; they are
+            // counted here and subtracted there)
+            if (cut(w.clp[r], b.score[i]) || !lm_allows(b, i, c)) exists = true;
+            if (!exists) {
+              logp = child_logp(i, c, w.clp[r]);
+              if (lm_scores(c)) logp = lm_apply(logp, lm_window(b, i, c));
+              ++ncand;
+            }
+          } else if (!exists) {
+            logp = child_logp(i, c, w.clp[r]);
+          }
+          const uint32_t k = exists ? 0u : ord_f32(logp);
           w.skey[s] = k;
           w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
           if (small_vocab) hist_add(wd, k);
         }
       }
+      if (LM) x.wave_add(&pv[P_NCAND], ncand);
     }
     if (split) x.template prio<0>();
     x.sync();
@@ -826,6 +1002,7 @@ struct Decoder {
         const int r = w.pinr[j] >= 0 ? w.pinr[j] : w.revr[j];
         if (r >= 0) {
           const int s = w.cstart[w.anc[j]] + r - ((brank >= 0 && r > brank) ? 1 : 0);
+          if (LM && w.skey[s] != 0u) x.atomic_add(&pv[P_NCAND], -1);
           w.skey[s] = 0; w.sinfo[s] = kHoleInfo;
         }
       }
@@ -836,7 +1013,7 @@ struct Decoder {
     x.mark(2);
 
     // ---- C: the K-th best key.  #candidates = beam entries + new children - children that already exist as entries
-    const int N = n * (1 + Vnb) - x.uni(npin_total);
+    const int N = LM ? x.uni(pv[P_NCAND]) : n * (1 + Vnb) - x.uni(npin_total);
     uint32_t tau = 0, tauc = 0;
     bool exact = false, have_bitmap = false;
     if (N > K) {  // ctc_beam_search_decoder.cpp:150
@@ -896,7 +1073,7 @@ struct Decoder {
     }
     // Three independent parts per survivor -- its LCP with the previous survivor, its structural fields (+ the pool
     // append), its probabilities -- go to three different sets of waves when the workgroup has them.
-    uint32_t kloc = 0;
+    uint32_t kloc = 0, kmin = 0xFFFFFFFFu;
     bool r_prob_any = true;
     {
       const int ne = (n_new + 63) & ~63;
@@ -975,14 +1152,23 @@ struct Decoder {
               logp = child_logp(w.anc[j], c, lp);
               o_lpc = w.rev_lpc[j];
             }
+            if (LM && lm_scores(c)) logp = lm_apply(logp, lm_window(b, child ? j : w.anc[j], c));  // as scored in phase B
             o_b = CTC_NEG_MAX; o_nb = logp; o_sc = logp;
           }
           nb.bprev[k] = o_b; nb.nbprev[k] = o_nb; nb.score[k] = o_sc; nb.lpc[k] = o_lpc;
+          if (LM) lm_emit(b, (self || child) ? j : w.anc[j], self ? -1 : c, nb, k);
         }
-        if (r_prob) kloc = w.skey[s] > kloc ? w.skey[s] : kloc;
+        if (r_prob) {
+          const uint32_t ks = w.skey[s];
+          kloc = ks > kloc ? ks : kloc;
+          kmin = ks < kmin ? ks : kmin;
+        }
       }
     }
-    if (x.uni((int)r_prob_any)) x.wave_max_to(&pv[P_NMAXKEY], kloc);  // only the waves that handled probabilities
+    if (x.uni((int)r_prob_any)) {  // only the waves that handled probabilities
+      x.wave_max_to(&pv[P_NMAXKEY], kloc);
+      if (LM) x.wave_min_to(&pv[P_NMINKEY], kmin);
+    }
     if (last) {  // the order std::nth_element left the survivors in (identity when it was not called)
       for (int q = tid; q < n_new; q += nt) w.fin[q] = exact ? rk[q] : q;
     }
@@ -1009,6 +1195,7 @@ struct Decoder {
       }
       st_wlog = wl;
       st_maxkey = (uint32_t)x.uni(pv[P_NMAXKEY]);
+      if (LM) st_minkey = (uint32_t)x.uni(pv[P_NMINKEY]);
       st_n = n_new;
       st_pool = pool_count + n_new;
     }
@@ -1096,17 +1283,59 @@ struct Decoder {
     // The two std::sorts (ctc_beam_search_decoder.cpp:188-190, decoder_utils.cpp:59) order by (score desc, character
     // asc).  Equal float32 scores are common in a beam (it spans a few hundred ulps), so the order libstdc++ leaves
     // equivalent prefixes in matters: both sorts are replayed exactly, on (key, entry) pairs packed into one word.
+    float *ext = w.sc_new;       // LM tier: score + last word's LM score (the map `scores` of decode(), :168-185)
+    float *approx = w.b_new;     //          PathTrie::approx_ctc (:194-208)
     {
       const float *sc = b.score;
       const int *ch = b.ch;
       uint64_t *pk = w.ek;
+      if (LM) {
+        for (int a = tid; a < n; a += nt) {
+          // the word the prefix ends in, when it does not end in a space (:173-185; word models only)
+          const bool partial = !lm->char_based && b.dep[a] > 0 && ch[a] != lm->space_id;
+          const bool word_here = partial && lm_allows(b, a, lm->space_id);  // a word of the model ends exactly here
+          const double wcond = word_here ? mk_f64(b.spc_lo[a], b.spc_hi[a]) : ctclm::kOovScore;
+          float e = sc[a];
+          if (partial) {
+            float score = 0.0f;
+            score = (float)(wcond * lm->alpha);
+            score = (float)((double)score + lm->beta);
+            e += score;
+          }
+          ext[a] = e;
+          // Scorer::get_sent_log_prob of the prefix's words (scorer.cpp:95-120): the windows of the completed words are
+          // already summed in acc; then the word it ends in, then "</s>"
+          double total = mk_f64(b.acc_lo[a], b.acc_hi[a]);
+          uint32_t st = (uint32_t)b.lmst[a];
+          int cl = b.lmcl[a];
+          if (b.dep[a] == 0) {               // empty prefix: the sentence is N x "<s>" then "</s>" (:97-100)
+            total += ctclm::lm_cond(*lm, &st, &cl, lm->w_bos);
+          } else if (partial) {
+            total += wcond;
+            if (word_here) { st = (uint32_t)b.spst[a]; cl = b.spcl[a]; } else { st = 0; cl = 0; }
+          }
+          total += ctclm::lm_cond(*lm, &st, &cl, lm->w_eos);
+          double ap = (double)e;
+          ap = ap - (double)(size_t)b.dep[a] * lm->beta;   // "remove word insert": per label (:203)
+          ap -= total * lm->alpha;                          // :205
+          approx[a] = (float)ap;
+        }
+        x.sync();
+      }
       for (int p = tid; p < nres; p += nt) {
         const int a = w.fin[p];
-        pk[p] = (key48(ord_f32(sc[a]), mk_info(ch[a], 0, 0)) << 16) | (uint64_t)a;
+        pk[p] = (key48(ord_f32(LM ? ext[a] : sc[a]), mk_info(ch[a], 0, 0)) << 16) | (uint64_t)a;
       }
       x.sync();
       auto before = [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); };
-      sort_like_std(pk, nres, before);
+      sort_like_std(pk, nres, before);   // :188-190, by the scores map
+      if (LM) {                          // decoder_utils.cpp:59 sorts by the RAW score
+        for (int p = tid; p < nres; p += nt) {
+          const int a = (int)(pk[p] & 0xFFFFu);
+          pk[p] = (key48(ord_f32(sc[a]), mk_info(ch[a], 0, 0)) << 16) | (uint64_t)a;
+        }
+        x.sync();
+      }
       sort_like_std(pk, nres, before);
       for (int p = tid; p < nres; p += nt) w.fin[p] = (int)(pk[p] & 0xFFFFu);
     }
@@ -1114,7 +1343,7 @@ struct Decoder {
     x.sync();
     for (int p = tid; p < nres; p += nt) {
       const int j = w.fin[p];
-      out_score[p] = -b.score[j];           // decoder_utils.cpp:68 (approx_ctc = score without a scorer)
+      out_score[p] = LM ? -approx[j] : -b.score[j];  // decoder_utils.cpp:68 (approx_ctc = score without a scorer)
       out_len[p] = b.dep[j];
     }
     // path_trie.cpp:113-126 (get_path_vec).  Neighbours in the (DFS-ordered) beam share their first lcp labels, so
@@ -1199,12 +1428,15 @@ struct PrunedRows {
 };
 
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
-template <bool IDENT, bool SMALLV = false, class X>
+// LM tier: `lm` = the scorer's tables, `raw` = the caller's own [len, V] rows (log-probabilities or probabilities,
+// `raw_log` says which): ctc_beam_search_decoder.cpp:78 takes the blank's log-probability from them directly.
+template <bool IDENT, bool SMALLV = false, bool LM = false, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
-                            const StreamState *ss = nullptr) {
+                            const StreamState *ss = nullptr, const ctclm::LmView *lm = nullptr, const float *raw = nullptr,
+                            int raw_log = 1) {
   if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
-  Decoder<X, IDENT, SMALLV> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl);
+  Decoder<X, IDENT, SMALLV, LM> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   if (t0 > 0) dec.load_state(*ss); else dec.init();
@@ -1229,6 +1461,11 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   for (int t = 0; t < len; ++t) {
     StepIn in;
     in.t = t0 + t;
+    in.blank_prob = 0.f;
+    if (LM) {
+      const float rb = raw[(size_t)t * d.V + blank];
+      in.blank_prob = raw_log ? rb : (float)ctc_log_f64((double)rb);  // float blank_prob = log_input ? p : std::log(p)
+    }
     x.trace_frame(in.t);
     bool stage = false;
     if (IDENT) {

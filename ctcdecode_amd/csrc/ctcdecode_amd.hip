@@ -22,6 +22,7 @@
 #include "../../include/ctcdecode_amd.h"
 #define CTC_EXACT_MATH_HOST_TABLES
 #include "beam_core.h"
+#include "lm_build.h"
 
 namespace {
 
@@ -166,6 +167,10 @@ struct DevX {
   __device__ __forceinline__ void wave_max_to(int *p, uint32_t v) {
     v = wave_max_u32(v);
     if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
+  }
+  __device__ __forceinline__ void wave_min_to(int *p, uint32_t v) {
+    v = ~wave_max_u32(~v);
+    if ((threadIdx.x & 63) == 0) atomicMin((unsigned *)p, v);
   }
 
   // bit s of bitmap = pred(s), for every slot s in [0, S): each wave owns a contiguous range of slots (the same mapping
@@ -367,6 +372,11 @@ struct KernelArgs {
   const int *st_poolcap;    // [B] nodes the pool of each stream can hold
   const unsigned char *st_eos;  // [B] 1: this call ends the stream (run decode())
   long long st_pool_off;    // byte offset of the node pool inside a stream block
+  // LM tier (ctcd_beam_decode_lm): the scorer's tables, and the caller's own rows (the blank's log-probability is taken
+  // from them, ctc_beam_search_decoder.cpp:78)
+  ctclm::LmView lm;
+  const float *raw;         // [B, T, V] as given by the caller
+  int raw_log;              // 1: they are log-probabilities
   const int *pr_cnt;        // pruned mode: [B, T] candidates per frame (null in identity mode)
   const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
   const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
@@ -377,11 +387,11 @@ struct KernelArgs {
 // 1 = fixed layout for beam <= kFixedK, vocabulary <= kFixedV: every LDS array sits at a compile-time address, which
 // frees the scalar registers the bases would occupy and folds them into the instructions' offset fields.
 constexpr int kFixedK = ctcbeam::kSmallK, kFixedV = ctcbeam::kSmallV;
-__host__ __device__ constexpr Dims fixed_layout_dims() { return Dims{kFixedK, kFixedV, kFixedV, 1}; }
+__host__ __device__ constexpr Dims fixed_layout_dims() { return Dims{kFixedK, kFixedV, kFixedV, 1, 0}; }
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
 
 // PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
-template <int PROF, bool BIG, int LAYOUT, bool PRUNED, int NT = 0>
+template <int PROF, bool BIG, int LAYOUT, bool PRUNED, int NT = 0, bool LM = false>
 __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -430,9 +440,15 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
 #else
   const OutRefs *outs = &a.outs;
 #endif
-  const int st = decode_utterance<!PRUNED, LAYOUT == 1>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
+  const ctclm::LmView *lmv = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (LM) lmv = (const ctclm::LmView *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernelArgs, lm));
+#else
+  if (LM) lmv = &a.lm;
+#endif
+  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
-                                  a.st_base ? &ss : (const StreamState *)nullptr);
+                                  a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + (size_t)b * a.T * a.V : nullptr, a.raw_log);
   if (threadIdx.x == 0) a.status[b] = st;
   if (PROF == 2 && a.tl && b == 0) {
     __syncthreads();
@@ -820,11 +836,21 @@ struct ctcd_decoder {
 // One audio stream's parked decoder state (ctcd_stream_*): a single HBM block [header | beam arrays | node pool].
 struct ctcd_stream {
   int device = 0;
+  ctcd_scorer *scorer = nullptr;  // DecoderState is created with its scorer (binding.cpp:243-261)
   char *block = nullptr;
   size_t bytes = 0;
   int V = 0, beam = 0;
   long long frames = 0;      // frames fed so far (host mirror of the header word)
   long long cap_frames = 0;  // frames the node pool can take
+};
+
+// The external scorer (ctcdecode/src/scorer.h:41-110, created by paddle_get_scorer, binding.cpp:143-150): built on the host
+// from the ARPA file (lm_build.h), its tables mirrored into the HBM of one device (lm_tables.h).
+struct ctcd_scorer {
+  ctclm::HostScorer host;
+  int device = 0;
+  char *blob = nullptr;      // one HBM allocation holding every table
+  ctclm::LmView dview;       // the tables as the kernel sees them (alpha / beta are refreshed at every launch)
 };
 
 namespace {
@@ -835,20 +861,22 @@ struct StreamCall {          // extra arguments of a streaming decode
   int out_T;
 };
 
-size_t stream_pool_offset(int beam) { return ((size_t)(SH_WORDS + kStateArrays * (size_t)beam) * 4 + 255) / 256 * 256; }
+// (the parked arrays are always laid out for the LM tier's larger set: a stream block is sized once, before its scorer matters)
+size_t stream_pool_offset(int beam) { return ((size_t)(SH_WORDS + kStateArraysLm * (size_t)beam) * 4 + 255) / 256 * 256; }
 // a stream block holds [header | beam arrays | node pool (nodes * 16 B) | express pointers (nodes * 4 B)]
 size_t stream_nodes(long long frames, int beam) { return (size_t)frames * beam + 1; }
 size_t stream_block_bytes(long long cap_frames, int beam) {
   return stream_pool_offset(beam) + stream_nodes(cap_frames, beam) * (sizeof(PoolNode) + sizeof(int));
 }
 
-Dims make_dims(int beam, int V, int cutoff_top_n, double cutoff_prob) {
+Dims make_dims(int beam, int V, int cutoff_top_n, double cutoff_prob, bool lm = false) {
   const bool pruned = cutoff_prob < 1.0 || cutoff_top_n < V;
   Dims d;
   d.K = beam;
   d.V = V;
   d.Vc_max = pruned ? (cutoff_top_n < V ? cutoff_top_n : V) : V;
   d.use_rank_table = pruned ? 1 : 0;
+  d.lm = lm ? 1 : 0;
   return d;
 }
 
@@ -948,8 +976,11 @@ int ctcd_set_threads(ctcd_decoder *d, int t) {
 
 static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                          double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, int32_t *out_tok, int32_t *out_ts,
-                         float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_, const StreamCall *sc) {
+                         float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_, const StreamCall *sc,
+                         ctcd_scorer *scorer = nullptr) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  if (scorer && scorer->device != d->device) return fail(CTCD_EINVAL, "the scorer's tables live on another device than the decoder");
+  if (scorer && (int)scorer->host.labels.size() != V) return fail(CTCD_EINVAL, "the scorer was built for a different number of labels");
   const int out_T = sc ? sc->out_T : T;
   // (a streaming call in which no stream ends has out_T == 0 and may pass null token / timestep buffers)
   const bool no_rows = sc && out_T == 0;
@@ -960,13 +991,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   hipStream_t stream = (hipStream_t)stream_;
   CTC_ON_DEVICE(d->device);
   if (B == 0) return CTCD_OK;
-  const Dims dims = make_dims(beam, V, cutoff_top_n, cutoff_prob);
+  const Dims dims = make_dims(beam, V, cutoff_top_n, cutoff_prob, scorer != nullptr);
   if (dims.S_max() > 65535)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) exceeds 65535 candidate slots");
   if (dims.use_rank_table && V > 32767) return fail(CTCD_EUNSUPPORTED, "vocabulary pruning with more than 32767 labels");
   Work wtmp;
   size_t far_bytes = 0;
-  const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout;
+  const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout && !scorer;  // (the LM tier runs the run-time layout)
   const Dims ldims = fixed ? fixed_layout_dims() : dims;
   size_t lds = carve<false>(wtmp, nullptr, nullptr, ldims, nullptr);
   bool big = false;
@@ -977,6 +1008,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   }
   if (lds + 2048 > (size_t)d->max_lds)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) needs " + std::to_string(lds) + " B of LDS, more than one workgroup has");
+  if (big && scorer) return fail(CTCD_EUNSUPPORTED, "the LM tier does not fit this beam width / vocabulary in LDS yet");
+  if (scorer && d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the LM tier");
   if (big && (rc = d->far.ensure((size_t)B * far_bytes))) return rc;
 
   // outputs: everything outside the valid region is defined as 0
@@ -1151,6 +1184,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   a.outs.K = beam; a.outs.T_stride = out_T;
   a.status = (int32_t *)d->status.p;
   a.st_base = st_base; a.st_poolcap = st_cap; a.st_eos = st_eos; a.st_pool_off = (long long)stream_pool_offset(beam);
+  a.raw = probs; a.raw_log = log_input;
+  std::memset(&a.lm, 0, sizeof(a.lm));
+  if (scorer) {
+    a.lm = scorer->dview;
+    a.lm.alpha = scorer->host.alpha;  // reset_params (binding.cpp:283-287) takes effect at the next decode
+    a.lm.beta = scorer->host.beta;
+  }
   a.pr_cnt = nullptr; a.pr_ch = nullptr; a.pr_lp = nullptr; a.pr_stride = 0;
   if (dims.use_rank_table) {
     a.pr_cnt = (const int *)d->pr_cnt.p; a.pr_ch = (const int *)d->pr_ch.p; a.pr_lp = (const float *)d->pr_lp.p;
@@ -1191,6 +1231,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     fn = (const void *)ctc_beam_decode_kernel<2, false, 1, false>;
   }
 #undef CTC_PICK
+  if (scorer) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, false, 0, false, 0, true>;
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
   void *kargs[] = {&a};
@@ -1207,7 +1248,90 @@ int ctcd_beam_decode(ctcd_decoder *d, const float *probs, const int32_t *seq_len
                        out_len, n_results, stream_, nullptr);
 }
 
+// ---- LM tier: the external scorer (binding.cpp:122-150,263-287)
+int ctcd_scorer_create(ctcd_scorer **out, double alpha, double beta, const char *lm_path, const char *const *labels, int V,
+                       int device_id) {
+  if (!out || !lm_path || !labels || V <= 0) return fail(CTCD_EINVAL, "bad scorer arguments");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(CTCD_EINVAL, "no such HIP device");
+  std::vector<std::string> lab(V);
+  for (int i = 0; i < V; ++i) {
+    if (!labels[i]) return fail(CTCD_EINVAL, "null label");
+    lab[i] = labels[i];
+  }
+  ctcd_scorer *s = new ctcd_scorer;
+  s->device = device_id;
+  if (!s->host.build(alpha, beta, lm_path, lab)) {
+    const std::string msg = s->host.error;
+    delete s;
+    return fail(msg.find("not supported") != std::string::npos || msg.find("supported for") != std::string::npos ? CTCD_EUNSUPPORTED : CTCD_EINVAL, msg);
+  }
+  CTC_ON_DEVICE(device_id);
+  const ctclm::HostScorer &h = s->host;
+  size_t off = 0;
+  auto place = [&off](size_t bytes) { const size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+  const size_t o_up = place(h.uni_prob.size() * 4), o_us = place(h.uni_state.size() * 4), o_bo = place(h.st_bo.size() * 4),
+               o_fl = place(h.st_fail.size() * 4), o_ng = place(h.ng.size() * sizeof(ctclm::NgSlot)),
+               o_dc = place(h.dict.size() * sizeof(ctclm::DictNode)), o_lw = place(h.label_word.size() * 4);
+  hipError_t e = hipMalloc((void **)&s->blob, off ? off : 256);
+  if (e != hipSuccess) { delete s; return fail(CTCD_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  auto up = [&](size_t o, const void *src, size_t bytes) { return bytes ? hipMemcpy(s->blob + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
+  if ((e = up(o_up, h.uni_prob.data(), h.uni_prob.size() * 4)) != hipSuccess || (e = up(o_us, h.uni_state.data(), h.uni_state.size() * 4)) != hipSuccess ||
+      (e = up(o_bo, h.st_bo.data(), h.st_bo.size() * 4)) != hipSuccess || (e = up(o_fl, h.st_fail.data(), h.st_fail.size() * 4)) != hipSuccess ||
+      (e = up(o_ng, h.ng.data(), h.ng.size() * sizeof(ctclm::NgSlot))) != hipSuccess ||
+      (e = up(o_dc, h.dict.data(), h.dict.size() * sizeof(ctclm::DictNode))) != hipSuccess ||
+      (e = up(o_lw, h.label_word.data(), h.label_word.size() * 4)) != hipSuccess) {
+    (void)hipFree(s->blob);
+    delete s;
+    return fail(CTCD_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+  }
+  s->dview = h.view();
+  s->dview.uni_prob = (const float *)(s->blob + o_up); s->dview.uni_state = (const uint32_t *)(s->blob + o_us);
+  s->dview.st_bo = (const float *)(s->blob + o_bo); s->dview.st_fail = (const uint32_t *)(s->blob + o_fl);
+  s->dview.ng = (const ctclm::NgSlot *)(s->blob + o_ng); s->dview.dict = (const ctclm::DictNode *)(s->blob + o_dc);
+  s->dview.label_word = (const uint32_t *)(s->blob + o_lw);
+  *out = s;
+  return CTCD_OK;
+}
+
+void ctcd_scorer_destroy(ctcd_scorer *s) {
+  if (!s) return;
+  DeviceGuard guard_(s->device);
+  if (s->blob) (void)hipFree(s->blob);
+  delete s;
+}
+int ctcd_scorer_is_character_based(const ctcd_scorer *s) { return s ? (s->host.char_based ? 1 : 0) : -1; }
+int ctcd_scorer_max_order(const ctcd_scorer *s) { return s ? s->host.order : -1; }
+int ctcd_scorer_dict_size(const ctcd_scorer *s) { return s ? s->host.dict_size : -1; }
+int ctcd_scorer_reset_params(ctcd_scorer *s, double alpha, double beta) {
+  if (!s) return fail(CTCD_EINVAL, "scorer == NULL");
+  s->host.alpha = alpha;
+  s->host.beta = beta;
+  return CTCD_OK;
+}
+double ctcd_scorer_cond_log_prob(const ctcd_scorer *s, const char *const *words, int n) {
+  if (!s || !words || n < 0) return 0.0;
+  std::vector<std::string> w(n);
+  for (int i = 0; i < n; ++i) w[i] = words[i] ? words[i] : "";
+  return s->host.cond_log_prob(w);
+}
+
+int ctcd_beam_decode_lm(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                        int /*num_processes*/, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer,
+                        int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
+  if (!scorer) return fail(CTCD_EINVAL, "scorer == NULL (use ctcd_beam_decode)");
+  return decode_common(d, probs, seq_lens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok, out_ts, out_sc,
+                       out_len, n_results, stream_, nullptr, scorer);
+}
+
 // ---- streaming: DecoderState kept between calls (ctcdecode/__init__.py:143-272, binding.cpp:153-265)
+int ctcd_stream_create_lm(ctcd_decoder *d, ctcd_stream **out, int V, int beam, int frames_hint, ctcd_scorer *scorer) {
+  int rc = ctcd_stream_create(d, out, V, beam, frames_hint);
+  if (rc == CTCD_OK) (*out)->scorer = scorer;
+  return rc;
+}
+
 int ctcd_stream_create(ctcd_decoder *d, ctcd_stream **out, int V, int beam, int frames_hint) {
   if (!d || !out || V <= 0 || beam <= 0 || beam > kMaxBeam) return fail(CTCD_EINVAL, "bad stream parameters");
   CTC_ON_DEVICE(d->device);
@@ -1246,6 +1370,7 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
   for (int b = 0; b < B; ++b) {
     ctcd_stream *st = states[b];
     if (!st || st->V != V || st->beam != beam) return fail(CTCD_EINVAL, "stream state does not match the decoder configuration");
+    if (st->scorer != states[0]->scorer) return fail(CTCD_EINVAL, "the streams of one batch must share their scorer");
     for (int c = 0; c < b; ++c)
       if (states[c] == st) return fail(CTCD_EINVAL, "the same stream state appears twice in one batch");
     int len = seq_lens_host ? seq_lens_host[b] : T;
@@ -1276,7 +1401,7 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
   HIP_TRY(hipStreamSynchronize(stream));
   StreamCall sc{states, is_eos, out_T};
   rc = decode_common(d, probs, (const int32_t *)d->st_lens.p, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok,
-                     out_ts, out_sc, out_len, n_results, stream_, &sc);
+                     out_ts, out_sc, out_len, n_results, stream_, &sc, states[0]->scorer);
   if (rc) return rc;
   for (int b = 0; b < B; ++b) states[b]->frames += lens[b];
   return CTCD_OK;
@@ -1285,6 +1410,16 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
 int ctcd_beam_decode_host(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                           int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
                           int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results) {
+  return ctcd_beam_decode_lm_host(d, probs, seq_lens, B, T, V, beam, num_processes, cutoff_prob, cutoff_top_n, blank_id, log_input,
+                                  nullptr, out_tok, out_ts, out_sc, out_len, n_results);
+}
+
+// paddle_beam_decode_lm as the reference's Python calls it (binding.cpp:122-140): CPU tensors in, CPU tensors out.
+// scorer == NULL decodes without a language model.
+int ctcd_beam_decode_lm_host(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                             int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                             ctcd_scorer *scorer, int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len,
+                             int32_t *n_results) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, out_tok, out_ts, out_sc, out_len);
   if (rc) return rc;
@@ -1298,9 +1433,10 @@ int ctcd_beam_decode_host(ctcd_decoder *d, const float *probs, const int32_t *se
   char *din = (char *)d->stage_in.p, *dout = (char *)d->stage_out.p;
   if (nin) HIP_TRY(hipMemcpy(din, probs, nin, hipMemcpyHostToDevice));
   if (seq_lens) HIP_TRY(hipMemcpy(din + off_sl, seq_lens, (size_t)B * 4, hipMemcpyHostToDevice));
-  rc = ctcd_beam_decode(d, (const float *)din, seq_lens ? (const int32_t *)(din + off_sl) : nullptr, B, T, V, beam, num_processes,
-                        cutoff_prob, cutoff_top_n, blank_id, log_input, (int32_t *)dout, (int32_t *)(dout + o_ts),
-                        (float *)(dout + o_sc), (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), nullptr);
+  (void)num_processes;
+  rc = decode_common(d, (const float *)din, seq_lens ? (const int32_t *)(din + off_sl) : nullptr, B, T, V, beam, cutoff_prob,
+                     cutoff_top_n, blank_id, log_input, (int32_t *)dout, (int32_t *)(dout + o_ts), (float *)(dout + o_sc),
+                     (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), nullptr, nullptr, scorer);
   if (rc) return rc;
   if ((rc = ctcd_check_status(d, B))) return rc;
   HIP_TRY(hipDeviceSynchronize());

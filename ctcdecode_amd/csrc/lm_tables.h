@@ -1,0 +1,142 @@
+// lm_tables.h -- the external scorer of the LM tier as flat tables a CDNA4 workgroup can query.
+//
+// Replaces, for the decode path, the reference's Scorer object (ctcdecode/src/scorer.{h,cpp}) and its two absent
+// third-party engines: kenlm (n-gram query) and OpenFST (dictionary).  The scorer is BUILT on the host
+// (lm_build.h: ARPA text -> tables, the counterpart of Scorer::setup, scorer.cpp:43-72,148-161,196-230) and its tables are
+// mirrored into HBM once; the per-frame queries of DecoderState::next() (ctc_beam_search_decoder.cpp:120-137) then run
+// inside the decode kernel -- a host round trip per frame is not an option at a few microseconds per frame.
+//
+//   * n-gram model = back-off automaton.  A state is a LISTED n-gram of order < N used as context (state 0 = empty
+//     context); (state, word) -> {log10 prob, next state} for every listed n-gram, in an open-addressed table of
+//     16-byte slots (one 128-bit load per probe); a miss adds the state's back-off weight and follows its failure
+//     link (longest listed proper suffix).  The value returned is kenlm's GenericModel::FullScore: the log10 prob of
+//     the longest listed n-gram plus the back-off weights of the longer contexts, added in float32 from the shorter
+//     context to the longer (lm/model.cc); n-grams whose own suffix is not listed are found all the same (kenlm fills
+//     such gaps at load time; here the failure link simply skips them -- their back-off weight is zero).
+//   * Scorer::get_log_cond_prob (scorer.cpp:74-93) feeds the N words of make_ngram's window starting from the empty
+//     context and returns OOV_SCORE as soon as one of them is unknown.  Fed incrementally, the automaton state after a
+//     prefix equals the state that window would build (the longest listed suffix, at most N-1 words), so every beam
+//     entry carries ONE state word plus a counter of how many in-vocabulary tokens it has seen since the last unknown
+//     one ("clean"): a window holds an unknown word iff clean < N-1 or the new word is unknown.
+//   * dictionary (word models) = prefix trie of (word + " ") over label ids with the children of a node stored
+//     contiguously in label order: child(node, c) = first_child + popcount(mask & below(c)).  One 16-byte record per
+//     node {label mask (64 bit), first child, word id of the word that ends here}.  Behaviour-equivalent to the
+//     determinised + minimised FST of scorer.cpp:196-230 for Find / Final; a completed word restarts
+//     the speller at the root (path_trie.cpp:83-92).
+#pragma once
+#include <stdint.h>
+
+#ifndef CTC_HD
+#if defined(__HIPCC__)
+#define CTC_HD __host__ __device__ __forceinline__
+#else
+#define CTC_HD inline
+#endif
+#endif
+
+namespace ctclm {
+
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+constexpr uint32_t kNoWord = 0xFFFFFFFFu;  // dictionary node at which no word ends
+constexpr int kMaxOrder = 6;               // KENLM_MAX_ORDER of the reference's build (setup.py:57)
+constexpr double kOovScore = -1000.0;      // scorer.h:16
+
+struct NgSlot { uint32_t state, word, prob_bits, next; };         // 16 bytes
+struct DictNode { uint32_t mask_lo, mask_hi, first_child, word; };  // 16 bytes
+
+struct LmView {
+  const float *uni_prob;       // [W] log10 p(w), w = word id (0 = <unk>)
+  const uint32_t *uni_state;   // [W] state of the unigram w
+  const float *st_bo;          // [S] back-off weight of a state (st_bo[0] = 0)
+  const uint32_t *st_fail;     // [S] longest listed proper suffix of the state (0 = empty context)
+  const NgSlot *ng;            // [ng_mask + 1]
+  const DictNode *dict;        // [D] (word models)
+  const uint32_t *label_word;  // [V] character models: word id of each label's string (0 = unknown)
+  uint32_t ng_mask;
+  int order;                   // N
+  int char_based;              // scorer.cpp:65-71
+  int space_id;                // label index of " " (-1: none)
+  uint32_t s0;                 // state after the (N-1) "<s>" tokens make_ngram pads a short history with
+  int clean0;                  // N-1 if "<s>" is a word of the model, else 0
+  uint32_t w_bos, w_eos;       // word ids of "<s>" and "</s>" (0 = unknown)
+  double alpha, beta;
+};
+
+CTC_HD uint32_t ng_hash(uint32_t state, uint32_t word) {
+  uint32_t h = state * 0x9E3779B1u ^ (word + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 13;
+  return h;
+}
+
+// log10 p(word | state) as kenlm computes it, and the state after the word.  word must be a known word (id != 0).
+CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *next) {
+  float bos[kMaxOrder];
+  int nb = 0;
+  uint32_t q = state;
+  float prob = 0.f;
+  uint32_t nx = 0;
+  bool hit = false;
+  while (q != 0 && !hit) {
+    uint32_t h = ng_hash(q, word) & L.ng_mask;
+    for (;;) {
+      const NgSlot s = L.ng[h];
+      if (s.state == q && s.word == word) {
+        union { uint32_t u; float f; } cv;
+        cv.u = s.prob_bits;
+        prob = cv.f;
+        nx = s.next;
+        hit = true;
+        break;
+      }
+      if (s.state == kEmptySlot) break;
+      h = (h + 1) & L.ng_mask;
+    }
+    if (!hit) {
+      if (nb < kMaxOrder) bos[nb++] = L.st_bo[q];
+      q = L.st_fail[q];
+    }
+  }
+  if (!hit) {
+    prob = L.uni_prob[word];
+    nx = L.uni_state[word];
+  }
+  float r = prob;
+  for (int i = nb - 1; i >= 0; --i) r += bos[i];  // float32, from the shorter context to the longer (lm/model.cc)
+  *next = nx;
+  return r;
+}
+
+// Scorer::get_log_cond_prob of the window that ends with `word` (scorer.cpp:74-93), given the entry's automaton state
+// and clean counter: natural-log probability (double), or OOV_SCORE when the window holds an unknown word.  Also
+// advances (state, clean) past the word.
+CTC_HD double lm_cond(const LmView &L, uint32_t *state, int *clean, uint32_t word) {
+  if (word == 0) {  // unknown: this window and the next N-1 are OOV; the history restarts after it
+    *state = 0;
+    *clean = 0;
+    return kOovScore;
+  }
+  uint32_t nx;
+  const float p10 = lm_score(L, *state, word, &nx);
+  const bool oov = *clean < L.order - 1;
+  *state = nx;
+  *clean = *clean + 1 < L.order - 1 ? *clean + 1 : L.order - 1;
+  if (oov) return kOovScore;
+  return (double)p10 / (double)0.4342944819f;  // decoder_utils.h:14 NUM_FLT_LOGE is a float constant
+}
+
+CTC_HD bool dict_has(const DictNode &n, int label) {
+  return label < 32 ? (n.mask_lo >> label) & 1u : (n.mask_hi >> (label - 32)) & 1u;
+}
+CTC_HD uint32_t dict_child(const DictNode &n, int label) {  // label must be an arc of n
+  uint32_t below;
+  if (label < 32) {
+    below = (uint32_t)__builtin_popcount(n.mask_lo & ((1u << label) - 1u));
+  } else {
+    below = (uint32_t)__builtin_popcount(n.mask_lo) + (uint32_t)__builtin_popcount(n.mask_hi & ((1u << (label - 32)) - 1u));
+  }
+  return n.first_child + below;
+}
+
+}  // namespace ctclm

@@ -59,6 +59,36 @@ int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *
                           int32_t *out_tokens, int32_t *out_timesteps, float *out_scores, int32_t *out_lens,
                           int32_t *n_results);
 
+/* ---- LM tier: the external scorer.  Replaces ctcdecode/src/binding.cpp:122-150,263-287:
+ *   ctcd_scorer_create          <- paddle_get_scorer(alpha, beta, lm_path, labels, vocab_size)   (binding.cpp:143-150)
+ *   ctcd_scorer_destroy         <- paddle_release_scorer                                          (binding.cpp:263-265)
+ *   ctcd_scorer_is_character_based / _max_order / _dict_size / _reset_params <- binding.cpp:271-287
+ *   ctcd_beam_decode_lm[_host]  <- paddle_beam_decode_lm: paddle_beam_decode plus `void *scorer`  (binding.cpp:122-140)
+ * The scorer object (ctcdecode/src/scorer.h:41-110) is built on the host from an ARPA text model (binary kenlm files are
+ * not supported) and the label strings; its tables -- n-gram back-off automaton, dictionary trie -- are mirrored into the
+ * HBM of `device_id` once, and the per-frame queries of DecoderState::next() run inside the decode kernel.  `labels`:
+ * V NUL-terminated UTF-8 strings.  Word models need a " " label and at most 64 labels.  LM arithmetic follows kenlm's
+ * published algorithm (float32 weights, longest listed n-gram, back-off weights added in float32); see DESIGN.md for
+ * what this parity is pinned to. */
+typedef struct ctcd_scorer ctcd_scorer;
+int ctcd_scorer_create(ctcd_scorer **out, double alpha, double beta, const char *lm_path, const char *const *labels, int V,
+                       int device_id);
+void ctcd_scorer_destroy(ctcd_scorer *scorer);
+int ctcd_scorer_is_character_based(const ctcd_scorer *scorer);
+int ctcd_scorer_max_order(const ctcd_scorer *scorer);
+int ctcd_scorer_dict_size(const ctcd_scorer *scorer);
+int ctcd_scorer_reset_params(ctcd_scorer *scorer, double alpha, double beta);
+/* Scorer::get_log_cond_prob (scorer.cpp:74-93) on explicit words, evaluated on the host copy of the tables (tests). */
+double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *words, int n);
+int ctcd_beam_decode_lm(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                        int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer,
+                        int32_t *out_tokens, int32_t *out_timesteps, float *out_scores, int32_t *out_lens, int32_t *n_results,
+                        void *stream);
+int ctcd_beam_decode_lm_host(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                             int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                             ctcd_scorer *scorer, int32_t *out_tokens, int32_t *out_timesteps, float *out_scores,
+                             int32_t *out_lens, int32_t *n_results);
+
 /* ---- Streaming ("online") decoding: replaces ctcdecode/src/binding.cpp:153-265 (paddle_get_decoder_state,
  * paddle_beam_decode_with_given_state, paddle_release_state) = DecoderState objects kept alive between calls
  * (ctcdecode/src/ctc_beam_search_decoder.cpp:230-243,288-317).  A ctcd_stream parks one utterance's beam and node pool
@@ -68,6 +98,8 @@ int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *
  * stream), elsewhere row b stays zero and n_results[b] = 0.  seq_lens_host and is_eos are HOST arrays (B entries). */
 typedef struct ctcd_stream ctcd_stream;
 int ctcd_stream_create(ctcd_decoder *dec, ctcd_stream **out, int V, int beam, int frames_hint);
+/* paddle_get_decoder_state with a scorer (binding.cpp:243-261): the stream decodes with the LM tier */
+int ctcd_stream_create_lm(ctcd_decoder *dec, ctcd_stream **out, int V, int beam, int frames_hint, ctcd_scorer *scorer);
 void ctcd_stream_destroy(ctcd_decoder *dec, ctcd_stream *st);
 long long ctcd_stream_frames(const ctcd_stream *st);
 int ctcd_stream_decode(ctcd_decoder *dec, ctcd_stream **states, const unsigned char *is_eos, const float *probs,

@@ -4,6 +4,7 @@
 // The product never links this file.
 #define CTC_EXACT_MATH_HOST_TABLES
 #include "../../ctcdecode_amd/csrc/beam_core.h"
+#include "../../ctcdecode_amd/csrc/lm_build.h"
 
 #include <algorithm>
 #include <atomic>
@@ -83,6 +84,7 @@ struct HostX {
       if (pred(s)) out[k++] = s;
   }
   void wave_max_to(int *p, uint32_t v) { *p = (int)std::max((uint32_t)*p, v); }
+  void wave_min_to(int *p, uint32_t v) { *p = (int)std::min((uint32_t)*p, v); }
 };
 
 // Vocabulary pruning exactly as the reference does it (decoder_utils.cpp:10-45) -- host stand-in for the GPU prune pass.
@@ -120,10 +122,60 @@ void prune_row(const float *row, int V, double cutoff_prob, int top_n, int *cnt,
 
 }  // namespace
 
+static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, int num_threads,
+                       double cutoff_prob, int cutoff_top_n, int blank_id, int32_t *out_tokens,
+                       int32_t *out_timesteps, float *out_scores, int32_t *out_lens, int32_t *n_results,
+                       const ctclm::LmView *lm, const float *raw, int raw_log);
+
 // log-probability input only (the prob->log conversion is a separate, elementwise stage of the product).
 extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, int num_threads,
                                   double cutoff_prob, int cutoff_top_n, int blank_id, int32_t *out_tokens,
                                   int32_t *out_timesteps, float *out_scores, int32_t *out_lens, int32_t *n_results) {
+  return decode_impl(probs, seq_lens, B, T, V, beam, num_threads, cutoff_prob, cutoff_top_n, blank_id, out_tokens, out_timesteps,
+                     out_scores, out_lens, n_results, nullptr, nullptr, 1);
+}
+
+// LM tier: the scorer is built by the product's own host code (lm_build.h); labels = V NUL-terminated strings.
+// log_input == 0: `probs` are probabilities (converted here the way the product's pre-pass does, decoder_utils.cpp:42).
+extern "C" int ctccore_decode_lm_f32(const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, int num_threads,
+                                     double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, double alpha, double beta,
+                                     const char *lm_path, const char *labels, int32_t *out_tokens, int32_t *out_timesteps,
+                                     float *out_scores, int32_t *out_lens, int32_t *n_results, int32_t *meta3) {
+  std::vector<std::string> lab(V);
+  for (int i = 0; i < V; ++i) {
+    lab[i] = labels;
+    labels += lab[i].size() + 1;
+  }
+  ctclm::HostScorer hs;
+  if (!hs.build(alpha, beta, lm_path, lab)) return -100;
+  if (meta3) { meta3[0] = hs.char_based; meta3[1] = hs.order; meta3[2] = hs.dict_size; }
+  const ctclm::LmView view = hs.view();
+  std::vector<float> logp;
+  const float *in = probs;
+  if (!log_input) {
+    logp.resize((size_t)B * T * V);
+    for (size_t i = 0; i < logp.size(); ++i) logp[i] = (float)std::log((double)probs[i] + (double)std::numeric_limits<float>::min());
+    in = logp.data();
+  }
+  return decode_impl(in, seq_lens, B, T, V, beam, num_threads, cutoff_prob, cutoff_top_n, blank_id, out_tokens, out_timesteps,
+                     out_scores, out_lens, n_results, &view, probs, log_input);
+}
+
+// Scorer::get_log_cond_prob through the product's tables (host copy): words = n NUL-terminated strings
+extern "C" double ctccore_lm_cond(const char *lm_path, const char *labels, int V, const char *words, int n, int32_t *meta3) {
+  std::vector<std::string> lab(V), ws(n);
+  for (int i = 0; i < V; ++i) { lab[i] = labels; labels += lab[i].size() + 1; }
+  for (int i = 0; i < n; ++i) { ws[i] = words; words += ws[i].size() + 1; }
+  ctclm::HostScorer hs;
+  if (!hs.build(0.0, 0.0, lm_path, lab)) return 1e300;
+  if (meta3) { meta3[0] = hs.char_based; meta3[1] = hs.order; meta3[2] = hs.dict_size; }
+  return hs.cond_log_prob(ws);
+}
+
+static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, int num_threads,
+                       double cutoff_prob, int cutoff_top_n, int blank_id, int32_t *out_tokens,
+                       int32_t *out_timesteps, float *out_scores, int32_t *out_lens, int32_t *n_results,
+                       const ctclm::LmView *lm, const float *raw, int raw_log) {
   using namespace ctcbeam;
   const bool pruned = std::log(cutoff_prob) < 0.0 || cutoff_top_n < V;
   Dims d;
@@ -131,6 +183,7 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
   d.V = V;
   d.Vc_max = pruned ? std::min(V, cutoff_top_n) : V;
   d.use_rank_table = pruned ? 1 : 0;
+  d.lm = lm ? 1 : 0;
   std::atomic<int> next{0}, bad{0};
   auto work = [&] {
     Work w;
@@ -155,7 +208,13 @@ extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, i
         for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
       int st;
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T};
-      if (beam <= 128 && V <= 32) {  // the shapes the device runs with its fixed layout
+      if (lm) {
+        const float *rawb = raw + (size_t)b * T * V;
+        if (pruned) st = decode_utterance<false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+        else st = decode_utterance<true, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+      } else if (beam <= 128 && V <= 32) {  // the shapes the device runs with its fixed layout
         if (pruned) st = decode_utterance<false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b);
         else st = decode_utterance<true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
@@ -184,7 +243,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
                                           int32_t *out_lens, int32_t *n_results) {
   using namespace ctcbeam;
   Dims d;
-  d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0;
+  d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0; d.lm = 0;
   Work w;
   size_t far_bytes = 0;
   std::vector<char> mem(carve<false>(w, nullptr, nullptr, d, &far_bytes) + 64);

@@ -27,8 +27,57 @@ def _ptr(a, t):
     return a.ctypes.data_as(t) if a is not None else None
 
 
+def _pack(strings):
+    return b"".join(x.encode("utf-8") + b"\0" for x in strings)
+
+
+class Scorer(object):
+    """The LM scorer of one of the CPU checkers: ``restated`` = oracle/ctc_oracle.cpp's own, ``reference`` = the
+    reference's scorer.cpp over the kenlm / OpenFST stand-ins of oracle/shim (binding.cpp:143-150,263-287)."""
+
+    def __init__(self, alpha, beta, lm_path, labels, which="restated"):
+        self.which, self.labels = which, list(labels)
+        self.lib = ctypes.CDLL(RESTATED_SO if which == "restated" else REFERENCE_SO)
+        self.pfx = "ctcoracle_scorer_" if which == "restated" else "ctcref_scorer_"
+        f = getattr(self.lib, self.pfx + "create")
+        f.restype = ctypes.c_void_p
+        f.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+        self.handle = f(alpha, beta, os.fsencode(lm_path), _pack(self.labels), len(self.labels))
+        if not self.handle:
+            raise RuntimeError("could not load the language model %r" % (lm_path,))
+
+    def _call(self, name, restype, *args, argtypes=()):
+        f = getattr(self.lib, self.pfx + name)
+        f.restype = restype
+        f.argtypes = [ctypes.c_void_p] + list(argtypes)
+        return f(self.handle, *args)
+
+    def is_character_based(self):
+        return bool(self._call("is_character_based", ctypes.c_int))
+
+    def max_order(self):
+        return self._call("max_order", ctypes.c_int)
+
+    def dict_size(self):
+        return self._call("dict_size", ctypes.c_int)
+
+    def reset_params(self, alpha, beta):
+        self._call("reset_params", None, alpha, beta, argtypes=[ctypes.c_double, ctypes.c_double])
+
+    def cond_logprob(self, words):
+        return self._call("cond_logprob", ctypes.c_double, _pack(words), len(words), argtypes=[ctypes.c_char_p, ctypes.c_int])
+
+    def sent_logprob(self, words):
+        return self._call("sent_logprob", ctypes.c_double, _pack(words), len(words), argtypes=[ctypes.c_char_p, ctypes.c_int])
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self._call("release", None)
+            self.handle = None
+
+
 def decode(probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, log_input=True,
-           threads=None, which="restated", want_stats=False):
+           threads=None, which="restated", want_stats=False, scorer=None):
     """Returns dict(tokens[B,K,T], timesteps[B,K,T], scores[B,K], lens[B,K], nres[B]) as numpy arrays.
 
     Unwritten positions are zero (the reference leaves them uninitialised, ctcdecode/__init__.py:83-86).
@@ -43,6 +92,17 @@ def decode(probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n=40, bla
     sc = np.zeros((B, beam), np.float32)
     ln = np.zeros((B, beam), np.int32)
     nres = np.zeros((B,), np.int32)
+    if scorer is not None:  # paddle_beam_decode_lm (binding.cpp:122-140)
+        assert scorer.which == which and len(scorer.labels) == V
+        fn = scorer.lib.ctcoracle_decode_lm_f32 if which == "restated" else scorer.lib.ctcref_decode_lm_f32
+        fn.argtypes = [_f32p, _i32p] + [ctypes.c_int] * 5 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                                             ctypes.c_void_p, _i32p, _i32p, _f32p, _i32p, _i32p]
+        rc = fn(_ptr(probs, _f32p), _ptr(seq_lens, _i32p), B, T, V, beam, threads, cutoff_prob, cutoff_top_n, blank_id,
+                int(bool(log_input)), _pack(scorer.labels), scorer.handle, _ptr(tok, _i32p), _ptr(ts, _i32p), _ptr(sc, _f32p),
+                _ptr(ln, _i32p), _ptr(nres, _i32p))
+        if rc != 1:
+            raise RuntimeError("checker returned %d" % rc)
+        return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)
     if which == "restated":
         lib = ctypes.CDLL(RESTATED_SO)
         stats = np.zeros((B, 5), np.int64) if want_stats else None
@@ -110,7 +170,7 @@ def build_core_host():
     import subprocess
 
     src = os.path.join(ROOT, "tests", "native", "core_host.cpp")
-    deps = [src] + [os.path.join(ROOT, "ctcdecode_amd", "csrc", f) for f in ("beam_core.h", "stl_emul.h", "exact_math.h")]
+    deps = [src] + [os.path.join(ROOT, "ctcdecode_amd", "csrc", f) for f in ("beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h")]
     if os.path.exists(CORE_HOST_SO) and all(os.path.getmtime(CORE_HOST_SO) >= os.path.getmtime(p) for p in deps):
         return CORE_HOST_SO
     os.makedirs(os.path.dirname(CORE_HOST_SO), exist_ok=True)
@@ -135,6 +195,43 @@ def decode_core_host(probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top
     if rc != 1:
         raise RuntimeError("core returned %d" % rc)
     return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)
+
+
+def decode_core_host_lm(probs, alpha, beta, lm_path, labels, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0,
+                        log_input=True, threads=None):
+    """The host build of the product's core with the LM tier (scorer built by ctcdecode_amd/csrc/lm_build.h)."""
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    B, T, V = probs.shape
+    if seq_lens is not None:
+        seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    threads = threads or os.cpu_count() or 1
+    tok = np.zeros((B, beam, T), np.int32)
+    ts = np.zeros((B, beam, T), np.int32)
+    sc = np.zeros((B, beam), np.float32)
+    ln = np.zeros((B, beam), np.int32)
+    nres = np.zeros((B,), np.int32)
+    meta = np.zeros((3,), np.int32)
+    lib = ctypes.CDLL(build_core_host())
+    fn = lib.ctccore_decode_lm_f32
+    fn.argtypes = [_f32p, _i32p] + [ctypes.c_int] * 5 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                         ctypes.c_char_p, ctypes.c_char_p, _i32p, _i32p, _f32p, _i32p, _i32p, _i32p]
+    rc = fn(_ptr(probs, _f32p), _ptr(seq_lens, _i32p), B, T, V, beam, threads, cutoff_prob, cutoff_top_n, blank_id, int(bool(log_input)),
+            alpha, beta, os.fsencode(lm_path), _pack(labels), _ptr(tok, _i32p), _ptr(ts, _i32p), _ptr(sc, _f32p), _ptr(ln, _i32p),
+            _ptr(nres, _i32p), _ptr(meta, _i32p))
+    if rc != 1:
+        raise RuntimeError("core returned %d" % rc)
+    return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres, meta=tuple(int(v) for v in meta))
+
+
+def core_host_lm_cond(lm_path, labels, words):
+    """Scorer::get_log_cond_prob evaluated by the product's own tables (host copy, ctcdecode_amd/csrc/lm_build.h)."""
+    lib = ctypes.CDLL(build_core_host())
+    fn = lib.ctccore_lm_cond
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, _i32p]
+    meta = np.zeros((3,), np.int32)
+    v = fn(os.fsencode(lm_path), _pack(labels), len(labels), _pack(words), len(words), _ptr(meta, _i32p))
+    return v, tuple(int(x) for x in meta)
 
 
 def decode_core_host_chunked(probs, bounds, beam=100, blank_id=0):

@@ -363,8 +363,8 @@ def test_empty_and_degenerate_batches(torch_mod):
         dec.decode(torch_mod.zeros((1, 3, 6)))
     with pytest.raises(ValueError):
         ctcdecode_amd.CTCBeamDecoder(["a", "b"], blank_id=5, log_probs_input=True).decode(torch_mod.zeros((1, 3, 2)))
-    with pytest.raises(NotImplementedError):
-        ctcdecode_amd.CTCBeamDecoder(["a", "b"], model_path="lm.arpa")
+    with pytest.raises(ValueError):  # scorer.cpp:57 aborts on a bad path; here it is an error
+        ctcdecode_amd.CTCBeamDecoder(["a", "b"], model_path="/no/such/lm.arpa")
 
 
 def test_device_math_bit_exact_vs_host_libm(torch_mod):

@@ -1,0 +1,150 @@
+"""-m gpu tests of the LM tier: the HIP path with the external scorer, through the drop-in classes and the
+raw C ABI, against the committed reference fixtures, the oracle, and the reference's own golden strings."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_util as ou
+from test_lm import DATA, LABELS29, LM_CASES, TEST_ARPA, VOCAB7, lm_case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return torch
+
+
+def _decode(torch, probs, lm, seq_lens=None, beam=100, cutoff_top_n=40, cutoff_prob=1.0, blank_id=0, log_input=True, threads=None):
+    import ctcdecode_amd
+
+    dec = ctcdecode_amd.CTCBeamDecoder(lm["labels"], model_path=lm["lm_path"], alpha=lm["alpha"], beta=lm["beta"], cutoff_top_n=cutoff_top_n,
+                                       cutoff_prob=cutoff_prob, beam_width=beam, blank_id=blank_id, log_probs_input=log_input, device="cuda:0")
+    if threads:
+        dec.set_threads(threads)
+    out, sc, ts, ln = dec.decode(torch.from_numpy(np.ascontiguousarray(probs)), torch.from_numpy(seq_lens) if seq_lens is not None else None)
+    meta = (int(dec.character_based()), dec.max_order(), dec.dict_size())
+    return dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy()), meta
+
+
+def _with_nres(got, want):
+    got = dict(got)
+    got["nres"] = want["nres"]
+    for b in range(got["lens"].shape[0]):
+        n = int(want["nres"][b])
+        assert not got["lens"][b, n:].any() and not got["scores"][b, n:].any() and not got["tokens"][b, n:].any()
+    return got
+
+
+@pytest.mark.parametrize("threads", [0, 256])
+@pytest.mark.parametrize("name", gu.lm_names())
+def test_lm_reference_fixtures(torch_mod, name, threads):
+    args, lm, want = gu.load_lm(name)
+    got, meta = _decode(torch_mod, lm=lm, threads=threads, **args)
+    assert meta == lm["meta"]
+    ou.assert_same(_with_nres(got, want), want, name)
+
+
+def test_reference_lm_golden_strings(torch_mod):
+    """tests/test_decode.py:55-64,93-115,141-159 of the reference: "a a" with test.arpa -- offline, online, online in two calls."""
+    import ctcdecode_amd
+
+    args, _ = gu.load("ref_fixtures_prob")
+    probs = torch_mod.from_numpy(args["probs"])
+    dec = ctcdecode_amd.CTCBeamDecoder(VOCAB7, beam_width=20, model_path=TEST_ARPA, blank_id=VOCAB7.index("_"))
+    assert dec.character_based() is False and dec.max_order() == 5 and dec.dict_size() == 1
+    out, sc, ts, ln = dec.decode(probs[1:2])
+    assert "".join(VOCAB7[x] for x in out[0][0][: ln[0][0]]) == "a a"          # test_beam_search_decoder_3
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder(VOCAB7, beam_width=20, blank_id=VOCAB7.index("_"), model_path=TEST_ARPA)
+    s1, s2 = ctcdecode_amd.DecoderState(dec), ctcdecode_amd.DecoderState(dec)
+    seq2 = probs[1:2]
+    out, sc, ts, ln = dec.decode(torch_mod.cat([seq2, seq2]), [s1, s2], [True, True])  # test_online_decoder_decoding
+    assert ["".join(VOCAB7[x] for x in out[b][0][: ln[b][0]]) for b in range(2)] == ["a a", "a a"]
+    s1 = ctcdecode_amd.DecoderState(dec)
+    dec.decode(seq2[:, :2], [s1], [False])                                       # ..._with_two_calls
+    out, sc, ts, ln = dec.decode(seq2[:, 2:], [s1], [True])
+    assert "".join(VOCAB7[x] for x in out[0][0][: ln[0][0]]) == "a a"
+
+
+@pytest.mark.parametrize("c", [LM_CASES[0], LM_CASES[2], LM_CASES[5]], ids=lambda c: c["name"])
+def test_lm_streaming_equals_one_shot(torch_mod, c):
+    """Chunked decoding with the scorer (states carry the LM fields between launches) == the one-shot result == the oracle."""
+    import ctcdecode_amd
+
+    x, kw = lm_case_inputs(c)
+    path = os.path.join(DATA, c["arpa"])
+    sc = ou.Scorer(c["alpha"], c["beta"], path, c["labels"], "restated")
+    want = ou.decode(x, scorer=sc, **kw)
+    B, T, V = x.shape
+    K = c["K"]
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder(c["labels"], model_path=path, alpha=c["alpha"], beta=c["beta"], beam_width=K,
+                                             blank_id=kw["blank_id"], log_probs_input=True)
+    states = [ctcdecode_amd.DecoderState(dec) for _ in range(B)]
+    xt = torch_mod.from_numpy(x)
+    bounds = [0, 1, T // 3, T // 3, T - 2, T]
+    for i in range(len(bounds) - 1):
+        out, scs, ts, ln = dec.decode(xt[:, bounds[i]:bounds[i + 1]], states, [i == len(bounds) - 2] * B)
+    got = dict(tokens=np.zeros((B, K, T), np.int32), timesteps=np.zeros((B, K, T), np.int32), scores=scs.numpy(), lens=ln.numpy(), nres=want["nres"])
+    got["tokens"][:, : out.shape[1], : out.shape[2]] = out.numpy()
+    got["timesteps"][:, : out.shape[1], : out.shape[2]] = ts.numpy()
+    ou.assert_same(got, want, "chunked with LM")
+
+
+def test_lm_config5_shape_sample(torch_mod):
+    """BASELINE.json configs[4]: V=29, beam 100, T=1500, test.arpa with alpha 0.5 / beta 1.0 -- 16 utterances of that shape against
+    the oracle (restated; oracle/_ref where built), and reset_params taking effect."""
+    import ctcdecode_amd
+
+    B, T, V, K = 16, 1500, 29, 100
+    lp = ou.synth_logprobs(B, T, V, 555)
+    lp[:, :, LABELS29.index(" ")] += np.float32(1.0)
+    lp[:, :, LABELS29.index("a")] += np.float32(1.0)
+    m = lp.max(-1, keepdims=True)
+    lp = (lp - (m + np.log(np.exp(lp - m).sum(-1, keepdims=True)))).astype(np.float32)
+    which = "reference" if ou.have_reference() else "restated"
+    sc = ou.Scorer(0.5, 1.0, TEST_ARPA, LABELS29, which)
+    want = ou.decode(lp, scorer=sc, which=which, beam=K, threads=os.cpu_count())
+    dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.5, beta=1.0, beam_width=K, log_probs_input=True)
+    out, scs, ts, ln = dec.decode(torch_mod.from_numpy(lp))
+    got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=scs.numpy(), lens=ln.numpy())
+    ou.assert_same(_with_nres(got, want), want, "configs[4] shape vs " + which)
+    dec.reset_params(0.0, 0.0)
+    out2, scs2, _, _ = dec.decode(torch_mod.from_numpy(lp[:2]))
+    sc.reset_params(0.0, 0.0)
+    want2 = ou.decode(lp[:2], scorer=sc, which=which, beam=K)
+    assert np.array_equal(scs2.numpy().view(np.uint32), want2["scores"].view(np.uint32))
+
+
+def test_lm_host_pointer_entry_and_scorer_queries(torch_mod):
+    """ctcd_beam_decode_lm_host (what a maintainer binds in place of paddle_beam_decode_lm) and ctcd_scorer_cond_log_prob."""
+    import ctcdecode_amd._native as n
+
+    args, lm, want = gu.load_lm("abcd_words")
+    probs = np.ascontiguousarray(args["probs"])
+    B, T, V = probs.shape
+    K = args["beam"]
+    labels = (ctypes.c_char_p * V)(*[x.encode() for x in lm["labels"]])
+    sc = ctypes.c_void_p()
+    n.check(n.lib.ctcd_scorer_create(ctypes.byref(sc), lm["alpha"], lm["beta"], lm["lm_path"].encode(), labels, V, 0))
+    h = ctypes.c_void_p()
+    n.check(n.lib.ctcd_create(ctypes.byref(h), 0))
+    tok = np.full((B, K, T), -7, np.int32); ts = np.full((B, K, T), -7, np.int32)
+    scs = np.full((B, K), -7, np.float32); ln = np.full((B, K), -7, np.int32); nres = np.zeros((B,), np.int32)
+    try:
+        n.check(n.lib.ctcd_beam_decode_lm_host(h, probs.ctypes.data, None, B, T, V, K, 4, 1.0, args["cutoff_top_n"], args["blank_id"], 1, sc,
+                                               tok.ctypes.data, ts.ctypes.data, scs.ctypes.data, ln.ctypes.data, nres.ctypes.data))
+        words = (ctypes.c_char_p * 2)(b"bad", b"bad")
+        got = n.lib.ctcd_scorer_cond_log_prob(sc, words, 2)
+    finally:
+        n.lib.ctcd_destroy(h)
+        n.lib.ctcd_scorer_destroy(sc)
+    ou.assert_same(dict(tokens=tok, timesteps=ts, scores=scs, lens=ln, nres=nres), want, "LM host entry point")
+    assert got == ou.Scorer(0.0, 0.0, lm["lm_path"], lm["labels"], "restated").cond_logprob(["bad", "bad"])
+    with pytest.raises(ValueError):
+        n.check(n.lib.ctcd_scorer_create(ctypes.byref(sc), 0.0, 0.0, b"/nonexistent.arpa", labels, V, 0))

@@ -1,0 +1,204 @@
+"""LM tier on the CPU: pins the restated scorer + LM-mode decoder of oracle/ctc_oracle.cpp.
+
+(a) kenlm's own published expectations for tests/test.arpa (lm/model_test.cc of github.com/kpu/kenlm: Starters,
+    Continuation, Blanks) -- the only pin of the LM ARITHMETIC that does not go through a restatement of kenlm;
+(b) the reference's golden "a a" (tests/test_decode.py:55-64 of the reference: test.arpa, alpha = beta = 0);
+(c) live differential against oracle/_ref = the reference's own scorer.cpp / decoder LM hooks (compiled unmodified) over
+    the kenlm / OpenFST stand-ins of oracle/shim, on word and character models with non-zero alpha and beta;
+(d) committed fixtures generated from (c) (tests/golden_lm, tests/golden/make_golden_lm.py) so that the pin travels.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_util as ou
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+TEST_ARPA = os.path.join(DATA, "test.arpa")
+VOCAB7 = ["'", " ", "a", "b", "c", "d", "_"]
+LOG10E = float(np.float32(0.4342944819))
+WHICH = ["restated"] + (["reference"] if ou.have_reference() else [])
+
+# (words fed after the null context, log10 p(last word | the ones before)); "<s>" first = kenlm's BeginSentenceState
+KENLM_KATS = [
+    (["<s>", "looking"], -0.4846522),
+    (["<s>", ","], -1.383514 + -0.4149733),
+    (["<s>", "this_is_not_found"], None),  # OOV: the Scorer returns OOV_SCORE before kenlm is asked (scorer.cpp:83-85)
+    (["<s>", "looking", "on"], -0.348837),
+    (["<s>", "looking", "on", "a"], -0.0155266),
+    (["<s>", "looking", "on", "a", "little"], -0.00306122),
+    (["<s>", "looking", "on", "a", "little", "the"], -4.04005),
+    (["<s>", "looking", "on", "a", "little", "the", "biarritz"], -1.9889),
+    (["<s>", "looking", "on", "a", "little", "more"], -0.00181395),
+    (["<s>", "looking", "on", "a", "little", "more", "loin"], -0.0432557),
+    (["also"], -1.687872),
+    (["also", "would"], -2.0),
+    (["also", "would", "consider"], -3.0),          # listed although its suffix "would consider" is not
+    (["also", "would", "consider", "higher"], -4.0),
+    (["also", "would", "consider", "higher", "looking"], -5.0),
+    (["higher"], -1.509559),
+    (["higher", "looking"], -1.285941 - 0.30103),
+    (["higher", "looking", "consider"], -1.687872 - 0.4771212),
+    (["would"], -1.687872),
+    (["would", "consider"], -1.687872 - 0.30103),
+    (["would", "consider", "higher"], -1.509559 - 0.30103),
+    (["would", "consider", "higher", "looking"], -1.285941 - 0.30103),
+    (["more", "."], -0.51363),
+    (["more", ".", "</s>"], -0.0191651),
+]
+
+
+@pytest.mark.parametrize("which", WHICH)
+def test_kenlm_published_values(which):
+    sc = ou.Scorer(0.0, 0.0, TEST_ARPA, VOCAB7, which)
+    assert not sc.is_character_based() and sc.max_order() == 5
+    for words, want in KENLM_KATS:
+        got = sc.cond_logprob(words)
+        if want is None:
+            assert got == -1000.0
+        else:
+            assert abs(got * LOG10E - want) <= 2e-5 * max(1.0, abs(want)), (words, got * LOG10E, want)
+    # get_sent_log_prob (scorer.cpp:95-120): <s> padding to the model order, </s> appended, one window per word
+    s = sc.sent_logprob(["looking", "on", "a", "little"])
+    want = (-0.4846522 - 0.3488368 - 0.01552657 - 0.003061223) + (-1.029493 - 0.4771212 - 0.69897 - 0.69897 - 0.4771212)  # </s> backs off four times
+    assert abs(s * LOG10E - want) < 1e-4
+    assert sc.sent_logprob(["not_a_word"]) <= -1000.0
+
+
+def test_kenlm_published_values_product_tables():
+    """The same expectations against the PRODUCT's scorer tables (back-off automaton of lm_tables.h, built by lm_build.h)."""
+    for words, want in KENLM_KATS:
+        got, meta = ou.core_host_lm_cond(TEST_ARPA, VOCAB7, words)
+        assert meta == (0, 5, 1)
+        if want is None:
+            assert got == -1000.0
+        else:
+            assert abs(got * LOG10E - want) <= 2e-5 * max(1.0, abs(want)), (words, got * LOG10E, want)
+    ref = ou.Scorer(0.0, 0.0, TEST_ARPA, VOCAB7, "restated")
+    rng = np.random.default_rng(3)
+    vocab = ["also", "would", "consider", "higher", "looking", "on", "a", "little", "more", "loin", ".", ",", "<s>", "</s>", "the", "foo", "bar", "baz", "nope"]
+    for _ in range(400):  # bitwise agreement with the restated oracle on random word sequences (incl. unknown words)
+        words = [vocab[i] for i in rng.integers(0, len(vocab), size=int(rng.integers(1, 8)))]
+        got, _ = ou.core_host_lm_cond(TEST_ARPA, VOCAB7, words)
+        assert got == ref.cond_logprob(words), words
+
+
+def _strings(r, vocab, b, n=3):
+    return ["".join(vocab[x] for x in r["tokens"][b, p, : r["lens"][b, p]]) for p in range(n)]
+
+
+@pytest.mark.parametrize("which", WHICH)
+def test_reference_golden_a_a(which):
+    """tests/test_decode.py:55-64 of the reference: probs_seq2 with test.arpa -> "a a" (dictionary gate; alpha = beta = 0)."""
+    args, _ = gu.load("ref_fixtures_prob")
+    sc = ou.Scorer(0.0, 0.0, TEST_ARPA, VOCAB7, which)
+    assert sc.dict_size() == 1  # of the model's words only "a" can be spelled with these labels
+    r = ou.decode(scorer=sc, which=which, **args)
+    assert _strings(r, VOCAB7, 1, 1) == ["a a"] and _strings(r, VOCAB7, 0, 1) == ["a a"]
+
+
+LABELS29 = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]  # blank first
+LM_CASES = [
+    dict(name="testarpa_cfg4", arpa="test.arpa", labels=LABELS29, alpha=0.5, beta=1.0, B=3, T=120, K=32, seed=101, bias={" ": 1.5, "a": 1.0}),
+    dict(name="testarpa_bigbeam", arpa="test.arpa", labels=LABELS29, alpha=1.25, beta=0.3, B=2, T=200, K=100, seed=102, bias={" ": 2.0}),
+    dict(name="abcd_words", arpa="abcd_words.arpa", labels=["_", "a", "b", "c", "d", "'", " "], alpha=0.7, beta=0.9, B=3, T=150, K=40, seed=103, bias={" ": 0.5}),
+    dict(name="abcd_words_negbeta", arpa="abcd_words.arpa", labels=["a", "b", " ", "c", "d", "'", "_"], blank=6, alpha=2.0, beta=-0.5, B=2, T=120, K=16, seed=104),
+    dict(name="abcd_words_full", arpa="abcd_words.arpa", labels=["_", "a", "b", "c", "d", "'", " "], alpha=0.4, beta=2.0, B=2, T=100, K=3, seed=105, quant=0.5),
+    dict(name="chars", arpa="chars.arpa", labels=["_", "a", "b", "c", "d", "'", "é", " "], alpha=0.6, beta=0.2, B=3, T=100, K=24, seed=106),
+    dict(name="chars_prob_input", arpa="chars.arpa", labels=["_", "a", "b", "c", "d", "'", "é"], alpha=1.0, beta=0.0, B=2, T=80, K=50, seed=107, prob_input=True),
+    dict(name="abcd_topn", arpa="abcd_words.arpa", labels=["_", "a", "b", "c", "d", "'", " "], alpha=0.7, beta=0.9, B=2, T=100, K=20, seed=108, top_n=4),
+    dict(name="testarpa_ragged", arpa="test.arpa", labels=LABELS29, alpha=0.5, beta=1.0, B=4, T=60, K=12, seed=109, ragged=True, bias={" ": 1.5}),
+]
+
+
+def lm_case_inputs(c):
+    V = len(c["labels"])
+    blank = c.get("blank", 0)
+    lp = ou.synth_logprobs(c["B"], c["T"], V, c["seed"], quant=c.get("quant"), blank_id=blank)
+    if c.get("bias"):  # favour some labels so that words of the model actually complete
+        x = lp.copy()
+        for ch, v in c["bias"].items():
+            x[:, :, c["labels"].index(ch)] += np.float32(v)
+        m = x.max(-1, keepdims=True)
+        lp = (x - (m + np.log(np.exp(x - m).sum(-1, keepdims=True)))).astype(np.float32)
+    x = np.exp(lp) if c.get("prob_input") else lp
+    sl = np.array([c["T"], 0, 1, c["T"] // 2][: c["B"]], np.int32) if c.get("ragged") else None
+    kw = dict(seq_lens=sl, beam=c["K"], cutoff_top_n=c.get("top_n", 40), blank_id=blank, log_input=not c.get("prob_input"))
+    return np.ascontiguousarray(x), kw
+
+
+@pytest.mark.skipif(not ou.have_reference(), reason="oracle/_ref not built (needs the reference checkout)")
+@pytest.mark.parametrize("c", LM_CASES, ids=lambda c: c["name"])
+def test_lm_live_differential(c):
+    x, kw = lm_case_inputs(c)
+    res = {}
+    for which in ("restated", "reference"):
+        sc = ou.Scorer(c["alpha"], c["beta"], os.path.join(DATA, c["arpa"]), c["labels"], which)
+        res[which] = ou.decode(x, scorer=sc, which=which, **kw)
+        res[which + "_meta"] = (sc.is_character_based(), sc.max_order(), sc.dict_size())
+    assert res["restated_meta"] == res["reference_meta"]
+    ou.assert_same(res["restated"], res["reference"], c["name"])
+    # the scorer must matter: without it the result differs
+    plain = ou.decode(x, which="restated", **kw)
+    assert not np.array_equal(plain["tokens"], res["restated"]["tokens"])
+
+
+@pytest.mark.parametrize("c", LM_CASES, ids=lambda c: c["name"])
+def test_product_core_with_lm_matches_oracle(c):
+    """ctcdecode_amd/csrc/beam_core.h (LM instantiation) + lm_tables.h, host build, against the restated oracle."""
+    x, kw = lm_case_inputs(c)
+    path = os.path.join(DATA, c["arpa"])
+    sc = ou.Scorer(c["alpha"], c["beta"], path, c["labels"], "restated")
+    want = ou.decode(x, scorer=sc, **kw)
+    got = ou.decode_core_host_lm(x, c["alpha"], c["beta"], path, c["labels"], **kw)
+    assert got["meta"] == (int(sc.is_character_based()), sc.max_order(), sc.dict_size())
+    ou.assert_same(got, want, c["name"])
+
+
+def test_product_core_with_lm_random_sweep():
+    rng = np.random.default_rng(11)
+    models = [("abcd_words.arpa", ["_", "a", "b", "c", "d", "'", " "]), ("chars.arpa", ["_", "a", "b", "c", "d", "'", "é", " "]),
+              ("test.arpa", LABELS29)]
+    for it in range(60):
+        arpa, labels = models[it % 3]
+        V = len(labels)
+        K = int(rng.choice([1, 2, 5, 16, 50, 100]))
+        T = int(rng.integers(1, 120))
+        alpha, beta = float(rng.choice([0.0, 0.3, 1.0, 2.5])), float(rng.choice([-1.0, 0.0, 0.5, 1.5]))
+        quant = [None, None, 0.5, 1.0][int(rng.integers(0, 4))]
+        lp = ou.synth_logprobs(2, T, V, 7000 + it, quant=quant)
+        if " " in labels:
+            lp[:, :, labels.index(" ")] += np.float32(rng.choice([0.0, 1.0, 2.0]))
+        top_n = int(rng.choice([40, 40, 5]))
+        sl = rng.integers(0, T + 3, size=2).astype(np.int32) if it % 5 == 0 else None
+        kw = dict(seq_lens=sl, beam=K, cutoff_top_n=top_n, blank_id=0)
+        path = os.path.join(DATA, arpa)
+        sc = ou.Scorer(alpha, beta, path, labels, "restated")
+        ou.assert_same(ou.decode_core_host_lm(lp, alpha, beta, path, labels, **kw), ou.decode(lp, scorer=sc, **kw),
+                       "case %d %s K=%d T=%d alpha=%g beta=%g q=%s" % (it, arpa, K, T, alpha, beta, quant))
+
+
+@pytest.mark.parametrize("name", gu.lm_names())
+def test_restatement_and_product_core_match_committed_lm_fixtures(name):
+    args, lm, want = gu.load_lm(name)
+    sc = ou.Scorer(lm["alpha"], lm["beta"], lm["lm_path"], lm["labels"], "restated")
+    assert (int(sc.is_character_based()), sc.max_order(), sc.dict_size()) == lm["meta"]
+    ou.assert_same(ou.decode(scorer=sc, **args), want, name + " (restated)")
+    got = ou.decode_core_host_lm(args["probs"], lm["alpha"], lm["beta"], lm["lm_path"], lm["labels"],
+                                 **{k: v for k, v in args.items() if k != "probs"})
+    ou.assert_same(got, want, name + " (product core, host build)")
+
+
+def test_reset_params_and_accessors():
+    sc = ou.Scorer(0.5, 1.0, os.path.join(DATA, "abcd_words.arpa"), ["_", "a", "b", "c", "d", "'", " "], "restated")
+    assert not sc.is_character_based() and sc.max_order() == 3 and sc.dict_size() == 17
+    c = LM_CASES[2]
+    x, kw = lm_case_inputs(c)
+    a = ou.decode(x, scorer=sc, **kw)
+    sc.reset_params(0.0, 0.0)  # binding.cpp:283-287
+    b = ou.decode(x, scorer=sc, **kw)
+    assert not np.array_equal(a["scores"], b["scores"])
+    ch = ou.Scorer(0.5, 1.0, os.path.join(DATA, "chars.arpa"), ["_", "a", "b", "c", "d", "'", "é"], "restated")
+    assert ch.is_character_based() and ch.dict_size() == 0
