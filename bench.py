@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gather", choices=["overlap", "sync", "none"], default="overlap",
                     help="N>1: gather the results to rank 0 inside the timed region; 'overlap' lets batch i's gather "
                          "run (RCCL streams) while batch i+1 is decoded, 'sync' finishes it before the next decode")
-    ap.add_argument("--gather-format", choices=["compact", "full"], default="full",
+    ap.add_argument("--gather-format", choices=["compact", "full"], default="compact",
                     help="what travels to rank 0: 'compact' = valid prefixes only, narrow integer types (expanded on rank 0); "
                          "'full' = the four padded tensors")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the gather path even with one rank (self-test)")
@@ -212,10 +212,13 @@ def main():
     if use_dist and a.gather != "none":
         from ctcdecode_amd.distributed import make_gatherer
 
-        gatherer = make_gatherer(a.gather_format, B, K, T, V, dev, dst=0, depth=2)
+        gatherer = make_gatherer(a.gather_format, B, K, T, V, dev, dst=0, depth=2, decoder=dec)
+    compact = gatherer is not None and a.gather_format == "compact"
 
     def step():
-        res = dec.decode_device(lp, None, check=False)
+        # N > 1 with the compact gather: a rank produces its results in compact form (nothing padded is written on it);
+        # rank 0 rebuilds the padded tensors of ALL ranks in its HBM.  N = 1: the padded tensors are written by the decode.
+        res = dec.decode_compact(lp, None) if compact else dec.decode_device(lp, None, check=False)
         if gatherer is not None:
             gatherer.submit(res)
             if a.gather == "sync":

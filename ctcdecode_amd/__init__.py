@@ -140,9 +140,84 @@ class CTCBeamDecoder(object):
         return output, scores, timesteps, out_len
 
     def decode(self, probs, seq_lens=None):
-        """Drop-in for ctcdecode/__init__.py:53-123: returns CPU tensors (output, scores, timesteps, out_seq_len)."""
-        res = self.decode_device(probs, seq_lens)
-        return _to_host(res)
+        """Drop-in for ctcdecode/__init__.py:53-123: returns CPU tensors (output, scores, timesteps, out_seq_len).
+
+        The results leave the GPU in compact form (every beam only the labels it does not share with its neighbour in the
+        trie, include/ctcdecode_amd.h) and ``num_processes`` host threads expand them into the four tensors."""
+        if probs.dim() != 3:
+            raise ValueError("probs must be [batch, time, labels]")
+        on_dev = probs.is_cuda
+        if on_dev:
+            probs = probs.to(device=self._device, dtype=torch.float32).contiguous()
+        else:
+            probs = probs.to(dtype=torch.float32).contiguous()  # ctcdecode/__init__.py:77
+        B, T, V = probs.shape
+        if V != self._num_labels:
+            raise ValueError("probs.shape[2] (%d) does not match the number of labels (%d)" % (V, self._num_labels))
+        if seq_lens is not None:
+            seq_lens = seq_lens.to(device=self._device if on_dev else "cpu", dtype=torch.int32).contiguous()
+            if seq_lens.numel() != B:
+                raise ValueError("seq_lens must have one entry per batch item")
+        K = self._beam_width
+        pin = B * K * T > 0
+        output = torch.empty((B, K, T), dtype=torch.int32, pin_memory=pin)
+        timesteps = torch.empty((B, K, T), dtype=torch.int32, pin_memory=pin)
+        scores = torch.empty((B, K), dtype=torch.float32, pin_memory=pin)
+        out_len = torch.empty((B, K), dtype=torch.int32, pin_memory=pin)
+        with torch.cuda.device(self._device):
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            _native.check(_native.lib.ctcd_beam_decode_to_host(
+                self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, 1 if on_dev else 0, B, T, V, K,
+                self._num_processes, float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
+                self._scorer.handle if self._scorer is not None else None, output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(),
+                out_len.data_ptr(), None, stream))
+        return output, scores, timesteps, out_len
+
+    def decode_padded(self, probs, seq_lens=None):
+        """The same call with the padded [B, K, T] tensors crossing PCIe (the delivery of round 1; kept for comparison)."""
+        return _to_host(self.decode_device(probs, seq_lens))
+
+    def decode_compact(self, probs, seq_lens=None):
+        """Device-resident compact results: (c_hdr [B,4], c_ent [B,K,4], c_labels [n], scores [B,K], out_lens [B,K]) in HBM --
+        what a rank ships to the gathering rank; ``expand_compact`` rebuilds the padded tensors there."""
+        if probs.dim() != 3:
+            raise ValueError("probs must be [batch, time, labels]")
+        probs = probs.to(device=self._device, dtype=torch.float32).contiguous()
+        B, T, V = probs.shape
+        if V != self._num_labels:
+            raise ValueError("probs.shape[2] (%d) does not match the number of labels (%d)" % (V, self._num_labels))
+        if seq_lens is not None:
+            seq_lens = seq_lens.to(device=self._device, dtype=torch.int32).contiguous()
+        K = self._beam_width
+        cap = int(_native.lib.ctcd_compact_label_capacity(B, K, T))
+        with torch.cuda.device(self._device):
+            if getattr(self, "_c_labels", None) is None or self._c_labels.numel() < max(cap, 1):
+                self._c_labels = torch.empty((max(cap, 1),), dtype=torch.int32, device=self._device)  # worst case, reused
+            hdr = torch.empty((B, 4), dtype=torch.int32, device=self._device)
+            ent = torch.empty((B, K, 4), dtype=torch.int32, device=self._device)
+            cnt = torch.empty((1,), dtype=torch.int32, device=self._device)
+            scores = torch.empty((B, K), dtype=torch.float32, device=self._device)
+            out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            _native.check(_native.lib.ctcd_beam_decode_compact(
+                self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K, self._num_processes,
+                float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
+                self._scorer.handle if self._scorer is not None else None, hdr.data_ptr(), ent.data_ptr(), self._c_labels.data_ptr(),
+                cnt.data_ptr(), cap, scores.data_ptr(), out_len.data_ptr(), None, stream))
+            _native.check(_native.lib.ctcd_check_status(self._handle, B))
+            n = int(cnt.item())
+        return hdr, ent, self._c_labels[:n], scores, out_len
+
+    def expand_compact(self, hdr, ent, labels, T):
+        """(c_hdr, c_ent, c_labels) of any number of items -> (output [B,K,T], timesteps [B,K,T]) in HBM."""
+        B, K = int(ent.shape[0]), int(ent.shape[1])
+        with torch.cuda.device(self._device):
+            output = torch.empty((B, K, T), dtype=torch.int32, device=self._device)
+            timesteps = torch.empty((B, K, T), dtype=torch.int32, device=self._device)
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            _native.check(_native.lib.ctcd_expand_compact(self._handle, hdr.contiguous().data_ptr(), ent.contiguous().data_ptr(),
+                                                          labels.contiguous().data_ptr(), B, K, T, output.data_ptr(), timesteps.data_ptr(), stream))
+        return output, timesteps
 
     def character_based(self):  # ctcdecode/__init__.py:125-136: None without a scorer
         return bool(_native.lib.ctcd_scorer_is_character_based(self._scorer.handle)) if self._scorer else None

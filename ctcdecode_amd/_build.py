@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libctcdecode_amd.so")
 SOURCES = ["ctcdecode_amd.hip"]
-HEADERS = ["beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h", os.path.join("..", "..", "include", "ctcdecode_amd.h")]
+HEADERS = ["beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h", "compact_results.h", os.path.join("..", "..", "include", "ctcdecode_amd.h")]
 ROCM = os.environ.get("ROCM_HOME", "/opt/rocm")
 
 

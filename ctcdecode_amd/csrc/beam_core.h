@@ -264,7 +264,17 @@ struct OutRefs {
   int32_t *len;          // [B][K]
   int32_t *n_results;    // [B] or null
   int K, T_stride;
+  // Compact delivery (tok == ts == nullptr): instead of K rows of T labels, every beam entry hands over only the labels it
+  // does not share with its DFS predecessor -- the beam is a trie, its K label sequences overlap almost entirely.
+  //   c_hdr[item]    = {#results, #labels of this item, first label's index in c_rag, 0}
+  //   c_ent[item][j] = {result row of DFS entry j, #labels shared with entry j-1, length, index of its own labels in c_rag}
+  //   c_rag[...]     = label | timestep << 16   (all items share one buffer; *c_count is its bump allocator)
+  int32_t *c_hdr, *c_ent;
+  uint32_t *c_rag;
+  unsigned *c_count;
+  unsigned c_cap;
 };
+enum : int { ST_COMPACT_OVERFLOW = 3 };
 
 // IDENT: the utterance is decoded without vocabulary pruning (candidate r of every frame is label r).  A compile-time
 // switch: the two modes keep different things in flight across a frame (next row vs. next candidate list), and mixing
@@ -1263,7 +1273,8 @@ struct Decoder {
   // DecoderState::decode() + get_beam_search_result + binding.cpp:85-99 for one utterance.
   // `had_steps`: false when the utterance has no frames (fin is then just the root); `max_depth`: bound on the length
   // of a label sequence (the number of frames fed).
-  CTC_HD void finish(bool had_steps, int max_depth, const OutRefs *outs, int item) {
+  // Returns ST_OK, or ST_COMPACT_OVERFLOW when the compact label buffer is too small (identical in every thread).
+  CTC_HD int finish(bool had_steps, int max_depth, const OutRefs *outs, int item) {
     const OutRefs o = *x.fresh(outs);
     const int T_stride = o.T_stride;
     const size_t ko = (size_t)o.K * (size_t)o.T_stride;
@@ -1361,6 +1372,31 @@ struct Decoder {
     }
     x.sync();
     x.mark(4);
+    const bool compact = o.c_hdr != nullptr;
+    unsigned cbase = 0;
+    if (compact) {
+      for (int j = tid; j < nres; j += nt) {
+        const int lo = b.lcp[j] > 0 ? b.lcp[j] : 0;
+        w.pos[j] = (uint32_t)(b.dep[j] > lo ? b.dep[j] - lo : 0);
+      }
+      if (tid == 0) w.pos[nres] = 0;
+      x.sync();
+      const uint32_t total = x.scan_excl(w.pos, nres + 1);
+      if (tid == 0) w.vars[VAR_CUT] = (int)x.global_add(o.c_count, total);
+      x.sync();
+      cbase = (unsigned)x.uni(w.vars[VAR_CUT]);
+      const bool fits = cbase + total <= o.c_cap && cbase + total >= cbase;
+      if (tid == 0) {
+        int32_t *h = o.c_hdr + (size_t)item * 4;
+        h[0] = fits ? nres : 0; h[1] = fits ? (int32_t)total : 0; h[2] = (int32_t)cbase; h[3] = 0;
+        if (!fits) w.vars[VAR_STATUS] = ST_COMPACT_OVERFLOW;
+      }
+      if (!fits) return ST_COMPACT_OVERFLOW;
+      for (int j = tid; j < nres; j += nt) {
+        int32_t *e = o.c_ent + ((size_t)item * o.K + j) * 4;
+        e[0] = row_of[j]; e[1] = b.lcp[j] > 0 ? b.lcp[j] : 0; e[2] = b.dep[j]; e[3] = (int32_t)(cbase + w.pos[j]);
+      }
+    }
     const int maxseg = max_depth / kExpress + 1;
     for (int idx = tid; idx < nres * maxseg; idx += nt) {
       const int i = idx / nres, j = idx - i * nres;
@@ -1379,6 +1415,16 @@ struct Decoder {
         xn = b.up[j];
         for (int h = 1; h < i; ++h) xn = pool_up[xn];
       }
+      if (compact) {
+        uint32_t *seg = o.c_rag + (size_t)cbase + w.pos[j] - lo;  // label at depth q (lo < q <= dj) sits at seg[q - 1]
+        while (dd > stop) {
+          const PoolNode pn = pool[xn];
+          seg[dd - 1] = (uint32_t)pn.ch | ((uint32_t)pn.tstep << 16);
+          xn = pn.parent;
+          --dd;
+        }
+        continue;
+      }
       const size_t row = (size_t)row_of[j] * T_stride;
       int32_t *tk = out_tok + row, *ts = out_ts + row;
       while (dd > stop) {
@@ -1389,6 +1435,7 @@ struct Decoder {
         --dd;
       }
     }
+    if (compact) return ST_OK;
     x.sync_full();  // rows are read back below by other waves
     x.mark(15);
     const int grp = x.group(), ngr = x.ngroups(), lane = x.lane(), lanes = x.lanes();
@@ -1415,6 +1462,7 @@ struct Decoder {
         }
       }
     }
+    return ST_OK;
   }
 };
 
@@ -1508,10 +1556,11 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     if (st != ST_OK) return st;
   }
   if (ss) dec.save_state(*ss, t0 + len);
-  if (!ss || ss->finish) dec.finish(t0 + len > 0, t0 + len, outs, item);
+  int fs = ST_OK;
+  if (!ss || ss->finish) fs = dec.finish(t0 + len > 0, t0 + len, outs, item);
   x.sync();
   x.mark(11);
-  return ST_OK;
+  return fs;
 }
 
 }  // namespace ctcbeam

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <limits>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -23,6 +25,7 @@
 #define CTC_EXACT_MATH_HOST_TABLES
 #include "beam_core.h"
 #include "lm_build.h"
+#include "compact_results.h"
 
 namespace {
 
@@ -168,6 +171,7 @@ struct DevX {
     v = wave_max_u32(v);
     if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
   }
+  __device__ __forceinline__ unsigned global_add(unsigned *p, unsigned v) { return atomicAdd(p, v); }
   __device__ __forceinline__ void wave_min_to(int *p, uint32_t v) {
     v = ~wave_max_u32(~v);
     if ((threadIdx.x & 63) == 0) atomicMin((unsigned *)p, v);
@@ -743,6 +747,39 @@ __global__ void scatter_pruned_kernel(const int32_t *recs, const unsigned *rows,
   }
 }
 
+// Compact results (beam_core.h OutRefs::c_*) -> the reference's tensors: tokens / timesteps [B, K, T], zero outside the
+// valid prefixes.  One workgroup per item; the entries are expanded in DFS order, each row taking what it shares with
+// its predecessor from the predecessor's finished row.
+__global__ void __launch_bounds__(1024) expand_compact_kernel(const int32_t *hdr, const int32_t *ent, const uint32_t *rag, int K, int T,
+                                                              int32_t *tok, int32_t *ts) {
+  const int b = (int)blockIdx.x;
+  const int nres = hdr[(size_t)b * 4];
+  int32_t *tk0 = tok + (size_t)b * K * T, *ts0 = ts + (size_t)b * K * T;
+  int prow = 0;
+  for (int j = 0; j < nres; ++j) {
+    const int32_t *e = ent + ((size_t)b * K + j) * 4;
+    const int row = e[0], lcp = e[1], dep = e[2];
+    const uint32_t *seg = rag + (uint32_t)e[3];
+    int32_t *tk = tk0 + (size_t)row * T, *tt = ts0 + (size_t)row * T;
+    const int32_t *pk = tk0 + (size_t)prow * T, *pt = ts0 + (size_t)prow * T;
+    for (int q = (int)threadIdx.x; q < T; q += (int)blockDim.x) {
+      int32_t c = 0, s = 0;
+      if (q < lcp) { c = pk[q]; s = pt[q]; }
+      else if (q < dep) { const uint32_t v = seg[q - lcp]; c = (int32_t)(v & 0xFFFFu); s = (int32_t)(v >> 16); }
+      tk[q] = c; tt[q] = s;
+    }
+    prow = row;
+    __syncthreads();  // the next entry reads this row
+  }
+  // rows without a result
+  for (int p = 0; p < K; ++p) {
+    bool used = false;
+    for (int j = 0; j < nres; ++j) used = used || ent[((size_t)b * K + j) * 4] == p;
+    if (used) continue;
+    for (int q = (int)threadIdx.x; q < T; q += (int)blockDim.x) { tk0[(size_t)p * T + q] = 0; ts0[(size_t)p * T + q] = 0; }
+  }
+}
+
 __global__ void debug_math_kernel(int mode, uint32_t start, uint32_t stride, const float *xs, const float *ys, float *out,
                                   size_t n, const uint64_t *tables) {
   __shared__ uint64_t tbl[64];
@@ -813,8 +850,55 @@ struct Buf {
 
 }  // namespace
 
+// A few host threads that stay parked between calls (expanding 2 x [B, K, T] on one thread would take longer than the decode)
+struct HostPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  std::function<void(int)> job;
+  int n_items = 0, next = 0, running = 0;
+  unsigned long long epoch = 0;
+  bool stop = false;
+  void start(int n) {
+    for (int i = 0; i < n; ++i) th.emplace_back([this] { loop(); });
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return stop || epoch != seen; });
+      if (stop) return;
+      seen = epoch;
+      for (;;) {
+        if (next >= n_items) break;
+        const int i = next++;
+        lk.unlock();
+        job(i);
+        lk.lock();
+      }
+      if (--running == 0) done_cv.notify_all();
+    }
+  }
+  void run(int items, std::function<void(int)> f) {
+    if (th.empty() || items <= 1) { for (int i = 0; i < items; ++i) f(i); return; }
+    std::unique_lock<std::mutex> lk(mu);
+    job = std::move(f); n_items = items; next = 0; running = (int)th.size(); ++epoch;
+    cv.notify_all();
+    done_cv.wait(lk, [&] { return running == 0; });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+  }
+};
+
 struct ctcd_decoder {
   int device = 0;
+  Buf c_hdr, c_ent, c_rag, c_cnt, c_sc, c_ln;  // compact results of the host-tensor entry points
+  void *h_stage = nullptr;  // page-locked staging for them
+  size_t h_stage_cap = 0;
+  HostPool *workers = nullptr;
   int threads = 0;  // 0 = choose per call from the number of candidate slots
   int max_lds = 0;
   Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
@@ -854,6 +938,13 @@ struct ctcd_scorer {
 };
 
 namespace {
+
+struct CompactOut {          // compact result delivery (beam_core.h OutRefs::c_*); all device pointers
+  int32_t *hdr, *ent;
+  uint32_t *rag;
+  unsigned *count;
+  unsigned cap;
+};
 
 struct StreamCall {          // extra arguments of a streaming decode
   ctcd_stream **states;
@@ -965,6 +1056,9 @@ void ctcd_destroy(ctcd_decoder *d) {
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
   d->dbg.release(); d->tl.release();
+  d->c_hdr.release(); d->c_ent.release(); d->c_rag.release(); d->c_cnt.release(); d->c_sc.release(); d->c_ln.release();
+  if (d->h_stage) (void)hipHostFree(d->h_stage);
+  delete d->workers;
   delete d;
 }
 
@@ -977,13 +1071,14 @@ int ctcd_set_threads(ctcd_decoder *d, int t) {
 static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                          double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, int32_t *out_tok, int32_t *out_ts,
                          float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_, const StreamCall *sc,
-                         ctcd_scorer *scorer = nullptr) {
+                         ctcd_scorer *scorer = nullptr, const CompactOut *co = nullptr) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   if (scorer && scorer->device != d->device) return fail(CTCD_EINVAL, "the scorer's tables live on another device than the decoder");
   if (scorer && (int)scorer->host.labels.size() != V) return fail(CTCD_EINVAL, "the scorer was built for a different number of labels");
   const int out_T = sc ? sc->out_T : T;
   // (a streaming call in which no stream ends has out_T == 0 and may pass null token / timestep buffers)
-  const bool no_rows = sc && out_T == 0;
+  const bool no_rows = (sc && out_T == 0) || co;
+  if (co && (out_T > 65536 || V > 65535)) return fail(CTCD_EUNSUPPORTED, "compact results pack label and frame into 16 bits each");
   int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, no_rows ? (const void *)d : (const void *)out_tok,
                       no_rows ? (const void *)d : (const void *)out_ts, out_sc, out_len);
   if (rc) return rc;
@@ -1013,7 +1108,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (big && (rc = d->far.ensure((size_t)B * far_bytes))) return rc;
 
   // outputs: everything outside the valid region is defined as 0
-  const size_t kt = (size_t)B * beam * out_T;
+  const size_t kt = co ? 0 : (size_t)B * beam * out_T;
+  if (co) {
+    HIP_TRY(hipMemsetAsync(co->count, 0, 4, stream));
+    HIP_TRY(hipMemsetAsync(co->hdr, 0, (size_t)B * 16, stream));
+  }
   if (kt) {
     HIP_TRY(hipMemsetAsync(out_tok, 0, kt * 4, stream));
     HIP_TRY(hipMemsetAsync(out_ts, 0, kt * 4, stream));
@@ -1182,6 +1281,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   a.tables = (const uint64_t *)d->tables.p;
   a.outs.tok = out_tok; a.outs.ts = out_ts; a.outs.len = out_len; a.outs.n_results = n_results; a.outs.score = out_sc;
   a.outs.K = beam; a.outs.T_stride = out_T;
+  a.outs.c_hdr = nullptr; a.outs.c_ent = nullptr; a.outs.c_rag = nullptr; a.outs.c_count = nullptr; a.outs.c_cap = 0;
+  if (co) {
+    a.outs.tok = nullptr; a.outs.ts = nullptr;
+    a.outs.c_hdr = co->hdr; a.outs.c_ent = co->ent; a.outs.c_rag = co->rag; a.outs.c_count = co->count; a.outs.c_cap = co->cap;
+  }
   a.status = (int32_t *)d->status.p;
   a.st_base = st_base; a.st_poolcap = st_cap; a.st_eos = st_eos; a.st_pool_off = (long long)stream_pool_offset(beam);
   a.raw = probs; a.raw_log = log_input;
@@ -1414,40 +1518,139 @@ int ctcd_beam_decode_host(ctcd_decoder *d, const float *probs, const int32_t *se
                                   nullptr, out_tok, out_ts, out_sc, out_len, n_results);
 }
 
+// ---- compact result delivery.  The K label sequences of an utterance overlap almost entirely (the beam
+// is a trie): a decode that hands over, per beam entry, only the labels it does not share with its DFS predecessor moves
+// ~40x fewer bytes than the padded [B, K, T] pair -- over PCIe for the reference's CPU-tensor contract, over xGMI for the
+// multi-GPU gather.  Layout: beam_core.h OutRefs::c_*.
+long long ctcd_compact_label_capacity(int B, int beam, int T) { return (long long)B * beam * T; }  // worst case: nothing shared
+
+int ctcd_beam_decode_compact(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                             int /*num_processes*/, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                             ctcd_scorer *scorer, int32_t *c_hdr, int32_t *c_ent, uint32_t *c_labels, uint32_t *c_count,
+                             long long label_capacity, float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
+  if (!c_hdr || !c_ent || !c_labels || !c_count || label_capacity <= 0) return fail(CTCD_EINVAL, "compact buffers missing");
+  CompactOut co{c_hdr, c_ent, c_labels, c_count, (unsigned)std::min<long long>(label_capacity, 0xFFFFFFFFLL)};
+  return decode_common(d, probs, seq_lens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, out_sc,
+                       out_len, n_results, stream_, nullptr, scorer, &co);
+}
+
+int ctcd_expand_compact(ctcd_decoder *d, const int32_t *c_hdr, const int32_t *c_ent, const uint32_t *c_labels, int B, int beam, int T,
+                        int32_t *out_tok, int32_t *out_ts, void *stream_) {
+  if (!d || B < 0 || beam <= 0 || T < 0) return fail(CTCD_EINVAL, "bad arguments");
+  if (B == 0 || T == 0) return CTCD_OK;
+  if (!c_hdr || !c_ent || !c_labels || !out_tok || !out_ts) return fail(CTCD_EINVAL, "null tensor");
+  CTC_ON_DEVICE(d->device);
+  hipLaunchKernelGGL(expand_compact_kernel, dim3(B), dim3(T >= 1024 ? 1024 : (T >= 256 ? 256 : 64)), 0, (hipStream_t)stream_, c_hdr, c_ent,
+                     c_labels, beam, T, out_tok, out_ts);
+  HIP_TRY(hipGetLastError());
+  return CTCD_OK;
+}
+
+// The reference's call as its Python makes it (ctcdecode/__init__.py:77-123 -> paddle_beam_decode[_lm]): the four results
+// arrive as HOST tensors.  probs / seq_lens may live on either side (probs_on_device != 0: both are device pointers).
+// The kernel hands its results over in compact form, they cross PCIe compact, and host threads expand them.
+int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int probs_on_device, int B, int T, int V,
+                             int beam, int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                             ctcd_scorer *scorer, int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len,
+                             int32_t *n_results, void *stream_) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, out_tok, out_ts, out_sc, out_len);
+  if (rc) return rc;
+  if (B == 0) return CTCD_OK;
+  CTC_ON_DEVICE(d->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t nin = (size_t)B * T * V * 4, kk = (size_t)B * beam;
+  const float *dprobs = probs;
+  const int32_t *dlens = seq_lens;
+  if (!probs_on_device) {
+    const size_t off_sl = (nin + 15) / 16 * 16;
+    if ((rc = d->stage_in.ensure(off_sl + (size_t)B * 4 + 16))) return rc;
+    char *din = (char *)d->stage_in.p;
+    if (nin) HIP_TRY(hipMemcpyAsync(din, probs, nin, hipMemcpyHostToDevice, stream));
+    if (seq_lens) HIP_TRY(hipMemcpyAsync(din + off_sl, seq_lens, (size_t)B * 4, hipMemcpyHostToDevice, stream));
+    dprobs = (const float *)din;
+    dlens = seq_lens ? (const int32_t *)(din + off_sl) : nullptr;
+  }
+  if (T > 65536 || V > 65535 || T == 0) {  // outside the compact format's 16-bit fields: the padded tensors travel
+    const size_t kt = kk * T * 4;
+    const size_t o_ts = (kt + 15) / 16 * 16, o_sc = o_ts * 2, o_ln = o_sc + (kk * 4 + 15) / 16 * 16, o_nr = o_ln + (kk * 4 + 15) / 16 * 16;
+    if ((rc = d->stage_out.ensure(o_nr + (size_t)B * 4 + 16))) return rc;
+    char *dout = (char *)d->stage_out.p;
+    rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, (int32_t *)dout, (int32_t *)(dout + o_ts),
+                       (float *)(dout + o_sc), (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), stream, nullptr, scorer);
+    if (rc) return rc;
+    if ((rc = ctcd_check_status(d, B))) return rc;
+    if (kt) {
+      HIP_TRY(hipMemcpy(out_tok, dout, kt, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(out_ts, dout + o_ts, kt, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipMemcpy(out_sc, dout + o_sc, kk * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_len, dout + o_ln, kk * 4, hipMemcpyDeviceToHost));
+    if (n_results) HIP_TRY(hipMemcpy(n_results, dout + o_nr, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return CTCD_OK;
+  }
+  const long long cap = ctcd_compact_label_capacity(B, beam, T);
+  if (cap > 0xFFFFFFFFLL) return fail(CTCD_EUNSUPPORTED, "batch too large for one compact label buffer; split the batch");
+  if ((rc = d->c_hdr.ensure((size_t)B * 16)) || (rc = d->c_ent.ensure(kk * 16)) || (rc = d->c_rag.ensure((size_t)cap * 4)) ||
+      (rc = d->c_cnt.ensure(256)) || (rc = d->c_sc.ensure(kk * 4)) || (rc = d->c_ln.ensure(kk * 4 + (size_t)B * 4)))
+    return rc;
+  int32_t *d_nres = (int32_t *)((char *)d->c_ln.p + kk * 4);
+  CompactOut co{(int32_t *)d->c_hdr.p, (int32_t *)d->c_ent.p, (uint32_t *)d->c_rag.p, (unsigned *)d->c_cnt.p, (unsigned)cap};
+  rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, (float *)d->c_sc.p,
+                     (int32_t *)d->c_ln.p, d_nres, stream, nullptr, scorer, &co);
+  if (rc) return rc;
+  // page-locked staging: [count | hdr | ent | labels]
+  const size_t o_hdr = 256, o_ent = o_hdr + (size_t)B * 16, o_lab = (o_ent + kk * 16 + 255) / 256 * 256;
+  const size_t first = o_lab;
+  size_t need = o_lab + (size_t)64 * 1024 * 1024 / 4;  // grown below when the labels need more
+  if (d->h_stage_cap < first + 4096) {
+    if (d->h_stage) (void)hipHostFree(d->h_stage);
+    d->h_stage = nullptr;
+    d->h_stage_cap = 0;
+    HIP_TRY(hipHostMalloc(&d->h_stage, need, hipHostMallocDefault));
+    d->h_stage_cap = need;
+  }
+  char *hs = (char *)d->h_stage;
+  HIP_TRY(hipMemcpyAsync(hs, d->c_cnt.p, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(hs + o_hdr, d->c_hdr.p, (size_t)B * 16, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(hs + o_ent, d->c_ent.p, kk * 16, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(out_sc, d->c_sc.p, kk * 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(out_len, d->c_ln.p, kk * 4, hipMemcpyDeviceToHost, stream));
+  if (n_results) HIP_TRY(hipMemcpyAsync(n_results, d_nres, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+  if ((rc = ctcd_check_status(d, B))) return rc;  // (synchronises the stream)
+  const size_t nlab = *(const unsigned *)hs;
+  if (o_lab + nlab * 4 > d->h_stage_cap) {  // rare: more unshared labels than the staging block holds -- take a bigger one
+    std::vector<char> keep(hs, hs + o_lab);
+    (void)hipHostFree(d->h_stage);
+    d->h_stage = nullptr;
+    d->h_stage_cap = 0;
+    need = o_lab + nlab * 4 + (nlab * 4) / 4;
+    HIP_TRY(hipHostMalloc(&d->h_stage, need, hipHostMallocDefault));
+    d->h_stage_cap = need;
+    hs = (char *)d->h_stage;
+    std::memcpy(hs, keep.data(), o_lab);
+  }
+  if (nlab) HIP_TRY(hipMemcpyAsync(hs + o_lab, d->c_rag.p, nlab * 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (!d->workers) {
+    d->workers = new HostPool;
+    const int want = num_processes > 0 ? num_processes : 4;  // the reference's num_processes = host threads for the results
+    d->workers->start(std::max(1, std::min({want, (int)std::thread::hardware_concurrency(), 64})));
+  }
+  const int32_t *hh = (const int32_t *)(hs + o_hdr), *he = (const int32_t *)(hs + o_ent);
+  const uint32_t *hl = (const uint32_t *)(hs + o_lab);
+  d->workers->run(B, [=](int b) { ctcbeam::expand_item_host(hh, he, hl, b, beam, T, out_tok, out_ts); });
+  return CTCD_OK;
+}
+
 // paddle_beam_decode_lm as the reference's Python calls it (binding.cpp:122-140): CPU tensors in, CPU tensors out.
 // scorer == NULL decodes without a language model.
 int ctcd_beam_decode_lm_host(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                              int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
                              ctcd_scorer *scorer, int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len,
                              int32_t *n_results) {
-  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
-  int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, out_tok, out_ts, out_sc, out_len);
-  if (rc) return rc;
-  if (B == 0) return CTCD_OK;
-  CTC_ON_DEVICE(d->device);
-  const size_t nin = (size_t)B * T * V * 4, kt = (size_t)B * beam * T * 4, kk = (size_t)B * beam * 4;
-  const size_t off_sl = (nin + 15) / 16 * 16;
-  if ((rc = d->stage_in.ensure(off_sl + (size_t)B * 4 + 16))) return rc;
-  const size_t o_ts = (kt + 15) / 16 * 16, o_sc = o_ts * 2, o_ln = o_sc + (kk + 15) / 16 * 16, o_nr = o_ln + (kk + 15) / 16 * 16;
-  if ((rc = d->stage_out.ensure(o_nr + (size_t)B * 4 + 16))) return rc;
-  char *din = (char *)d->stage_in.p, *dout = (char *)d->stage_out.p;
-  if (nin) HIP_TRY(hipMemcpy(din, probs, nin, hipMemcpyHostToDevice));
-  if (seq_lens) HIP_TRY(hipMemcpy(din + off_sl, seq_lens, (size_t)B * 4, hipMemcpyHostToDevice));
-  (void)num_processes;
-  rc = decode_common(d, (const float *)din, seq_lens ? (const int32_t *)(din + off_sl) : nullptr, B, T, V, beam, cutoff_prob,
-                     cutoff_top_n, blank_id, log_input, (int32_t *)dout, (int32_t *)(dout + o_ts), (float *)(dout + o_sc),
-                     (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), nullptr, nullptr, scorer);
-  if (rc) return rc;
-  if ((rc = ctcd_check_status(d, B))) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  if (kt) {
-    HIP_TRY(hipMemcpy(out_tok, dout, kt, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_ts, dout + o_ts, kt, hipMemcpyDeviceToHost));
-  }
-  HIP_TRY(hipMemcpy(out_sc, dout + o_sc, kk, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_len, dout + o_ln, kk, hipMemcpyDeviceToHost));
-  if (n_results) HIP_TRY(hipMemcpy(n_results, dout + o_nr, (size_t)B * 4, hipMemcpyDeviceToHost));
-  return CTCD_OK;
+  return ctcd_beam_decode_to_host(d, probs, seq_lens, 0, B, T, V, beam, num_processes, cutoff_prob, cutoff_top_n, blank_id, log_input,
+                                  scorer, out_tok, out_ts, out_sc, out_len, n_results, nullptr);
 }
 
 // HIP-event timing of the decode kernel alone, on the stream it is launched on (bench.py's roofline figure).

@@ -101,9 +101,86 @@ class ResultGatherer(object):
         return self._recv[slot] if self._recv is not None else None
 
 
-def make_gatherer(fmt, B, K, T, V, device, dst=0, group=None, depth=2):
-    """The gatherer bench.py / a serving loop uses: ``fmt`` = "full" (the four padded tensors travel) or "compact"."""
+class CompactGatherer(object):
+    """Gather of COMPACT results (include/ctcdecode_amd.h "Compact result delivery"): every rank ships, per beam entry, only
+    the labels it does not share with its neighbour in the trie -- an order of magnitude fewer bytes than the padded
+    [B, K, T] pair -- and ``dst`` rebuilds the padded tensors of the whole batch in its HBM with one expansion kernel.
+
+    Two small steps per batch: the label counts are gathered (one int64 per rank), then each rank's three buffers travel
+    point to point (every peer has its own xGMI link to the root).  ``submit`` returns at once; ``wait`` drains and, on
+    ``dst``, leaves the expanded tensors of the last batch in ``self.last`` = (output, scores, timesteps, out_lens)."""
+
+    def __init__(self, decoder, T, dst=0, group=None, depth=2):
+        self.dec, self.T, self.dst, self.group = decoder, T, dst, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.depth = max(1, depth)
+        self._host_only = dist.get_backend(group) == "gloo"
+        self._inflight = []
+        self.last = None
+
+    def _xfer(self, t):
+        return t.cpu() if self._host_only and t.is_cuda else t
+
+    def submit(self, compact):
+        hdr, ent, labels, scores, lens = compact
+        while len(self._inflight) >= self.depth:
+            self._finish(self._inflight.pop(0))
+        dev = hdr.device
+        n_here = torch.tensor([labels.numel()], dtype=torch.int64, device="cpu" if self._host_only else dev)
+        counts = [torch.zeros_like(n_here) for _ in range(self.world)] if self.rank == self.dst else None
+        dist.gather(n_here, counts, dst=self.dst, group=self.group)
+        works, recv = [], None
+        if self.rank == self.dst:
+            ns = [int(c.item()) for c in counts]
+            recv = []
+            for r in range(self.world):
+                if r == self.dst:
+                    recv.append((hdr, ent, labels, scores, lens))
+                    continue
+                bufs = (torch.empty_like(self._xfer(hdr)), torch.empty_like(self._xfer(ent)),
+                        torch.empty((max(ns[r], 1),), dtype=labels.dtype, device="cpu" if self._host_only else dev),
+                        torch.empty_like(self._xfer(scores)), torch.empty_like(self._xfer(lens)))
+                works += [dist.irecv(b, src=r, group=self.group) for b in bufs]
+                recv.append(bufs)
+        else:
+            lab = labels if labels.numel() else torch.zeros((1,), dtype=labels.dtype, device=labels.device)
+            keep = [self._xfer(t).contiguous() for t in (hdr, ent, lab, scores, lens)]
+            works += [dist.isend(t, dst=self.dst, group=self.group) for t in keep]
+            recv = keep  # keep the sources alive until the sends completed
+        self._inflight.append((works, recv, dev))
+
+    def _finish(self, item):
+        works, recv, dev = item
+        for wk in works:
+            wk.wait()
+        if self.rank != self.dst:
+            return
+        hdrs, ents, labs, scs, lns = [], [], [], [], []
+        base = 0
+        for h, e, lab, sc, ln in recv:
+            h, e, lab, sc, ln = (t.to(dev) for t in (h, e, lab, sc, ln))
+            n = int(h[:, 1].sum().item())
+            e = e.clone()
+            e[:, :, 3] += base  # label indices (relative to the rank's own buffer) rebased onto the concatenated one
+            hdrs.append(h); ents.append(e); labs.append(lab[:n] if n else lab[:0]); scs.append(sc); lns.append(ln)
+            base += n
+        hdr, ent = torch.cat(hdrs, 0), torch.cat(ents, 0)
+        labels = torch.cat(labs, 0) if base else torch.zeros((1,), dtype=torch.int32, device=dev)
+        out, ts = self.dec.expand_compact(hdr, ent, labels, self.T)
+        self.last = (out, torch.cat(scs, 0), ts, torch.cat(lns, 0))
+
+    def wait(self):
+        while self._inflight:
+            self._finish(self._inflight.pop(0))
+
+
+def make_gatherer(fmt, B, K, T, V, device, dst=0, group=None, depth=2, decoder=None):
+    """The gatherer bench.py / a serving loop uses: ``fmt`` = "full" (the four padded tensors travel) or "compact"
+    (the trie-compact form travels; needs the ``decoder`` to expand it on ``dst``)."""
     if fmt == "full":
         shapes = [((B, K, T), torch.int32), ((B, K), torch.float32), ((B, K, T), torch.int32), ((B, K), torch.int32)]
         return ResultGatherer(shapes, device, dst=dst, group=group, depth=depth)
+    if fmt == "compact":
+        return CompactGatherer(decoder, T, dst=dst, group=group, depth=depth)
     raise ValueError("unknown gather format %r" % (fmt,))

@@ -59,6 +59,30 @@ int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *
                           int32_t *out_tokens, int32_t *out_timesteps, float *out_scores, int32_t *out_lens,
                           int32_t *n_results);
 
+/* ---- Compact result delivery (no reference counterpart: the reference fills two padded [B, beam, T] tensors,
+ * binding.cpp:85-99).  The beam is a trie, so its label sequences overlap almost entirely; in compact form every beam
+ * entry hands over only the labels it does not share with its predecessor in trie (DFS) order:
+ *   c_hdr    int32 [B][4]        {#results, #labels of the item, index of its first label in c_labels, 0}
+ *   c_ent    int32 [B][beam][4]  per entry j in DFS order: {result row, #labels shared with entry j-1, length, index of its own labels}
+ *   c_labels uint32 [capacity]   label | frame << 16 (T <= 65536, V <= 65535), one bump-allocated buffer for the batch
+ *   c_count  uint32 [1]          labels used (device word, zeroed by the call)
+ * ctcd_beam_decode_compact = ctcd_beam_decode[_lm] (scorer may be NULL) writing this form (everything device memory);
+ * ctcd_expand_compact rebuilds out_tokens / out_timesteps [B, beam, T] on the device (e.g. on the rank that gathered them);
+ * ctcd_beam_decode_to_host is the reference's whole call -- results as HOST tensors, inputs on either side -- with the
+ * compact form crossing PCIe and `num_processes` host threads expanding it. */
+long long ctcd_compact_label_capacity(int B, int beam, int T);
+typedef struct ctcd_scorer ctcd_scorer;
+int ctcd_beam_decode_compact(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
+                             int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                             ctcd_scorer *scorer, int32_t *c_hdr, int32_t *c_ent, uint32_t *c_labels, uint32_t *c_count,
+                             long long label_capacity, float *out_scores, int32_t *out_lens, int32_t *n_results, void *stream);
+int ctcd_expand_compact(ctcd_decoder *dec, const int32_t *c_hdr, const int32_t *c_ent, const uint32_t *c_labels, int B, int beam,
+                        int T, int32_t *out_tokens, int32_t *out_timesteps, void *stream);
+int ctcd_beam_decode_to_host(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int probs_on_device, int B, int T, int V,
+                             int beam, int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                             ctcd_scorer *scorer, int32_t *out_tokens, int32_t *out_timesteps, float *out_scores,
+                             int32_t *out_lens, int32_t *n_results, void *stream);
+
 /* ---- LM tier: the external scorer.  Replaces ctcdecode/src/binding.cpp:122-150,263-287:
  *   ctcd_scorer_create          <- paddle_get_scorer(alpha, beta, lm_path, labels, vocab_size)   (binding.cpp:143-150)
  *   ctcd_scorer_destroy         <- paddle_release_scorer                                          (binding.cpp:263-265)
@@ -70,7 +94,6 @@ int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *
  * V NUL-terminated UTF-8 strings.  Word models need a " " label and at most 64 labels.  LM arithmetic follows kenlm's
  * published algorithm (float32 weights, longest listed n-gram, back-off weights added in float32); see DESIGN.md for
  * what this parity is pinned to. */
-typedef struct ctcd_scorer ctcd_scorer;
 int ctcd_scorer_create(ctcd_scorer **out, double alpha, double beta, const char *lm_path, const char *const *labels, int V,
                        int device_id);
 void ctcd_scorer_destroy(ctcd_scorer *scorer);

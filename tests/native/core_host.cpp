@@ -5,6 +5,7 @@
 #define CTC_EXACT_MATH_HOST_TABLES
 #include "../../ctcdecode_amd/csrc/beam_core.h"
 #include "../../ctcdecode_amd/csrc/lm_build.h"
+#include "../../ctcdecode_amd/csrc/compact_results.h"
 
 #include <algorithm>
 #include <atomic>
@@ -85,6 +86,7 @@ struct HostX {
   }
   void wave_max_to(int *p, uint32_t v) { *p = (int)std::max((uint32_t)*p, v); }
   void wave_min_to(int *p, uint32_t v) { *p = (int)std::min((uint32_t)*p, v); }
+  unsigned global_add(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
 };
 
 // Vocabulary pruning exactly as the reference does it (decoder_utils.cpp:10-45) -- host stand-in for the GPU prune pass.
@@ -161,6 +163,37 @@ extern "C" int ctccore_decode_lm_f32(const float *probs, const int32_t *seq_lens
                      out_scores, out_lens, n_results, &view, probs, log_input);
 }
 
+// Compact result delivery: decode every item into the compact form (one shared label buffer, bump-allocated), then expand
+// it with the product's host expansion.  Must reproduce the padded results exactly; *labels_used reports the sharing.
+extern "C" int ctccore_decode_compact_f32(const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, int blank_id,
+                                          int32_t *out_tokens, int32_t *out_timesteps, float *out_scores, int32_t *out_lens,
+                                          int32_t *n_results, long long *labels_used) {
+  using namespace ctcbeam;
+  Dims d;
+  d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0; d.lm = 0;
+  Work w;
+  size_t far_bytes = 0;
+  std::vector<char> mem(carve<false>(w, nullptr, nullptr, d, &far_bytes) + 64);
+  std::vector<int32_t> hdr((size_t)B * 4, 0), ent((size_t)B * beam * 4, 0);
+  std::vector<uint32_t> rag((size_t)B * beam * T + 1);
+  unsigned count = 0;
+  for (int b = 0; b < B; ++b) {
+    std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
+    std::vector<int> pool_up(pool.size());
+    int len = seq_lens ? seq_lens[b] : T;
+    len = std::max(0, std::min(len, T));
+    carve<false>(w, mem.data(), nullptr, d, nullptr);
+    HostX x;
+    const OutRefs outs{nullptr, nullptr, out_scores, out_lens, n_results, beam, T, hdr.data(), ent.data(), rag.data(), &count, (unsigned)(rag.size() - 1)};
+    int st = decode_utterance<true>(x, w, d, blank_id, probs + (size_t)b * T * V, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(),
+                                    (int)pool.size(), ctcmath::host_tables().w, &outs, b);
+    if (st != ST_OK) return -st;
+  }
+  for (int b = 0; b < B; ++b) expand_item_host(hdr.data(), ent.data(), rag.data(), b, beam, T, out_tokens, out_timesteps);
+  if (labels_used) *labels_used = count;
+  return 1;
+}
+
 // Scorer::get_log_cond_prob through the product's tables (host copy): words = n NUL-terminated strings
 extern "C" double ctccore_lm_cond(const char *lm_path, const char *labels, int V, const char *words, int n, int32_t *meta3) {
   std::vector<std::string> lab(V), ws(n);
@@ -207,7 +240,7 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
       if (pruned)
         for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
       int st;
-      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T};
+      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u};
       if (lm) {
         const float *rawb = raw + (size_t)b * T * V;
         if (pruned) st = decode_utterance<false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
@@ -258,7 +291,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       carve<false>(w, mem.data(), nullptr, d, nullptr);
       HostX x;
       StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
-      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T};
+      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u};
       int st = decode_utterance<true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
                                 pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss);
       if (st != ST_OK) return -st;

@@ -170,7 +170,7 @@ def build_core_host():
     import subprocess
 
     src = os.path.join(ROOT, "tests", "native", "core_host.cpp")
-    deps = [src] + [os.path.join(ROOT, "ctcdecode_amd", "csrc", f) for f in ("beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h")]
+    deps = [src] + [os.path.join(ROOT, "ctcdecode_amd", "csrc", f) for f in ("beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h", "compact_results.h")]
     if os.path.exists(CORE_HOST_SO) and all(os.path.getmtime(CORE_HOST_SO) >= os.path.getmtime(p) for p in deps):
         return CORE_HOST_SO
     os.makedirs(os.path.dirname(CORE_HOST_SO), exist_ok=True)
@@ -221,6 +221,26 @@ def decode_core_host_lm(probs, alpha, beta, lm_path, labels, seq_lens=None, beam
     if rc != 1:
         raise RuntimeError("core returned %d" % rc)
     return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres, meta=tuple(int(v) for v in meta))
+
+
+def decode_core_host_compact(probs, seq_lens=None, beam=100, blank_id=0):
+    """The host build of the core writing COMPACT results, expanded by the product's host expansion (compact_results.h)."""
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    B, T, V = probs.shape
+    if seq_lens is not None:
+        seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    tok = np.full((B, beam, T), -9, np.int32)
+    ts = np.full((B, beam, T), -9, np.int32)
+    sc = np.zeros((B, beam), np.float32)
+    ln = np.zeros((B, beam), np.int32)
+    nres = np.zeros((B,), np.int32)
+    used = ctypes.c_longlong(0)
+    lib = ctypes.CDLL(build_core_host())
+    rc = lib.ctccore_decode_compact_f32(_ptr(probs, _f32p), _ptr(seq_lens, _i32p), B, T, V, beam, blank_id, _ptr(tok, _i32p), _ptr(ts, _i32p),
+                                        _ptr(sc, _f32p), _ptr(ln, _i32p), _ptr(nres, _i32p), ctypes.byref(used))
+    if rc != 1:
+        raise RuntimeError("core returned %d" % rc)
+    return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres, labels_used=int(used.value))
 
 
 def core_host_lm_cond(lm_path, labels, words):

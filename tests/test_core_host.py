@@ -109,3 +109,20 @@ def test_core_helpers():
     lib.ctccore_check_helpers.restype = ctypes.c_longlong
     lib.ctccore_check_helpers.argtypes = [ctypes.c_ulonglong, ctypes.c_longlong]
     assert lib.ctccore_check_helpers(12345, 2_000_000) == 0
+
+
+def test_compact_results_expand_to_the_padded_tensors():
+    """Compact delivery (beam_core.h OutRefs::c_*, compact_results.h): every entry hands over only the labels it does not
+    share with its DFS predecessor; expanded, the result must be the padded tensors exactly -- zeros included."""
+    for seed, (B, T, V, K, kw) in enumerate([(3, 200, 29, 50, {}), (2, 150, 9, 100, dict(quant=0.5)), (4, 60, 29, 16, dict(ragged=True)),
+                                             (2, 2, 3, 50, dict(blank_id=1)), (2, 300, 29, 100, dict(blank_bias=4.0))]):
+        blank = kw.get("blank_id", 0)
+        lp = ou.synth_logprobs(B, T, V, 300 + seed, quant=kw.get("quant"), blank_bias=kw.get("blank_bias", 0.0), blank_id=blank)
+        sl = np.array([T, 0, 1, T // 2][:B], np.int32) if kw.get("ragged") else None
+        want = ou.decode(lp, sl, beam=K, blank_id=blank)
+        got = ou.decode_core_host_compact(lp, sl, beam=K, blank_id=blank)
+        ou.assert_same(got, want, "compact case %d" % seed)
+        assert np.array_equal(got["tokens"], want["tokens"]) and np.array_equal(got["timesteps"], want["timesteps"])  # the zero fill too
+        assert got["labels_used"] <= int(want["lens"].sum())
+        if T >= 150 and not kw.get("blank_bias"):
+            assert got["labels_used"] * 2 < int(want["lens"].sum()), "the beam's sequences overlap: far fewer labels travel than rows hold"

@@ -192,6 +192,57 @@ def test_sharded_decode_real_hip_world2(B):
     assert dict(ret) == {0: True, 1: True}
 
 
+def _gpu_compact_worker(rank, world, port, ret):
+    """Two ranks on cuda:0 over gloo: each decodes its own batch in compact form, rank 0 gathers and expands both."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import oracle_util as ou
+
+    import ctcdecode_amd
+    from ctcdecode_amd import distributed as dd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, T, V, K = 6, 150, 29, 32
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], beam_width=K, log_probs_input=True, device="cuda:0")
+    g = dd.make_gatherer("compact", B, K, T, V, torch.device("cuda:0"), dst=0, depth=2, decoder=dec)
+    ok = True
+    for step in range(3):  # more submissions than pipeline slots
+        lp = [ou.synth_logprobs(B, T, V, 9000 + 10 * step + r) for r in range(world)]
+        g.submit(dec.decode_compact(torch.from_numpy(lp[rank])))
+        if step == 2:
+            g.wait()
+            if rank == 0:
+                out, sc, ts, ln = (t.cpu().numpy() for t in g.last)
+                want = ou.decode(np.concatenate(lp, 0), beam=K)
+                got = dict(tokens=out, scores=sc, timesteps=ts, lens=ln, nres=want["nres"])
+                ou.assert_same(got, want, "compact gather over 2 ranks")
+                ok = bool(np.array_equal(out, want["tokens"]) and np.array_equal(ts, want["timesteps"]))
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_compact_gather_real_hip_world2():
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_gpu_compact_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
+
+
 @pytest.mark.gpu
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (they share the one device

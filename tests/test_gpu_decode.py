@@ -418,3 +418,30 @@ def test_workgroup_size_must_be_a_power_of_two(torch_mod):
     for bad in (32, 96, 768, 2048, -64):
         with pytest.raises(ValueError):
             dec.set_threads(bad)
+
+
+def test_result_delivery_paths_agree(torch_mod):
+    """decode() (compact over PCIe + host expansion), decode_padded() (padded tensors over PCIe), decode_device() (HBM) and
+    decode_compact() + expand_compact() must give identical tensors, zero fill included; inputs on either side."""
+    import ctcdecode_amd
+
+    for seed, (B, T, V, K, ragged) in enumerate([(5, 300, 29, 100, True), (3, 120, 9, 40, False), (2, 1, 29, 7, False), (300, 50, 29, 8, False)]):
+        lp = ou.synth_logprobs(B, T, V, 1200 + seed, quant=0.5 if seed == 1 else None)
+        sl = np.array([(53 * i) % (T + 4) for i in range(B)], np.int32) if ragged else None
+        dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], beam_width=K, log_probs_input=True, num_processes=7)
+        x = torch_mod.from_numpy(lp)
+        s = torch_mod.from_numpy(sl) if sl is not None else None
+        a = dec.decode(x, s)
+        b = dec.decode_padded(x, s)
+        c = dec.decode(x.cuda(), s.cuda() if s is not None else None)
+        d = tuple(t.cpu() for t in dec.decode_device(x, s))
+        hdr, ent, labels, sc, ln = dec.decode_compact(x, s)
+        out, ts = dec.expand_compact(hdr, ent, labels, T)
+        e = (out.cpu(), sc.cpu(), ts.cpu(), ln.cpu())
+        for other, name in ((b, "padded"), (c, "device input"), (d, "decode_device"), (e, "compact + device expansion")):
+            for i in range(4):
+                assert torch_mod.equal(a[i], other[i]), "%s differs in tensor %d (case %d)" % (name, i, seed)
+        assert int(labels.numel()) <= int(ln.sum())
+        want = ou.decode(lp, sl, beam=K)
+        got = dict(tokens=a[0].numpy(), scores=a[1].numpy(), timesteps=a[2].numpy(), lens=a[3].numpy())
+        ou.assert_same(_with_nres(got, want), want, "delivery case %d" % seed)
