@@ -132,7 +132,10 @@ def other_configs(torch, ctcdecode_amd, dev):
     def run(name, B, T, V, K, top_n=40, cutoff_prob=1.0, reps=2, **kw):
         g = torch.Generator(device="cpu").manual_seed(7)
         lp = torch.randn((B, T, V), generator=g).log_softmax(-1).to(dev)
-        dec = ctcdecode_amd.CTCBeamDecoder([str(i) if i != 1 else " " for i in range(V)], cutoff_top_n=top_n, cutoff_prob=cutoff_prob, beam_width=K,
+        labels = [str(i) for i in range(V)]
+        if V == 29:  # blank, apostrophe, space, a..z: the words of tests/data/test.arpa can be spelled
+            labels = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
+        dec = ctcdecode_amd.CTCBeamDecoder(labels, cutoff_top_n=top_n, cutoff_prob=cutoff_prob, beam_width=K,
                                            log_probs_input=True, device=dev, **kw)
         dec.set_timing(True)
         ks, ps = [], []

@@ -748,35 +748,56 @@ __global__ void scatter_pruned_kernel(const int32_t *recs, const unsigned *rows,
 }
 
 // Compact results (beam_core.h OutRefs::c_*) -> the reference's tensors: tokens / timesteps [B, K, T], zero outside the
-// valid prefixes.  One workgroup per item; the entries are expanded in DFS order, each row taking what it shares with
-// its predecessor from the predecessor's finished row.
+// valid prefixes.  HBM-bound (it writes 8 B per label position of the padded pair).  One workgroup per item; every wave
+// takes whole rows, its lanes consecutive label positions (coalesced 256-byte stores).  Label q of DFS entry j is held
+// by the nearest entry o <= j with lcp[o] <= q; owner[] (the nearest earlier entry that shares LESS with its own
+// predecessor) lets the search skip runs of entries, as in the decode kernel's own back-trace.
+constexpr int kExpandMaxK = 4096;  // entries whose tables fit LDS; wider beams take the generic slow loop
 __global__ void __launch_bounds__(1024) expand_compact_kernel(const int32_t *hdr, const int32_t *ent, const uint32_t *rag, int K, int T,
                                                               int32_t *tok, int32_t *ts) {
+  extern __shared__ int esm[];
+  int *lcp = esm, *dep = esm + K, *off = esm + 2 * K, *row = esm + 3 * K, *owner = esm + 4 * K;
+  unsigned *used = (unsigned *)(esm + 5 * K);  // K bits
   const int b = (int)blockIdx.x;
   const int nres = hdr[(size_t)b * 4];
   int32_t *tk0 = tok + (size_t)b * K * T, *ts0 = ts + (size_t)b * K * T;
-  int prow = 0;
-  for (int j = 0; j < nres; ++j) {
-    const int32_t *e = ent + ((size_t)b * K + j) * 4;
-    const int row = e[0], lcp = e[1], dep = e[2];
-    const uint32_t *seg = rag + (uint32_t)e[3];
-    int32_t *tk = tk0 + (size_t)row * T, *tt = ts0 + (size_t)row * T;
-    const int32_t *pk = tk0 + (size_t)prow * T, *pt = ts0 + (size_t)prow * T;
-    for (int q = (int)threadIdx.x; q < T; q += (int)blockDim.x) {
-      int32_t c = 0, s = 0;
-      if (q < lcp) { c = pk[q]; s = pt[q]; }
-      else if (q < dep) { const uint32_t v = seg[q - lcp]; c = (int32_t)(v & 0xFFFFu); s = (int32_t)(v >> 16); }
-      tk[q] = c; tt[q] = s;
-    }
-    prow = row;
-    __syncthreads();  // the next entry reads this row
+  for (int i = (int)threadIdx.x; i < (K + 31) / 32; i += (int)blockDim.x) used[i] = 0u;
+  for (int j = (int)threadIdx.x; j < nres; j += (int)blockDim.x) {
+    const int4 e = *reinterpret_cast<const int4 *>(ent + ((size_t)b * K + j) * 4);
+    row[j] = e.x; lcp[j] = j == 0 ? 0 : e.y; dep[j] = e.z; off[j] = e.w;
   }
-  // rows without a result
-  for (int p = 0; p < K; ++p) {
-    bool used = false;
-    for (int j = 0; j < nres; ++j) used = used || ent[((size_t)b * K + j) * 4] == p;
-    if (used) continue;
-    for (int q = (int)threadIdx.x; q < T; q += (int)blockDim.x) { tk0[(size_t)p * T + q] = 0; ts0[(size_t)p * T + q] = 0; }
+  __syncthreads();
+  for (int j = (int)threadIdx.x; j < nres; j += (int)blockDim.x) {
+    int o = j - 1;
+    const int l = lcp[j];
+    while (o >= 0 && lcp[o] >= l) --o;
+    owner[j] = o < 0 ? 0 : o;
+    atomicOr(&used[row[j] >> 5], 1u << (row[j] & 31));
+  }
+  __syncthreads();
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, nw = (int)blockDim.x >> 6;
+  for (int j = wave; j < K; j += nw) {
+    if (j < nres) {
+      int32_t *tk = tk0 + (size_t)row[j] * T, *tt = ts0 + (size_t)row[j] * T;
+      const int dj = dep[j];
+      for (int q = lane; q < T; q += 64) {
+        int32_t c = 0, sv = 0;
+        if (q < dj) {
+          int o = j;
+          while (lcp[o] > q) o = owner[o];  // (lcp[0] = 0 ends the walk)
+          const uint32_t v = rag[(uint32_t)off[o] + (uint32_t)(q - lcp[o])];
+          c = (int32_t)(v & 0xFFFFu);
+          sv = (int32_t)(v >> 16);
+        }
+        tk[q] = c;
+        tt[q] = sv;
+      }
+    }
+    // rows without a result: row index j doubles as the row to check
+    if (!((used[j >> 5] >> (j & 31)) & 1u)) {
+      int32_t *tk = tk0 + (size_t)j * T, *tt = ts0 + (size_t)j * T;
+      for (int q = lane; q < T; q += 64) { tk[q] = 0; tt[q] = 0; }
+    }
   }
 }
 
@@ -1540,8 +1561,10 @@ int ctcd_expand_compact(ctcd_decoder *d, const int32_t *c_hdr, const int32_t *c_
   if (B == 0 || T == 0) return CTCD_OK;
   if (!c_hdr || !c_ent || !c_labels || !out_tok || !out_ts) return fail(CTCD_EINVAL, "null tensor");
   CTC_ON_DEVICE(d->device);
-  hipLaunchKernelGGL(expand_compact_kernel, dim3(B), dim3(T >= 1024 ? 1024 : (T >= 256 ? 256 : 64)), 0, (hipStream_t)stream_, c_hdr, c_ent,
-                     c_labels, beam, T, out_tok, out_ts);
+  if (beam > kExpandMaxK) return fail(CTCD_EUNSUPPORTED, "device expansion of compact results: beam_width > 4096");
+  const size_t esm = ((size_t)5 * beam + (beam + 31) / 32 + 4) * 4;
+  hipLaunchKernelGGL(expand_compact_kernel, dim3(B), dim3(beam >= 16 ? 1024 : 256), esm, (hipStream_t)stream_, c_hdr, c_ent, c_labels, beam, T,
+                     out_tok, out_ts);
   HIP_TRY(hipGetLastError());
   return CTCD_OK;
 }
@@ -1634,7 +1657,9 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
   HIP_TRY(hipStreamSynchronize(stream));
   if (!d->workers) {
     d->workers = new HostPool;
-    const int want = num_processes > 0 ? num_processes : 4;  // the reference's num_processes = host threads for the results
+    // host threads that expand the results: at least 16 (memory-bound work; the reference's default num_processes = 4 was
+    // chosen for its CPU decode), more if the caller asks, never more than the machine has
+    const int want = std::max(num_processes, 16);
     d->workers->start(std::max(1, std::min({want, (int)std::thread::hardware_concurrency(), 64})));
   }
   const int32_t *hh = (const int32_t *)(hs + o_hdr), *he = (const int32_t *)(hs + o_ent);
