@@ -730,6 +730,179 @@ __global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
   }
 }
 
+// The same pass for large vocabularies, shaped for HBM bandwidth (the one genuinely HBM-bound kernel of this library:
+// V * 4 bytes read per frame, 8 * top_n + 4 written).  One workgroup of four waves per frame: every thread fetches
+// F4 x 16 bytes of the row with 128-bit loads, all in flight together, and keeps them in registers.  A lower bound of
+// the n-th largest value comes from the threads' maxima (the n-th largest of the 256 of them, to 20 bits: that many
+// values are at least as large); the few dozen values above it are listed in LDS and wave 0 ranks them exactly -- ties,
+// the cumulative cut and the log conversion are decided as in prune_rows_kernel above.
+// Requires V % 4 == 0 (16-byte aligned rows), V <= 1024 * F4, cutoff_top_n <= 64.
+template <int F4>
+__global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char psm[];
+  __shared__ uint32_t s_bound, s_max[256];
+  __shared__ int s_cnt;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.top_n < a.V ? a.top_n : a.V;
+  uint32_t *lkey = (uint32_t *)psm;
+  int *lidx = (int *)lkey + a.stride;
+  int *sidx = lidx + a.stride;
+  uint32_t *ckey = (uint32_t *)(sidx + a.stride);
+  int *cidx = (int *)ckey + kPruneCand;
+  const int nv4 = a.V >> 2;
+  for (long long r = blockIdx.x; r < a.rows; r += gridDim.x) {
+    if (a.seq_lens) {
+      const long long b = r / a.T;
+      int len = a.seq_lens[b];
+      len = len < 0 ? 0 : len;
+      if ((int)(r - b * a.T) >= len) continue;
+    }
+    const float *x = a.in + (size_t)r * a.V;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    uint32_t keys[4 * F4];
+#pragma unroll
+    for (int u = 0; u < F4; ++u) {
+      const int i4 = tid + 256 * u;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = i4 < nv4;
+      if (ok) v = x4[i4];
+      keys[4 * u + 0] = ok ? prune_key(v.x) : 0u;
+      keys[4 * u + 1] = ok ? prune_key(v.y) : 0u;
+      keys[4 * u + 2] = ok ? prune_key(v.z) : 0u;
+      keys[4 * u + 3] = ok ? prune_key(v.w) : 0u;
+    }
+    if (tid == 0) s_cnt = 0;
+    uint32_t lmax = 0;
+#pragma unroll
+    for (int e = 0; e < 4 * F4; ++e) lmax = keys[e] > lmax ? keys[e] : lmax;
+    s_max[tid] = lmax;
+    __syncthreads();
+    if (wave == 0) {
+      const uint32_t m0 = s_max[lane], m1 = s_max[lane + 64], m2 = s_max[lane + 128], m3 = s_max[lane + 192];
+      uint32_t bw = 0;
+      for (int bit = 31; bit >= 12; --bit) {
+        const uint32_t trial = bw | (1u << bit);
+        const int c = __popcll(__ballot(m0 >= trial)) + __popcll(__ballot(m1 >= trial)) + __popcll(__ballot(m2 >= trial)) +
+                      __popcll(__ballot(m3 >= trial));
+        if (c >= n) bw = trial;
+      }
+      if (lane == 0) s_bound = bw;
+    }
+    __syncthreads();
+    const uint32_t bound = s_bound;
+#pragma unroll
+    for (int e = 0; e < 4 * F4; ++e) {
+      const bool in = keys[e] >= bound && keys[e] != 0u;
+      const unsigned long long m = __ballot(in);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (in && p < kPruneCand) { ckey[p] = keys[e]; cidx[p] = 4 * (tid + 256 * (e >> 2)) + (e & 3); }
+      }
+    }
+    __syncthreads();
+    const int ns = s_cnt;
+    if (wave == 0) {
+      bool flag = ns > kPruneCand;  // more values above the bound than the list holds: the host decides this frame
+      int kept = 0;
+      if (!flag) {
+        uint32_t found = 0;
+        for (int q = lane; q < ns; q += 64) {
+          const uint32_t mine = ckey[q];
+          int gg = 0, ee = 0;
+          for (int o = 0; o < ns; ++o) {
+            const uint32_t k = ckey[o];
+            gg += k > mine;
+            ee += k == mine;
+          }
+          if (gg < n && n <= gg + ee) found = mine;
+        }
+        const unsigned long long mf = __ballot(found != 0u);
+        const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)found, __ffsll((long long)mf) - 1);
+        int g = 0, e = 0;
+        for (int q = lane; q < ns; q += 64) { g += ckey[q] > tau; e += ckey[q] == tau; }
+        g = wave_sum(g);
+        e = wave_sum(e);
+        if (e > n - g) flag = true;  // equal values straddle the cut: std::sort decides which of them are kept
+        for (int q0 = 0; q0 < ns; q0 += 64) {
+          const int q = q0 + lane;
+          const uint32_t k = q < ns ? ckey[q] : 0u;
+          const bool keep = q < ns && (k > tau || (k == tau && !flag));
+          const unsigned long long m = __ballot(keep);
+          if (keep) {
+            const int p = kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            lkey[p] = k;
+            lidx[p] = cidx[q];
+          }
+          kept += __popcll(m);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
+      int *och = a.ch + (size_t)r * a.stride;
+      float *olp = a.lp + (size_t)r * a.stride;
+      for (int q = lane; q < kept; q += 64) {
+        const uint32_t mine = lkey[q];
+        int rank = 0, dup = 0;
+        for (int o = 0; o < kept; ++o) {
+          const uint32_t k = lkey[o];
+          rank += k > mine;
+          dup += k == mine;
+        }
+        if (dup > 1) flag = true;  // equal kept values: their order is std::sort's business
+        const int idx = lidx[q];
+        float v = x[idx];
+        if (!a.log_input) {  // decoder_utils.cpp:42
+          const double y = log((double)v + (double)FLT_MIN);
+          v = (float)y;
+          const double eps = fabs(y) * 0x1p-50;
+          if ((float)(y - eps) != v || (float)(y + eps) != v || !(y == y)) flag = true;
+        }
+        if (dup <= 1) { och[rank] = idx; olp[rank] = v; sidx[rank] = idx; }
+      }
+      flag = __ballot(flag) != 0ull;
+      int len = kept;
+      if (a.cutoff_prob < 1.0 && !flag) {  // decoder_utils.cpp:25-32, as in prune_rows_kernel
+        int stop = kept;
+        double carry = 0.0;
+        for (int i0 = 0; i0 < kept && stop == kept; i0 += 64) {
+          const int i = i0 + lane;
+          double p = 0.0;
+          if (i < kept) {
+            const double v = (double)x[sidx[i]];
+            p = a.log_input ? exp(v) : v;
+          }
+          double incl = p;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+          }
+          const double cum = log(1.0 + carry + incl);
+          const bool near = i < kept && (fabs(cum - a.cutoff_prob) <= 1e-9 * (1.0 + fabs(cum)) || !(cum == cum));
+          const bool hit = i < kept && (cum >= a.cutoff_prob || i + 1 >= a.top_n);
+          const unsigned long long mh = __ballot(hit), mn = __ballot(near);
+          const int firsthit = mh ? __ffsll((long long)mh) - 1 : 64;
+          if (mn && (__ffsll((long long)mn) - 1) <= firsthit) flag = true;
+          if (mh) stop = i0 + firsthit + 1;
+          carry += __shfl(incl, 63, 64);
+        }
+        len = stop;
+        flag = __ballot(flag) != 0ull;
+      }
+      if (lane == 0) {
+        a.cnt[r] = len;
+        if (flag) {
+          const unsigned k = atomicAdd(a.n_flag, 1u);
+          if (k < a.flag_cap) a.flag_rows[k] = (unsigned)r;
+        }
+      }
+    }
+    __syncthreads();  // the lists are reused by the next frame
+  }
+}
+
 // Flagged frames: rows to a contiguous staging buffer, and host-resolved records back into the candidate lists.
 __global__ void gather_rows_kernel(const float *in, const unsigned *rows, int V, float *out) {
   const float *src = in + (size_t)rows[blockIdx.x] * V;
@@ -1188,10 +1361,20 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     const size_t psm = (size_t)wpb * (3 * (size_t)stride + 2 * kPruneCand) * 4;
     if (psm > (size_t)d->max_lds) return fail(CTCD_EUNSUPPORTED, "cutoff_top_n too large for the prune pass");
     const int blocks = (int)std::min<long long>((rows + wpb - 1) / wpb, 256 * 16);
-    const void *pfn = V <= 64 ? (const void *)prune_rows_kernel<1> : V <= 256 ? (const void *)prune_rows_kernel<4>
+    const void *pfn = nullptr;
+    pfn = V <= 64 ? (const void *)prune_rows_kernel<1> : V <= 256 ? (const void *)prune_rows_kernel<4>
                     : V <= 1024 ? (const void *)prune_rows_kernel<16> : V <= 4096 ? (const void *)prune_rows_kernel<64>
                     : V <= 10240 ? (const void *)prune_rows_kernel<160> : (const void *)prune_rows_kernel<0>;
-    HIP_TRY(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm));
+    bool wg_kernel = false;
+    if (V % 4 == 0 && V > 256 && V <= 16384 && std::min(cutoff_top_n, V) <= 64) {  // the bandwidth-shaped variant
+      wg_kernel = true;
+      pfn = V <= 1024 ? (const void *)prune_rows_wg_kernel<1> : V <= 2048 ? (const void *)prune_rows_wg_kernel<2>
+          : V <= 4096 ? (const void *)prune_rows_wg_kernel<4> : V <= 10240 ? (const void *)prune_rows_wg_kernel<10>
+          : (const void *)prune_rows_wg_kernel<16>;
+    }
+    const size_t psm_launch = wg_kernel ? (3 * (size_t)stride + 2 * kPruneCand) * 4 : psm;
+    const int blocks_launch = wg_kernel ? (int)std::min<long long>(rows, 256 * 32) : blocks;
+    HIP_TRY(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm_launch));
     unsigned nf = 0;
     unsigned *n_flag = nullptr, *flag_rows = nullptr;
     d->prune_timed = false;
@@ -1207,7 +1390,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
       void *pargs[] = {&pa};
       if (d->timing) HIP_TRY(hipEventRecord(d->ev2, stream));
-      HIP_TRY(hipLaunchKernel(pfn, dim3(blocks), dim3(wpb * 64), pargs, psm, stream));
+      HIP_TRY(hipLaunchKernel(pfn, dim3(blocks_launch), dim3(wpb * 64), pargs, psm_launch, stream));
       HIP_TRY(hipGetLastError());
       if (d->timing) { HIP_TRY(hipEventRecord(d->ev3, stream)); d->prune_timed = true; }
       HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
