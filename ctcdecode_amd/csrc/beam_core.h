@@ -557,23 +557,8 @@ struct Decoder {
   CTC_HD void rank_bucket(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb) {
     const int tid = x.tid(), nt = x.nt();
     CTC_ASSUME(inb >= 1 && inb <= kListCap);
-    {
-      const uint32_t *skey = w.skey;
-      uint32_t *list = w.list;
-      int *lslot = w.lslot, *lcount = &pv[P_LCOUNT];
-      X &xx = x;
-      // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
-      x.mark_slots(S, w.bitmap, [=, &xx](int s) -> bool {
-        const uint32_t k = skey[s];
-        if (k < b32) return false;
-        const uint32_t dk = k - b32;
-        if (dk > bspan) return direct;
-        const int li = xx.atomic_add(lcount, 1);
-        list[li] = dk + 1u;
-        lslot[li] = s;
-        return false;
-      });
-    }
+    // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
+    x.list_bucket(S, w.skey, b32, bspan, direct, w.bitmap, w.list, w.lslot, &pv[P_LCOUNT]);
     for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
     x.sync();
     x.mark(14);

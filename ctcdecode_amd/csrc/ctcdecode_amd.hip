@@ -208,6 +208,63 @@ struct DevX {
       }
     }
   }
+  // One pass over the slot keys for the select: the keys inside the bucket [b32, b32 + bspan] are appended to list[]
+  // (key offset + 1) / lslot[] (slot), and -- when `direct` -- bit s of the bitmap says "key above the bucket".
+  // A wave reserves the list space of ALL its slots with ONE returning LDS atomic: a returning atomic costs a full LDS
+  // round trip, and one per bucket member (in divergent code, once per round) was most of this pass.
+  __device__ __forceinline__ void list_bucket(int S, const uint32_t *skey, uint32_t b32, uint32_t bspan, bool direct, uint32_t *bitmap,
+                                              uint32_t *list, int *lslot, int *lcount) {
+    const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
+    const int first = wave * rounds * 64;
+#define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
+    if (rounds <= 4) {
+      const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
+      const uint32_t k0 = s0 < S ? skey[s0] : 0u, k1 = (rounds > 1 && s1 < S) ? skey[s1] : 0u;
+      const uint32_t k2 = (rounds > 2 && s2 < S) ? skey[s2] : 0u, k3 = (rounds > 3 && s3 < S) ? skey[s3] : 0u;
+      const uint32_t d0 = k0 - b32, d1 = k1 - b32, d2 = k2 - b32, d3 = k3 - b32;
+      const bool g0 = k0 >= b32, g1 = k1 >= b32, g2 = k2 >= b32, g3 = k3 >= b32;  // (b32 >= 1: holes, key 0, never pass)
+      const bool i0 = g0 && d0 <= bspan, i1 = g1 && d1 <= bspan, i2 = g2 && d2 <= bspan, i3 = g3 && d3 <= bspan;
+      const unsigned long long m0 = __ballot(i0), m1 = __ballot(i1), m2 = __ballot(i2), m3 = __ballot(i3);
+      const unsigned long long a0 = __ballot(direct && g0 && !i0), a1 = __ballot(direct && g1 && !i1), a2 = __ballot(direct && g2 && !i2),
+                               a3 = __ballot(direct && g3 && !i3);
+      const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+      const int tot = c0 + c1 + c2 + c3;
+      if (tot) {  // (uniform)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(lcount, tot);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (i0) { const int p = base + CTC_BELOW(m0); list[p] = d0 + 1u; lslot[p] = s0; }
+        if (i1) { const int p = base + c0 + CTC_BELOW(m1); list[p] = d1 + 1u; lslot[p] = s1; }
+        if (i2) { const int p = base + c0 + c1 + CTC_BELOW(m2); list[p] = d2 + 1u; lslot[p] = s2; }
+        if (i3) { const int p = base + c0 + c1 + c2 + CTC_BELOW(m3); list[p] = d3 + 1u; lslot[p] = s3; }
+      }
+      if (lane < rounds) {
+        const unsigned long long m = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a3;
+        bitmap[2 * (wave * rounds + lane)] = (uint32_t)m;
+        bitmap[2 * (wave * rounds + lane) + 1] = (uint32_t)(m >> 32);
+      }
+      return;
+    }
+    for (int it = 0; it < rounds; ++it) {
+      const int s = first + it * 64 + lane;
+      const uint32_t k = s < S ? skey[s] : 0u, dk = k - b32;
+      const bool g = k >= b32, in = g && dk <= bspan;
+      const unsigned long long m = __ballot(in), am = __ballot(direct && g && !in);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(lcount, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (in) { const int p = base + CTC_BELOW(m); list[p] = dk + 1u; lslot[p] = s; }
+      }
+      if (lane == 0) {
+        bitmap[2 * (wave * rounds + it)] = (uint32_t)am;
+        bitmap[2 * (wave * rounds + it) + 1] = (uint32_t)(am >> 32);
+      }
+    }
+#undef CTC_BELOW
+  }
   // out[r] = s for the r-th set bit s of the bitmap (ascending); one wave, the others wait at the closing barrier.
   __device__ __forceinline__ void expand_bitmap(const uint32_t *bitmap, int nwords64, int *out) {
     if (threadIdx.x < 64) {
@@ -1536,7 +1593,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<0, false, 1, false, 1024>;
   if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes only
     if (big || !fixed || pruned_mode) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels, no pruning");
-    fn = (const void *)ctc_beam_decode_kernel<2, false, 1, false>;
+    if (threads != 1024) return fail(CTCD_EUNSUPPORTED, "barrier timeline: 1024 threads per workgroup (the product configuration)");
+    fn = (const void *)ctc_beam_decode_kernel<2, false, 1, false, 1024>;
   }
 #undef CTC_PICK
   if (scorer) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, false, 0, false, 0, true>;

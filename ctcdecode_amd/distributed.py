@@ -106,9 +106,10 @@ class CompactGatherer(object):
     the labels it does not share with its neighbour in the trie -- an order of magnitude fewer bytes than the padded
     [B, K, T] pair -- and ``dst`` rebuilds the padded tensors of the whole batch in its HBM with one expansion kernel.
 
-    Two small steps per batch: the label counts are gathered (one int64 per rank), then each rank's three buffers travel
-    point to point (every peer has its own xGMI link to the root).  ``submit`` returns at once; ``wait`` drains and, on
-    ``dst``, leaves the expanded tensors of the last batch in ``self.last`` = (output, scores, timesteps, out_lens)."""
+    Per batch: one all_reduce of a single word (the longest label buffer, so that every rank pads to the same length),
+    then five gathers to ``dst`` (point to point underneath: every peer has its own xGMI link to the root).  ``submit``
+    launches them asynchronously; ``wait`` drains and, on ``dst``, leaves the expanded tensors of the last batch in
+    ``self.last`` = (output, scores, timesteps, out_lens)."""
 
     def __init__(self, decoder, T, dst=0, group=None, depth=2):
         self.dec, self.T, self.dst, self.group = decoder, T, dst, group
@@ -127,28 +128,20 @@ class CompactGatherer(object):
         while len(self._inflight) >= self.depth:
             self._finish(self._inflight.pop(0))
         dev = hdr.device
-        n_here = torch.tensor([labels.numel()], dtype=torch.int64, device="cpu" if self._host_only else dev)
-        counts = [torch.zeros_like(n_here) for _ in range(self.world)] if self.rank == self.dst else None
-        dist.gather(n_here, counts, dst=self.dst, group=self.group)
-        works, recv = [], None
+        # the label buffers differ in length: agree on the longest (one all_reduce of a single word), pad, gather
+        nmax = torch.tensor([labels.numel()], dtype=torch.int64, device="cpu" if self._host_only else dev)
+        dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
+        nmax = max(int(nmax.item()), 1)
+        lab = labels
+        if lab.numel() < nmax:
+            lab = torch.cat([lab, torch.zeros((nmax - lab.numel(),), dtype=lab.dtype, device=lab.device)])
+        send = [self._xfer(t).contiguous() for t in (hdr, ent, lab, scores, lens)]
+        recv, works = None, []
         if self.rank == self.dst:
-            ns = [int(c.item()) for c in counts]
-            recv = []
-            for r in range(self.world):
-                if r == self.dst:
-                    recv.append((hdr, ent, labels, scores, lens))
-                    continue
-                bufs = (torch.empty_like(self._xfer(hdr)), torch.empty_like(self._xfer(ent)),
-                        torch.empty((max(ns[r], 1),), dtype=labels.dtype, device="cpu" if self._host_only else dev),
-                        torch.empty_like(self._xfer(scores)), torch.empty_like(self._xfer(lens)))
-                works += [dist.irecv(b, src=r, group=self.group) for b in bufs]
-                recv.append(bufs)
-        else:
-            lab = labels if labels.numel() else torch.zeros((1,), dtype=labels.dtype, device=labels.device)
-            keep = [self._xfer(t).contiguous() for t in (hdr, ent, lab, scores, lens)]
-            works += [dist.isend(t, dst=self.dst, group=self.group) for t in keep]
-            recv = keep  # keep the sources alive until the sends completed
-        self._inflight.append((works, recv, dev))
+            recv = [[torch.empty_like(t) for _ in range(self.world)] for t in send]
+        for i, t in enumerate(send):
+            works.append(dist.gather(t, recv[i] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True))
+        self._inflight.append((works, recv if self.rank == self.dst else send, dev))  # (sources stay alive until the gather is done)
 
     def _finish(self, item):
         works, recv, dev = item
@@ -156,19 +149,18 @@ class CompactGatherer(object):
             wk.wait()
         if self.rank != self.dst:
             return
-        hdrs, ents, labs, scs, lns = [], [], [], [], []
+        hdrs, ents, labs = [], [], []
         base = 0
-        for h, e, lab, sc, ln in recv:
-            h, e, lab, sc, ln = (t.to(dev) for t in (h, e, lab, sc, ln))
+        for r in range(self.world):
+            h, e, lab = recv[0][r].to(dev), recv[1][r].to(dev).clone(), recv[2][r].to(dev)
             n = int(h[:, 1].sum().item())
-            e = e.clone()
             e[:, :, 3] += base  # label indices (relative to the rank's own buffer) rebased onto the concatenated one
-            hdrs.append(h); ents.append(e); labs.append(lab[:n] if n else lab[:0]); scs.append(sc); lns.append(ln)
+            hdrs.append(h); ents.append(e); labs.append(lab[:n])
             base += n
         hdr, ent = torch.cat(hdrs, 0), torch.cat(ents, 0)
         labels = torch.cat(labs, 0) if base else torch.zeros((1,), dtype=torch.int32, device=dev)
         out, ts = self.dec.expand_compact(hdr, ent, labels, self.T)
-        self.last = (out, torch.cat(scs, 0), ts, torch.cat(lns, 0))
+        self.last = (out, torch.cat([t.to(dev) for t in recv[3]], 0), ts, torch.cat([t.to(dev) for t in recv[4]], 0))
 
     def wait(self):
         while self._inflight:

@@ -73,6 +73,22 @@ struct HostX {
     for (int s = 0; s < S; ++s)
       if (pred(s)) bitmap[s >> 5] |= 1u << (s & 31);
   }
+  void list_bucket(int S, const uint32_t *skey, uint32_t b32, uint32_t bspan, bool direct, uint32_t *bitmap, uint32_t *list, int *lslot,
+                   int *lcount) {
+    for (int wd = 0; wd < 2 * ((S + 63) / 64); ++wd) bitmap[wd] = 0;
+    for (int s = 0; s < S; ++s) {
+      const uint32_t k = skey[s];
+      if (k < b32) continue;
+      const uint32_t dk = k - b32;
+      if (dk > bspan) {
+        if (direct) bitmap[s >> 5] |= 1u << (s & 31);
+        continue;
+      }
+      const int li = (*lcount)++;
+      list[li] = dk + 1u;
+      lslot[li] = s;
+    }
+  }
   void expand_bitmap(const uint32_t *bitmap, int nwords64, int *out) {
     int k = 0;
     for (int s = 0; s < nwords64 * 64; ++s)
