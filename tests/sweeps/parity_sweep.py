@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--beam", type=int, default=100)
     ap.add_argument("--out", default="")
+    ap.add_argument("--head", default="", help="git revision of the tree under test (recorded in the output)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -44,7 +45,7 @@ def main():
             except AssertionError:
                 bad += 1
         r = {"input": name, "utterances": a.n, "frames": a.frames, "beam": a.beam, "mismatching_utterances": bad,
-             "checker": "reference" if ou.have_reference() else "restated", "gpu_decode_s_incl_pcie": round(tg, 3), "cpu_s": round(tc, 1)}
+             "checker": "reference" if ou.have_reference() else "restated", "git_head": a.head, "gpu_decode_s_incl_pcie": round(tg, 3), "cpu_s": round(tc, 1)}
         print(json.dumps(r), flush=True)
         res.append(r)
     if a.out:
