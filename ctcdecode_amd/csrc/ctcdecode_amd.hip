@@ -448,7 +448,7 @@ struct KernelArgs {
 // 1 = fixed layout for beam <= kFixedK, vocabulary <= kFixedV: every LDS array sits at a compile-time address, which
 // frees the scalar registers the bases would occupy and folds them into the instructions' offset fields.
 constexpr int kFixedK = ctcbeam::kSmallK, kFixedV = ctcbeam::kSmallV;
-__host__ __device__ constexpr Dims fixed_layout_dims() { return Dims{kFixedK, kFixedV, kFixedV, 1, 0}; }
+__host__ __device__ constexpr Dims fixed_layout_dims(bool lm = false) { return Dims{kFixedK, kFixedV, kFixedV, 1, lm ? 1 : 0}; }
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
 
 // PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   const int b = (int)blockIdx.x;
   if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
   Work w;
-  if (LAYOUT == 1) carve<false>(w, smem, nullptr, fixed_layout_dims(), nullptr);
+  if (LAYOUT == 1) carve<false>(w, smem, nullptr, fixed_layout_dims(LM), nullptr);
   else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
   __shared__ long long prof[16];
   __shared__ long long tlbuf[PROF == 2 ? 16 * kTimelineCap : 1];
@@ -1343,8 +1343,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (dims.use_rank_table && V > 32767) return fail(CTCD_EUNSUPPORTED, "vocabulary pruning with more than 32767 labels");
   Work wtmp;
   size_t far_bytes = 0;
-  const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout && !scorer;  // (the LM tier runs the run-time layout)
-  const Dims ldims = fixed ? fixed_layout_dims() : dims;
+  // workgroup size (measured): 1024 threads for the usual shapes; below ~1300 candidate slots 512 is marginally better
+  // (fewer idle waves), fewer than that is always slower (the new-children phase wants its own waves)
+  int threads = d->threads;
+  if (threads == 0) threads = (dims.S_max() <= 1300 && !scorer) ? 512 : 1024;
+  // (the LM tier has the fixed-layout kernel at 1024 threads only)
+  const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout && (!scorer || threads == 1024);
+  const Dims ldims = fixed ? fixed_layout_dims(scorer != nullptr) : dims;
   size_t lds = carve<false>(wtmp, nullptr, nullptr, ldims, nullptr);
   bool big = false;
   if (lds + 2048 > (size_t)d->max_lds) {  // wide beam: rare-path arrays go to HBM scratch
@@ -1579,10 +1584,6 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   }
   a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
   const bool pruned_mode = a.pr_cnt != nullptr;
-  // workgroup size (measured): 1024 threads for the usual shapes; below ~1300 candidate slots 512 is marginally better
-  // (fewer idle waves), fewer than that is always slower (the new-children phase wants its own waves)
-  int threads = d->threads;
-  if (threads == 0) threads = dims.S_max() <= 1300 ? 512 : 1024;
   const void *fn;
 #define CTC_PICK(PROF_)                                                                                                  \
   (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, true, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, true, 0, false>)    \
@@ -1597,7 +1598,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     fn = (const void *)ctc_beam_decode_kernel<2, false, 1, false, 1024>;
   }
 #undef CTC_PICK
-  if (scorer) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, false, 0, false, 0, true>;
+  if (scorer) {
+    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, false, 0, false, 0, true>;
+    if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
+      fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, false, 1, false, 1024, true>;
+  }
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
   void *kargs[] = {&a};
