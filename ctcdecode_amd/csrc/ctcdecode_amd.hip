@@ -788,25 +788,29 @@ __global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
 }
 
 // The same pass for large vocabularies, shaped for HBM bandwidth (the one genuinely HBM-bound kernel of this library:
-// V * 4 bytes read per frame, 8 * top_n + 4 written).  One workgroup of four waves per frame: every thread fetches
-// F4 x 16 bytes of the row with 128-bit loads, all in flight together, and keeps them in registers.  A lower bound of
-// the n-th largest value comes from the threads' maxima (the n-th largest of the 256 of them, to 20 bits: that many
-// values are at least as large); the few dozen values above it are listed in LDS and wave 0 ranks them exactly -- ties,
-// the cumulative cut and the log conversion are decided as in prune_rows_kernel above.
+// V * 4 bytes read per frame, 8 * top_n + 4 written).  One workgroup of four waves per frame, two sweeps over the row
+// with 128-bit loads: the first keeps only every thread's maximum (a lower bound of the n-th largest value follows from
+// the lanes' maxima: in each wave the ceil(n/4)-th largest of its 64 lane maxima, to 20 bits; the smallest of the four
+// wave bounds has at least n values above it), the second -- served by L2, the row was just read -- lists the few
+// dozen values at or above the bound in LDS, where wave 0 ranks them exactly.  Ties, the cumulative cut and the log
+// conversion are decided as in prune_rows_kernel above.  Few registers per thread (nothing of the row is kept), so
+// eight workgroups share a CU and hide each other's latencies.
 // Requires V % 4 == 0 (16-byte aligned rows), V <= 1024 * F4, cutoff_top_n <= 64.
 template <int F4>
 __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
-  __shared__ uint32_t s_bound, s_max[256];
+  __shared__ uint32_t s_bound[4];
   __shared__ int s_cnt;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = a.top_n < a.V ? a.top_n : a.V;
+  const int nq = (n + 3) >> 2;  // per-wave share
   uint32_t *lkey = (uint32_t *)psm;
   int *lidx = (int *)lkey + a.stride;
   int *sidx = lidx + a.stride;
   uint32_t *ckey = (uint32_t *)(sidx + a.stride);
   int *cidx = (int *)ckey + kPruneCand;
   const int nv4 = a.V >> 2;
+  constexpr int kChunk = F4 < 5 ? F4 : 5;  // 128-bit loads in flight per thread
   for (long long r = blockIdx.x; r < a.rows; r += gridDim.x) {
     if (a.seq_lens) {
       const long long b = r / a.T;
@@ -816,47 +820,48 @@ __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
     }
     const float *x = a.in + (size_t)r * a.V;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    uint32_t keys[4 * F4];
-#pragma unroll
-    for (int u = 0; u < F4; ++u) {
-      const int i4 = tid + 256 * u;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool ok = i4 < nv4;
-      if (ok) v = x4[i4];
-      keys[4 * u + 0] = ok ? prune_key(v.x) : 0u;
-      keys[4 * u + 1] = ok ? prune_key(v.y) : 0u;
-      keys[4 * u + 2] = ok ? prune_key(v.z) : 0u;
-      keys[4 * u + 3] = ok ? prune_key(v.w) : 0u;
-    }
     if (tid == 0) s_cnt = 0;
     uint32_t lmax = 0;
+    for (int u0 = 0; u0 < F4; u0 += kChunk) {
+      float4 v[kChunk];
 #pragma unroll
-    for (int e = 0; e < 4 * F4; ++e) lmax = keys[e] > lmax ? keys[e] : lmax;
-    s_max[tid] = lmax;
-    __syncthreads();
-    if (wave == 0) {
-      const uint32_t m0 = s_max[lane], m1 = s_max[lane + 64], m2 = s_max[lane + 128], m3 = s_max[lane + 192];
-      uint32_t bw = 0;
-      for (int bit = 31; bit >= 12; --bit) {
-        const uint32_t trial = bw | (1u << bit);
-        const int c = __popcll(__ballot(m0 >= trial)) + __popcll(__ballot(m1 >= trial)) + __popcll(__ballot(m2 >= trial)) +
-                      __popcll(__ballot(m3 >= trial));
-        if (c >= n) bw = trial;
+      for (int u = 0; u < kChunk; ++u) {
+        const int i4 = tid + 256 * (u0 + u);
+        v[u] = (u0 + u < F4 && i4 < nv4) ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       }
-      if (lane == 0) s_bound = bw;
-    }
-    __syncthreads();
-    const uint32_t bound = s_bound;
 #pragma unroll
-    for (int e = 0; e < 4 * F4; ++e) {
-      const bool in = keys[e] >= bound && keys[e] != 0u;
-      const unsigned long long m = __ballot(in);
-      if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (in && p < kPruneCand) { ckey[p] = keys[e]; cidx[p] = 4 * (tid + 256 * (e >> 2)) + (e & 3); }
+      for (int u = 0; u < kChunk; ++u) {
+        const int i4 = tid + 256 * (u0 + u);
+        if (u0 + u < F4 && i4 < nv4) {
+          const uint32_t k0 = prune_key(v[u].x), k1 = prune_key(v[u].y), k2 = prune_key(v[u].z), k3 = prune_key(v[u].w);
+          const uint32_t m01 = k0 > k1 ? k0 : k1, m23 = k2 > k3 ? k2 : k3, m = m01 > m23 ? m01 : m23;
+          lmax = m > lmax ? m : lmax;
+        }
+      }
+    }
+    uint32_t bw = 0;
+    for (int bit = 31; bit >= 12; --bit) {
+      const uint32_t trial = bw | (1u << bit);
+      if (__popcll(__ballot(lmax >= trial)) >= nq) bw = trial;
+    }
+    if (lane == 0) s_bound[wave] = bw;
+    __syncthreads();
+    uint32_t bound = s_bound[0];
+    bound = s_bound[1] < bound ? s_bound[1] : bound;
+    bound = s_bound[2] < bound ? s_bound[2] : bound;
+    bound = s_bound[3] < bound ? s_bound[3] : bound;
+    if (lmax >= bound && lmax != 0u) {  // (only the few threads that hold a value at or above the bound sweep again)
+      for (int u = 0; u < F4; ++u) {
+        const int i4 = tid + 256 * u;
+        if (i4 >= nv4) break;
+        const float4 v = x4[i4];
+        const uint32_t kk[4] = {prune_key(v.x), prune_key(v.y), prune_key(v.z), prune_key(v.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kk[e] >= bound && kk[e] != 0u) {
+            const int p = atomicAdd(&s_cnt, 1);
+            if (p < kPruneCand) { ckey[p] = kk[e]; cidx[p] = 4 * i4 + e; }
+          }
       }
     }
     __syncthreads();
@@ -864,60 +869,38 @@ __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
     if (wave == 0) {
       bool flag = ns > kPruneCand;  // more values above the bound than the list holds: the host decides this frame
       int kept = 0;
+      int *och = a.ch + (size_t)r * a.stride;
+      float *olp = a.lp + (size_t)r * a.stride;
       if (!flag) {
-        uint32_t found = 0;
-        for (int q = lane; q < ns; q += 64) {
-          const uint32_t mine = ckey[q];
+        // every lane ranks its own candidates among all of them: rank = #greater; the n-th largest has rank < n <= rank + #equal
+        for (int q0 = 0; q0 < ns; q0 += 64) {
+          const int q = q0 + lane;
+          const uint32_t mine = q < ns ? ckey[q] : 0u;
           int gg = 0, ee = 0;
           for (int o = 0; o < ns; ++o) {
             const uint32_t k = ckey[o];
             gg += k > mine;
             ee += k == mine;
           }
-          if (gg < n && n <= gg + ee) found = mine;
-        }
-        const unsigned long long mf = __ballot(found != 0u);
-        const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)found, __ffsll((long long)mf) - 1);
-        int g = 0, e = 0;
-        for (int q = lane; q < ns; q += 64) { g += ckey[q] > tau; e += ckey[q] == tau; }
-        g = wave_sum(g);
-        e = wave_sum(e);
-        if (e > n - g) flag = true;  // equal values straddle the cut: std::sort decides which of them are kept
-        for (int q0 = 0; q0 < ns; q0 += 64) {
-          const int q = q0 + lane;
-          const uint32_t k = q < ns ? ckey[q] : 0u;
-          const bool keep = q < ns && (k > tau || (k == tau && !flag));
-          const unsigned long long m = __ballot(keep);
-          if (keep) {
-            const int p = kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            lkey[p] = k;
-            lidx[p] = cidx[q];
+          const bool keep = q < ns && gg < n;
+          if (keep && gg + ee > n) flag = true;   // equal values straddle the cut: std::sort decides which of them are kept
+          if (keep && ee > 1) flag = true;        // equal kept values: their order is std::sort's business
+          if (keep && ee == 1) {
+            const int idx = cidx[q];
+            float v = x[idx];
+            if (!a.log_input) {  // decoder_utils.cpp:42
+              const double y = log((double)v + (double)FLT_MIN);
+              v = (float)y;
+              const double eps = fabs(y) * 0x1p-50;
+              if ((float)(y - eps) != v || (float)(y + eps) != v || !(y == y)) flag = true;
+            }
+            och[gg] = idx; olp[gg] = v; sidx[gg] = idx;
           }
-          kept += __popcll(m);
+          kept += __popcll(__ballot(keep));
         }
+        if (kept > n) kept = n;
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
-      int *och = a.ch + (size_t)r * a.stride;
-      float *olp = a.lp + (size_t)r * a.stride;
-      for (int q = lane; q < kept; q += 64) {
-        const uint32_t mine = lkey[q];
-        int rank = 0, dup = 0;
-        for (int o = 0; o < kept; ++o) {
-          const uint32_t k = lkey[o];
-          rank += k > mine;
-          dup += k == mine;
-        }
-        if (dup > 1) flag = true;  // equal kept values: their order is std::sort's business
-        const int idx = lidx[q];
-        float v = x[idx];
-        if (!a.log_input) {  // decoder_utils.cpp:42
-          const double y = log((double)v + (double)FLT_MIN);
-          v = (float)y;
-          const double eps = fabs(y) * 0x1p-50;
-          if ((float)(y - eps) != v || (float)(y + eps) != v || !(y == y)) flag = true;
-        }
-        if (dup <= 1) { och[rank] = idx; olp[rank] = v; sidx[rank] = idx; }
-      }
       flag = __ballot(flag) != 0ull;
       int len = kept;
       if (a.cutoff_prob < 1.0 && !flag) {  // decoder_utils.cpp:25-32, as in prune_rows_kernel
