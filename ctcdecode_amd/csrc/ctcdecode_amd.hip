@@ -1149,6 +1149,7 @@ struct ctcd_decoder {
   bool prune_timed = false;
   hipStream_t last_stream = nullptr;  // the stream of the last decode launch (ctcd_check_status reads the status words on it)
   std::mutex mu;
+  std::mutex mu_host;  // the host-tensor entry points: compact buffers, page-locked staging and the worker threads are per decoder
 };
 
 // One audio stream's parked decoder state (ctcd_stream_*): a single HBM block [header | beam arrays | node pool].
@@ -1809,6 +1810,7 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
   int rc = check_args(B, T, V, beam, cutoff_top_n, blank_id, probs, out_tok, out_ts, out_sc, out_len);
   if (rc) return rc;
   if (B == 0) return CTCD_OK;
+  std::lock_guard<std::mutex> host_lock(d->mu_host);
   CTC_ON_DEVICE(d->device);
   hipStream_t stream = (hipStream_t)stream_;
   const size_t nin = (size_t)B * T * V * 4, kk = (size_t)B * beam;
