@@ -164,17 +164,29 @@ CTC_HD P *carve_ptr(char *&p, size_t count) {
 // Lay the workspace out in `base` (LDS on the GPU).  Returns bytes used; call with base == nullptr to size it.
 // BIG: the arrays that only the rare paths touch per slot (info words, and the scratch of the exact replay) live in
 // `far` (HBM, per utterance) instead, so that wide beams still fit the 160 KiB of LDS; *far_bytes gets their size.
+// level (BIG only): 1 = the rare-path per-slot arrays in HBM; 2 = also the slot keys and the rarely read per-entry arrays
+// (dead-interior bookkeeping, existing-child ranks): the widest beams, slowly.
 template <bool BIG>
-CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_bytes) {
+CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_bytes, int level = 1) {
   char *p = base;
+  char *q = BIG ? far : nullptr;
+  const bool deep = BIG && level >= 2;
   const size_t K = (size_t)d.K, S = (size_t)d.S_max();
+  const size_t Kr = ((K * 4 + 15) / 16) * 16;
   Beam *bs[2] = {&w.cur, &w.nxt};
-  w.beam_blk = (size_t)(kBeamArrays + (d.lm ? kBeamArraysLm : 0)) * (((K * 4 + 15) / 16) * 16);
+  // the distance between the two copies of a beam array is the same for every array (Decoder::beam_at)
+  w.beam_blk = (size_t)(kBeamArrays - (deep ? 3 : 0) + (d.lm ? kBeamArraysLm : 0)) * Kr;
   for (int i = 0; i < 2; ++i) {
     Beam &b = *bs[i];
     b.node = carve_ptr<int>(p, K); b.par = carve_ptr<int>(p, K); b.ch = carve_ptr<int>(p, K);
-    b.dep = carve_ptr<int>(p, K); b.lcp = carve_ptr<int>(p, K); b.via = carve_ptr<int>(p, K);
-    b.viaanc = carve_ptr<int>(p, K); b.viach = carve_ptr<int>(p, K); b.up = carve_ptr<int>(p, K);
+    b.dep = carve_ptr<int>(p, K); b.lcp = carve_ptr<int>(p, K);
+    if (deep) {
+      char *f = q + (size_t)i * w.beam_blk;
+      b.via = carve_ptr<int>(f, K); b.viaanc = carve_ptr<int>(f, K); b.viach = carve_ptr<int>(f, K);
+    } else {
+      b.via = carve_ptr<int>(p, K); b.viaanc = carve_ptr<int>(p, K); b.viach = carve_ptr<int>(p, K);
+    }
+    b.up = carve_ptr<int>(p, K);
     b.bprev = carve_ptr<float>(p, K); b.nbprev = carve_ptr<float>(p, K); b.score = carve_ptr<float>(p, K);
     b.lpc = carve_ptr<float>(p, K);
     const size_t Kl = d.lm ? K : 0;
@@ -182,32 +194,30 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
     b.dn = carve_ptr<int>(p, Kl); b.dmlo = carve_ptr<int>(p, Kl); b.dmhi = carve_ptr<int>(p, Kl); b.dfc = carve_ptr<int>(p, Kl);
     b.spc_lo = carve_ptr<int>(p, Kl); b.spc_hi = carve_ptr<int>(p, Kl); b.spst = carve_ptr<int>(p, Kl); b.spcl = carve_ptr<int>(p, Kl);
   }
+  if (deep) q += w.beam_blk + 3 * Kr;
   w.beam0 = w.cur;
   w.e = carve_ptr<int>(p, K); w.ancbuf = carve_ptr<int>(p, 2 * K); w.acntbuf = carve_ptr<int>(p, 2 * K); w.anc = w.ancbuf;
   w.ostart = carve_ptr<int>(p, K);
-  w.cstart = carve_ptr<int>(p, K); w.pinr = carve_ptr<int>(p, K);
-  w.revr = carve_ptr<int>(p, K); w.hit = carve_ptr<uint32_t>(p, 2 * K);
-  w.b_new = carve_ptr<float>(p, K); w.nb_new = carve_ptr<float>(p, K); w.sc_new = carve_ptr<float>(p, K); w.rev_lpc = carve_ptr<float>(p, K);
+  w.cstart = carve_ptr<int>(p, K);
+  w.pinr = carve_ptr<int>(deep ? q : p, K);
+  w.revr = carve_ptr<int>(deep ? q : p, K); w.hit = carve_ptr<uint32_t>(p, 2 * K);
+  w.b_new = carve_ptr<float>(p, K); w.nb_new = carve_ptr<float>(p, K); w.sc_new = carve_ptr<float>(p, K);
+  w.rev_lpc = carve_ptr<float>(deep ? q : p, K);
   w.cch = carve_ptr<int>(p, (size_t)d.Vc_max);
   w.clpbuf = carve_ptr<float>(p, 2 * (size_t)d.Vc_max); w.clp = w.clpbuf;
   w.rank_of = carve_ptr<int16_t>(p, d.use_rank_table ? (size_t)d.V : 0);
-  w.skey = carve_ptr<uint32_t>(p, S);
+  w.skey = carve_ptr<uint32_t>(deep ? q : p, S);
   w.surv = carve_ptr<int>(p, 3 * K + 4);
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
   w.lslot = carve_ptr<int>(p, kListCap + 4); w.bitmap = carve_ptr<uint32_t>(p, 2 * ((S + 63) / 64 + 17));
   w.fin = carve_ptr<int>(p, K);
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
-  char *q = BIG ? far : p;
-  w.sinfo = carve_ptr<uint32_t>(q, S);
-  w.pos = carve_ptr<uint32_t>(q, S + 2);
-  w.ek = carve_ptr<uint64_t>(q, S); w.lr = carve_ptr<uint16_t>(q, 2 * S + 2);
-  if (BIG) {
-    if (far_bytes) *far_bytes = (size_t)(q - far);
-  } else {
-    p = q;
-    if (far_bytes) *far_bytes = 0;
-  }
+  char *&r = BIG ? q : p;
+  w.sinfo = carve_ptr<uint32_t>(r, S);
+  w.pos = carve_ptr<uint32_t>(r, S + 2);
+  w.ek = carve_ptr<uint64_t>(r, S); w.lr = carve_ptr<uint16_t>(r, 2 * S + 2);
+  if (far_bytes) *far_bytes = BIG ? (size_t)(q - far) : 0;
   return (size_t)(p - base);
 }
 

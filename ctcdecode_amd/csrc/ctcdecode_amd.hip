@@ -428,6 +428,7 @@ struct KernelArgs {
   int tl_cap, tl_f0, tl_nf;
   char *far;                // BIG layout: per-utterance HBM scratch, far_stride bytes each
   long long far_stride;
+  int far_level;            // BIG layout: 1 or 2 (beam_core.h carve)
   // streaming (ctcd_stream_decode): per item, the HBM block that holds its parked beam + node pool
   char **st_base;           // [B] or null
   const int *st_poolcap;    // [B] nodes the pool of each stream can hold
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
   Work w;
   if (LAYOUT == 1) carve<false>(w, smem, nullptr, fixed_layout_dims(LM), nullptr);
-  else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
+  else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr, a.far_level);
   __shared__ long long prof[16];
   __shared__ long long tlbuf[PROF == 2 ? 16 * kTimelineCap : 1];
   __shared__ int tlcnt[16];
@@ -1336,9 +1337,14 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   const Dims ldims = fixed ? fixed_layout_dims(scorer != nullptr) : dims;
   size_t lds = carve<false>(wtmp, nullptr, nullptr, ldims, nullptr);
   bool big = false;
+  int far_level = 1;
   if (lds + 2048 > (size_t)d->max_lds) {  // wide beam: rare-path arrays go to HBM scratch
     big = true;
-    lds = carve<true>(wtmp, nullptr, nullptr, dims, &far_bytes);
+    lds = carve<true>(wtmp, nullptr, nullptr, dims, &far_bytes, 1);
+    if (lds + 2048 > (size_t)d->max_lds) {  // wider still: the slot keys and the rarely read per-entry arrays follow them
+      far_level = 2;
+      lds = carve<true>(wtmp, nullptr, nullptr, dims, &far_bytes, 2);
+    }
     far_bytes = (far_bytes + 255) / 256 * 256;
   }
   if (lds + 2048 > (size_t)d->max_lds)
@@ -1566,7 +1572,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if ((rc = d->prof.ensure((size_t)B * 16 * 8))) return rc;
     a.prof = (long long *)d->prof.p;
   }
-  a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
+  a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes; a.far_level = far_level;
   const bool pruned_mode = a.pr_cnt != nullptr;
   const void *fn;
 #define CTC_PICK(PROF_)                                                                                                  \

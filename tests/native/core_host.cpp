@@ -237,8 +237,9 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
   auto work = [&] {
     Work w;
     size_t far_bytes = 0;
-    const bool big = getenv("CTC_HOST_BIG") != nullptr;  // exercise the HBM-scratch layout too
-    std::vector<char> mem((big ? carve<true>(w, nullptr, nullptr, d, &far_bytes) : carve<false>(w, nullptr, nullptr, d, &far_bytes)) + 64);
+    const bool big = getenv("CTC_HOST_BIG") != nullptr;  // exercise the HBM-scratch layouts too (CTC_HOST_BIG=1 or 2)
+    const int flevel = big && getenv("CTC_HOST_BIG")[0] == '2' ? 2 : 1;
+    std::vector<char> mem((big ? carve<true>(w, nullptr, nullptr, d, &far_bytes, flevel) : carve<false>(w, nullptr, nullptr, d, &far_bytes)) + 64);
     std::vector<char> far(far_bytes + 64);
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
     std::vector<int> pool_up(pool.size());
@@ -249,7 +250,7 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
       if (b >= B) return;
       int len = seq_lens ? seq_lens[b] : T;
       len = std::max(0, std::min(len, T));
-      if (big) carve<true>(w, mem.data(), far.data(), d, nullptr); else carve<false>(w, mem.data(), nullptr, d, nullptr);
+      if (big) carve<true>(w, mem.data(), far.data(), d, nullptr, flevel); else carve<false>(w, mem.data(), nullptr, d, nullptr);
       HostX x;
       const float *rows = probs + (size_t)b * T * V;
       PrunedRows pr{pcnt.data(), pch.data(), plp.data(), d.Vc_max};

@@ -82,10 +82,16 @@ def test_oracle_edge_cases_against_live_reference(name, lp, kw):
     ou.assert_same(ou.decode(lp, which="restated", **kw), ou.decode(lp, which="reference", **kw), name)
 
 
-def test_core_hbm_scratch_layout(monkeypatch):
-    monkeypatch.setenv("CTC_HOST_BIG", "1")
-    lp = ou.synth_logprobs(2, 150, 29, 44, quant=0.5)
-    ou.assert_same(ou.decode(lp, beam=64), ou.decode_core_host(lp, beam=64))
+@pytest.mark.parametrize("level", ["1", "2"])
+def test_core_hbm_scratch_layout(monkeypatch, level):
+    """The wide-beam workspace layouts: level 1 keeps the rare-path per-slot arrays outside the workgroup's LDS, level 2
+    (beam_width ~1000) also the slot keys and the rarely read per-entry arrays."""
+    monkeypatch.setenv("CTC_HOST_BIG", level)
+    for seed, kw in [(44, dict(quant=0.5)), (45, dict(blank_bias=3.0)), (46, {})]:
+        lp = ou.synth_logprobs(2, 150, 29, seed, **kw)
+        ou.assert_same(ou.decode(lp, beam=64), ou.decode_core_host(lp, beam=64))
+    lp = ou.synth_logprobs(1, 40, 29, 47)
+    ou.assert_same(ou.decode(lp, beam=1000), ou.decode_core_host(lp, beam=1000), "beam 1000")
 
 
 def test_core_streaming_equals_one_shot():

@@ -196,6 +196,16 @@ def test_wide_beam_hbm_scratch_layout(torch_mod):
         ou.assert_same(_with_nres(got, want), want, "K=500 seed %d" % seed)
 
 
+def test_beam_width_1000(torch_mod):
+    """beam_width=1000 at V=29: 31 000 candidate slots; the slot keys and the rarely read per-entry arrays live in HBM scratch
+    (workspace level 2), only the beam itself and the per-frame temporaries stay in LDS."""
+    for seed, T, quant in [(73, 120, None), (74, 90, 0.5)]:
+        lp = ou.synth_logprobs(2, T, 29, seed, quant=quant)
+        want = ou.decode(lp, beam=1000, which="restated")
+        got = _decode(torch_mod, lp, beam=1000)
+        ou.assert_same(_with_nres(got, want), want, "K=1000 seed %d" % seed)
+
+
 def test_config3_shape_long_wide(torch_mod):
     """T=2000, beam_width=500 (configs[2] is B=2048 over 8 GPUs = 256 such utterances per GPU): 32 utterances, all checked
     against the real reference (the restatement where oracle/_ref is not built)."""
