@@ -12,7 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
-LIB_PATH = os.path.join(LIB_DIR, "libctcdecode_amd.so")
+# CTCDECODE_AMD_LIB: load another build of the library (kernel experiments: tools/build_variants.sh)
+LIB_PATH = os.environ.get("CTCDECODE_AMD_LIB") or os.path.join(LIB_DIR, "libctcdecode_amd.so")
 SOURCES = ["ctcdecode_amd.hip"]
 HEADERS = ["beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h", "compact_results.h", os.path.join("..", "..", "include", "ctcdecode_amd.h")]
 ROCM = os.environ.get("ROCM_HOME", "/opt/rocm")
@@ -42,15 +43,17 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not is_stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines/out: build a variant of the library (kernel experiments) next to the product one."""
+    lib_path = out or LIB_PATH
+    if not out and not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.splitext(lib_path)[0] + "." + os.path.splitext(src)[0] + ".o" if out else os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-               "-Wno-unused-result", "-c", os.path.join(CSRC, src), "-o", obj]
+               "-Wno-unused-result"] + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd), file=sys.stderr)
@@ -58,14 +61,14 @@ def build(force=False, verbose=False):
         objs.append(obj)
     tl = _torch_lib_dir()
     libdirs = ([tl] if tl else []) + [os.path.join(ROCM, "lib")]
-    link = ["g++", "-shared", "-o", LIB_PATH] + objs
+    link = ["g++", "-shared", "-o", lib_path] + objs
     for ld in libdirs:
         link += ["-L" + ld, "-Wl,-rpath," + ld, "-Wl,-rpath-link," + ld]
     link += ["-lamdhip64", "-lpthread"]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.run(link, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":

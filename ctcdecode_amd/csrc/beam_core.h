@@ -52,6 +52,11 @@
 #include <cstdlib>
 #endif
 
+// Branch-probability hints for the rare paths of a frame (tie replay, revived nodes, pool overflow, last frame): the
+// compiler then lays the common path out as fall-through code (measured: +0.7 % at the north-star shape).
+#define CTC_RARE(x) __builtin_expect(!!(x), 0)
+#define CTC_USUAL(x) __builtin_expect(!!(x), 1)
+
 namespace ctcbeam {
 
 struct PoolNode {   // one alive-or-retired trie node in HBM (16 bytes, one dwordx4 access)
@@ -605,7 +610,7 @@ struct Decoder {
     x.mark(13);
     // The usual outcome: the first histogram isolates a bucket with a handful of keys, several values wide.  Everything
     // about it fits 32-bit arithmetic (the window's top is the previous best key, below 2^32).
-    if (fb[0] >= 0 && fb[3] <= kListCap && (wd.shift != 0 || fb[0] == kBins - 1)) {
+    if (CTC_USUAL(fb[0] >= 0 && fb[3] <= kListCap && (wd.shift != 0 || fb[0] == kBins - 1))) {
       const uint32_t b32 = wd.lo + ((uint32_t)fb[0] << wd.shift);
       const uint32_t bspan = fb[0] == kBins - 1 ? 0xFFFFFFFFu - b32 : (1u << wd.shift) - 1u;
       rank_bucket(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3]);
@@ -849,7 +854,7 @@ struct Decoder {
           pr = rank_of_char(in, b.ch[j]);
         } else {
           // dead-interior child X of the nearest in-beam ancestor on the way down to j (alive because j is below it)
-          if (b.viaanc[j] != b.node[P]) {
+          if (CTC_RARE(b.viaanc[j] != b.node[P])) {
             int hops = dj - b.dep[P] - 1, xn = b.node[j];
             for (int h = 0; h < hops; ++h) xn = pool[xn].parent;
             b.via[j] = xn;
@@ -911,7 +916,7 @@ struct Decoder {
         const int s0 = w.ostart[j];
         uint32_t k0 = 0, i0 = kHoleInfo;
         const int rx = w.revr[j];
-        if (rx >= 0 && !cut(w.clp[rx], b.score[P])) {                       // path_trie.cpp:40-57: hit + revive
+        if (CTC_RARE(rx >= 0 && !cut(w.clp[rx], b.score[P]))) {                       // path_trie.cpp:40-57: hit + revive
           const int cx = b.viach[j];
           const float lp = w.clp[rx];
           const int xn = b.via[j];
@@ -1021,25 +1026,25 @@ struct Decoder {
     const int N = LM ? x.uni(pv[P_NCAND]) : n * (1 + Vnb) - x.uni(npin_total);
     uint32_t tau = 0, tauc = 0;
     bool exact = false, have_bitmap = false;
-    if (N > K) {  // ctc_beam_search_decoder.cpp:150
+    if (CTC_USUAL(N > K)) {  // ctc_beam_search_decoder.cpp:150
       have_bitmap = select_kth(S, K, pv, wd);
       int tv[4];
       x.uni4(&w.vars[VAR_TAU], tv);
       tau = (uint32_t)tv[0];
       const int E = tv[2], m = K - tv[1];
-      if (E > m) {
+      if (CTC_RARE(E > m)) {
         have_bitmap = false;
         if (resolve_by_character(S, tau, m, E, pv)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);
         else exact = true;  // the boundary splits a group of equivalent prefixes
       }
-      if (last) exact = true;  // decode() sorts the array exactly as nth_element left it (:164-190)
+      if (CTC_RARE(last)) exact = true;  // decode() sorts the array exactly as nth_element left it (:164-190)
     }
     x.mark(5);
 
     // ---- D: who survives, in DFS (= slot) order.  Normally an ordered compaction of the slots that pass the
     // threshold; when the outcome depends on it, an exact replay of std::nth_element followed by a ranking by slot.
     const int n_new = N < K ? N : K;
-    if (exact) {
+    if (CTC_RARE(exact)) {
       for (int s = tid; s <= S; s += nt) w.pos[s] = (s < S && info_type(w.sinfo[s]) != T_HOLE) ? 1u : 0u;
       x.sync();
       x.scan_excl(w.pos, S + 1);
@@ -1071,7 +1076,7 @@ struct Decoder {
       x.mark(3);
     }
     x.mark(4);
-    if (pool_count + n_new > pool_cap) {  // cannot happen when the pool is sized 1 + K*T
+    if (CTC_RARE(pool_count + n_new > pool_cap)) {  // cannot happen when the pool is sized 1 + K*T
       if (tid == 0) w.vars[VAR_STATUS] = ST_POOL_OVERFLOW;
       x.sync_full();
       return ST_POOL_OVERFLOW;
@@ -1134,7 +1139,7 @@ struct Decoder {
             PoolNode pn; pn.parent = node_j; pn.ch = c; pn.tstep = in.t; pn.lpc = w.clp[rank_of_char(in, c)];
             pool[id] = pn;
             pool_up[id] = upv;
-          } else if (!self) {                                                         // path_trie.cpp:50-56 : revived
+          } else if (CTC_RARE(!self)) {                                                         // path_trie.cpp:50-56 : revived
             const int P = w.anc[j];
             o_node = via_j; o_par = b.node[P]; o_dep = b.dep[P] + 1; o_up = pool_up[via_j];
           }
@@ -1174,7 +1179,7 @@ struct Decoder {
       x.wave_max_to(&pv[P_NMAXKEY], kloc);
       if (LM) x.wave_min_to(&pv[P_NMINKEY], kmin);
     }
-    if (last) {  // the order std::nth_element left the survivors in (identity when it was not called)
+    if (CTC_RARE(last)) {  // the order std::nth_element left the survivors in (identity when it was not called)
       for (int q = tid; q < n_new; q += nt) w.fin[q] = exact ? rk[q] : q;
     }
     // un-register this step's candidates from the rank table -- only once every wave has finished emitting (the emit
