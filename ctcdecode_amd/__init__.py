@@ -62,7 +62,7 @@ class CTCBeamDecoder(object):
     """
 
     def __init__(self, labels, model_path=None, alpha=0, beta=0, cutoff_top_n=40, cutoff_prob=1.0, beam_width=100,
-                 num_processes=4, blank_id=0, log_probs_input=False, device=None):
+                 num_processes=4, blank_id=0, log_probs_input=False, device=None, logits_input=False):
         self.cutoff_top_n = cutoff_top_n
         self._beam_width = beam_width
         self._scorer = None
@@ -70,7 +70,9 @@ class CTCBeamDecoder(object):
         self._labels = list(labels)
         self._num_labels = len(labels)
         self._blank_id = blank_id
-        self._log_probs = 1 if log_probs_input else 0
+        # logits_input (extension, not in the reference): the input holds raw logits; the device normalises them with a
+        # float32 log_softmax (include/ctcdecode_amd.h ctcd_log_softmax) before decoding
+        self._log_probs = 2 if logits_input else (1 if log_probs_input else 0)
         self._cutoff_prob = cutoff_prob
         if not torch.cuda.is_available():
             raise RuntimeError("ctcdecode_amd: no HIP device visible; this decoder has no CPU path")
@@ -173,6 +175,22 @@ class CTCBeamDecoder(object):
                 out_len.data_ptr(), None, stream))
         return output, scores, timesteps, out_len
 
+    def log_softmax(self, logits, seq_lens=None):
+        """The float32 log_softmax that ``logits_input=True`` applies before decoding, as a tensor in HBM ([B, T, V]; frames at
+        or beyond ``seq_lens`` are left 0).  Bit-reproducible: see include/ctcdecode_amd.h ctcd_log_softmax."""
+        if logits.dim() != 3:
+            raise ValueError("logits must be [batch, time, labels]")
+        logits = logits.to(device=self._device, dtype=torch.float32).contiguous()
+        B, T, V = logits.shape
+        if seq_lens is not None:
+            seq_lens = seq_lens.to(device=self._device, dtype=torch.int32).contiguous()
+        with torch.cuda.device(self._device):
+            out = torch.zeros_like(logits)
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            _native.check(_native.lib.ctcd_log_softmax(self._handle, logits.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None,
+                                                       B, T, V, out.data_ptr(), stream))
+        return out
+
     def decode_padded(self, probs, seq_lens=None):
         """The same call with the padded [B, K, T] tensors crossing PCIe (the delivery of round 1; kept for comparison)."""
         return _to_host(self.decode_device(probs, seq_lens))
@@ -248,7 +266,7 @@ class OnlineCTCBeamDecoder(object):
     every stream stay in HBM between calls; ``timesteps`` count frames from the beginning of the stream."""
 
     def __init__(self, labels, model_path=None, alpha=0, beta=0, cutoff_top_n=40, cutoff_prob=1.0, beam_width=100,
-                 num_processes=4, blank_id=0, log_probs_input=False, device=None):
+                 num_processes=4, blank_id=0, log_probs_input=False, device=None, logits_input=False):
         self._cutoff_top_n = cutoff_top_n
         self._beam_width = beam_width
         self._scorer = None
@@ -256,7 +274,9 @@ class OnlineCTCBeamDecoder(object):
         self._labels = list(labels)
         self._num_labels = len(labels)
         self._blank_id = blank_id
-        self._log_probs = 1 if log_probs_input else 0
+        # logits_input (extension, not in the reference): the input holds raw logits; the device normalises them with a
+        # float32 log_softmax (include/ctcdecode_amd.h ctcd_log_softmax) before decoding
+        self._log_probs = 2 if logits_input else (1 if log_probs_input else 0)
         self._cutoff_prob = cutoff_prob
         if not torch.cuda.is_available():
             raise RuntimeError("ctcdecode_amd: no HIP device visible; this decoder has no CPU path")

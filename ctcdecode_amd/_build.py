@@ -53,7 +53,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     for src in SOURCES:
         obj = os.path.splitext(lib_path)[0] + "." + os.path.splitext(src)[0] + ".o" if out else os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-               "-Wno-unused-result"] + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+               "-Wno-unused-result"] + ["-D" + d for d in defines] + os.environ.get("CTCD_EXTRA_HIPCC_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd), file=sys.stderr)

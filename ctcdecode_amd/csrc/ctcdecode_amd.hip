@@ -553,6 +553,41 @@ __global__ void scatter_elems_kernel(const float *vals, const unsigned long long
   if (k < n) out[idx[k]] = vals[k];
 }
 
+// Raw-logit input (log_input == 2, an extension: the reference's callers run log_softmax themselves): one wave per frame,
+//   y_j = (x_j - m) - logf(s),  m = max_j x_j,  s = sum_j expf(x_j - m) in float32,
+// where lane l first adds up the terms j = l, l + 64, ... in increasing j and the 64 partial sums are then combined by a
+// butterfly (lane ^ 1, ^ 2, ... ^ 32); expf / logf are the bit-exact restatements of exact_math.h (expf below -88 is 0).
+// The order of the additions is part of the definition: tests/native/core_host.cpp computes the same thing with the C
+// library, bit for bit.  A frame without a finite logit yields -inf everywhere.
+__global__ void __launch_bounds__(256) log_softmax_rows_kernel(const float *in, float *out, long long rows, const int32_t *seq_lens, int T, int V,
+                                                               const uint64_t *tables) {
+  __shared__ uint64_t tbl[64];
+  if (threadIdx.x < 64) tbl[threadIdx.x] = tables[threadIdx.x];
+  __syncthreads();
+  const int lane = (int)threadIdx.x & 63;
+  const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long r = wave0; r < rows; r += nwaves) {
+    if (seq_lens) {  // frames beyond the utterance's length are never read (binding.cpp:64-65)
+      const long long b = r / T;
+      if ((int)(r - b * T) >= seq_lens[b]) continue;
+    }
+    const float *x = in + (size_t)r * V;
+    float *y = out + (size_t)r * V;
+    float m = -INFINITY;
+    for (int j = lane; j < V; j += 64) { const float v = x[j]; m = v > m ? v : m; }
+    for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if (!(m > -INFINITY)) {
+      for (int j = lane; j < V; j += 64) y[j] = -INFINITY;
+      continue;
+    }
+    float part = 0.0f;
+    for (int j = lane; j < V; j += 64) part += ctcmath::expf_nonpos(x[j] - m, tbl);
+    for (int off = 1; off < 64; off <<= 1) part += __shfl_xor(part, off, 64);
+    const float ls = ctcmath::logf_normal(part, tbl);
+    for (int j = lane; j < V; j += 64) y[j] = (x[j] - m) - ls;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ vocabulary prune
 // get_pruned_log_probs (decoder_utils.cpp:10-45) for every frame, one wave per frame, no barriers: the top
 // min(cutoff_top_n, V) values in descending order (and, with cutoff_prob < 1, the reference's cumulative cut).
@@ -1136,7 +1171,7 @@ struct ctcd_decoder {
   HostPool *workers = nullptr;
   int threads = 0;  // 0 = choose per call from the number of candidate slots
   int max_lds = 0;
-  Buf pool, status, tables, logp, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
+  Buf pool, status, tables, logp, lsm, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
   Buf prune_in, prune_out, st_lens;  // own staging: the host-pointer entry points keep their tensors in stage_in/out
   long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
   bool tables_ready = false;
@@ -1289,7 +1324,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   if (!d) return;
   DeviceGuard guard_(d->device);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->ev3); }
-  d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->flags.release();
+  d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->lsm.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
   d->dbg.release(); d->tl.release();
   d->c_hdr.release(); d->c_ent.release(); d->c_rag.release(); d->c_cnt.release(); d->c_sc.release(); d->c_ln.release();
@@ -1371,6 +1406,18 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if ((rc = d->tables.ensure(sizeof(ctcmath::Tables)))) return rc;
     HIP_TRY(hipMemcpy(d->tables.p, ctcmath::host_tables().w, sizeof(ctcmath::Tables), hipMemcpyHostToDevice));
     d->tables_ready = true;
+  }
+  if (log_input == 2) {  // raw logits: normalise once, in HBM; everything below sees log-probabilities
+    if (T > 0) {
+      if ((rc = d->lsm.ensure((size_t)B * T * V * 4))) return rc;
+      if (seq_lens) HIP_TRY(hipMemsetAsync(d->lsm.p, 0, (size_t)B * T * V * 4, stream));  // frames past an utterance's end stay defined
+      const long long rows = (long long)B * T;
+      hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 256 * 64)), dim3(256), 0, stream, probs,
+                         (float *)d->lsm.p, rows, seq_lens, T, V, (const uint64_t *)d->tables.p);
+      HIP_TRY(hipGetLastError());
+      probs = (const float *)d->lsm.p;
+    }
+    log_input = 1;
   }
   const long long pool_stride = (long long)beam * T + 1;
   if (!sc && (rc = d->pool.ensure((size_t)B * pool_stride * (sizeof(PoolNode) + sizeof(int))))) return rc;
@@ -1913,6 +1960,29 @@ int ctcd_beam_decode_lm_host(ctcd_decoder *d, const float *probs, const int32_t 
                              int32_t *n_results) {
   return ctcd_beam_decode_to_host(d, probs, seq_lens, 0, B, T, V, beam, num_processes, cutoff_prob, cutoff_top_n, blank_id, log_input,
                                   scorer, out_tok, out_ts, out_sc, out_len, n_results, nullptr);
+}
+
+// The normalisation that log_input == 2 applies, on its own (device pointers; `out` may alias `logits`): float32
+// log_softmax over the last axis with the summation order documented at log_softmax_rows_kernel.
+int ctcd_log_softmax(ctcd_decoder *d, const float *logits, const int32_t *seq_lens, int B, int T, int V, float *out, void *stream_) {
+  if (!d || !logits || !out || B < 0 || T < 0 || V < 1) return fail(CTCD_EINVAL, "bad arguments");
+  if (B == 0 || T == 0) return CTCD_OK;
+  CTC_ON_DEVICE(d->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  {
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (!d->tables_ready) {
+      if ((rc = d->tables.ensure(sizeof(ctcmath::Tables)))) return rc;
+      HIP_TRY(hipMemcpy(d->tables.p, ctcmath::host_tables().w, sizeof(ctcmath::Tables), hipMemcpyHostToDevice));
+      d->tables_ready = true;
+    }
+  }
+  const long long rows = (long long)B * T;
+  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 256 * 64)), dim3(256), 0, stream, logits, out, rows,
+                     seq_lens, T, V, (const uint64_t *)d->tables.p);
+  HIP_TRY(hipGetLastError());
+  return CTCD_OK;
 }
 
 // HIP-event timing of the decode kernel alone, on the stream it is launched on (bench.py's roofline figure).

@@ -16,7 +16,9 @@
  * calling thread.
  *
  * Tensor layouts (row-major, identical to the reference's tensors, ctcdecode/__init__.py:83-86):
- *   probs        float32 [B, T, V]   log-probabilities if log_input != 0, probabilities otherwise
+ *   probs        float32 [B, T, V]   log_input == 1: log-probabilities; 0: probabilities (the reference's two modes,
+ *                                    ctcdecode/__init__.py:42 log_probs_input); 2 (extension): raw logits, normalised on the
+ *                                    device by a float32 log_softmax first (see ctcd_log_softmax)
  *   seq_lens     int32   [B] or NULL (all T); each clamped to [0, T]         (binding.cpp:64-65)
  *   out_tokens   int32   [B, beam, T] label ids   of beam p of item b at [b][p][0 .. out_lens[b][p])
  *   out_timesteps int32  [B, beam, T] frame index at which each label's probability peaked (path_trie.cpp:42-45)
@@ -52,6 +54,13 @@ int ctcd_beam_decode(ctcd_decoder *dec, const float *probs, const int32_t *seq_l
                      int num_processes /* accepted for signature parity; unused on the GPU */, double cutoff_prob,
                      int cutoff_top_n, int blank_id, int log_input, int32_t *out_tokens, int32_t *out_timesteps,
                      float *out_scores, int32_t *out_lens, int32_t *n_results, void *stream);
+
+/* log_softmax over the last axis of float32 [B, T, V] device memory, `out` may alias `logits` (no reference counterpart:
+ * its callers run torch's log_softmax before decode(), README.md:30-38).  This is what log_input == 2 applies.  Defined
+ * to the bit: y_j = (x_j - m) - logf(s), m = max x, s = sum_j expf(x_j - m) in float32 with lane l = j mod 64 adding its
+ * terms in increasing j and the 64 partial sums combined by a butterfly (^1, ^2, ... ^32); expf / logf as in glibc, expf
+ * below -88 taken as 0.  Frames at or beyond seq_lens[b] are not touched.  Asynchronous on `stream`. */
+int ctcd_log_softmax(ctcd_decoder *dec, const float *logits, const int32_t *seq_lens, int B, int T, int V, float *out, void *stream);
 
 /* Same, with HOST pointers for every tensor (what paddle_beam_decode receives).  Synchronous. */
 int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,

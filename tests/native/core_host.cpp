@@ -145,6 +145,37 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
                        int32_t *out_timesteps, float *out_scores, int32_t *out_lens, int32_t *n_results,
                        const ctclm::LmView *lm, const float *raw, int raw_log);
 
+// Host twin of the product's log_softmax pre-pass (ctcdecode_amd.hip log_softmax_rows_kernel; input mode 2 / ctcd_log_softmax):
+// the same float32 operations in the same order, with the C library's expf / logf.
+extern "C" void ctccore_log_softmax_rows(const float *x, long long rows, int V, float *out) {
+  for (long long r = 0; r < rows; ++r) {
+    const float *xr = x + (size_t)r * V;
+    float *yr = out + (size_t)r * V;
+    float m = -INFINITY;
+    for (int j = 0; j < V; ++j) m = xr[j] > m ? xr[j] : m;
+    if (!(m > -INFINITY)) {
+      for (int j = 0; j < V; ++j) yr[j] = -INFINITY;
+      continue;
+    }
+    float part[64];
+    for (int l = 0; l < 64; ++l) {
+      float p = 0.0f;
+      for (int j = l; j < V; j += 64) {
+        const float d = xr[j] - m;
+        p += d < -88.0f ? 0.0f : std::exp(d);
+      }
+      part[l] = p;
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+      float nxt[64];
+      for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ off];
+      std::memcpy(part, nxt, sizeof(part));
+    }
+    const float ls = std::log(part[0]);
+    for (int j = 0; j < V; ++j) yr[j] = (xr[j] - m) - ls;
+  }
+}
+
 // log-probability input only (the prob->log conversion is a separate, elementwise stage of the product).
 extern "C" int ctccore_decode_f32(const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, int num_threads,
                                   double cutoff_prob, int cutoff_top_n, int blank_id, int32_t *out_tokens,

@@ -178,6 +178,17 @@ def build_core_host():
     return CORE_HOST_SO
 
 
+def log_softmax_rows(x):
+    """float32 log_softmax over the last axis exactly as the product's pre-pass defines it (host twin, C library expf/logf)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib = ctypes.CDLL(build_core_host())
+    lib.ctccore_log_softmax_rows.restype = None
+    lib.ctccore_log_softmax_rows.argtypes = [_f32p, ctypes.c_longlong, ctypes.c_int, _f32p]
+    lib.ctccore_log_softmax_rows(_ptr(x, _f32p), x.size // x.shape[-1], x.shape[-1], _ptr(out, _f32p))
+    return out
+
+
 def decode_core_host(probs, seq_lens=None, beam=100, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, threads=None):
     probs = np.ascontiguousarray(probs, dtype=np.float32)
     B, T, V = probs.shape

@@ -132,3 +132,22 @@ def test_compact_results_expand_to_the_padded_tensors():
         assert got["labels_used"] <= int(want["lens"].sum())
         if T >= 150 and not kw.get("blank_bias"):
             assert got["labels_used"] * 2 < int(want["lens"].sum()), "the beam's sequences overlap: far fewer labels travel than rows hold"
+
+
+def test_log_softmax_host_twin_is_a_log_softmax():
+    """The host twin of the logits pre-pass (exact definition in include/ctcdecode_amd.h) against float64 arithmetic."""
+    rng = np.random.default_rng(11)
+    for V in (1, 2, 29, 64, 65, 130, 1000):
+        x = (rng.standard_normal((7, V)) * 4).astype(np.float32)
+        x[1, :] -= 200.0
+        if V > 2:
+            x[2, 1] = -np.inf
+            x[3, :] = -np.inf
+        y = ou.log_softmax_rows(x)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            x64 = x.astype(np.float64)
+            m = x64.max(-1, keepdims=True)
+            want = x64 - m - np.log(np.exp(x64 - m).sum(-1, keepdims=True))
+        ok = np.isfinite(want)
+        assert np.allclose(y[ok], want[ok], rtol=0, atol=2e-6 * (1 + np.log(V)))
+        assert np.all(np.isneginf(y[~ok]))

@@ -455,3 +455,38 @@ def test_result_delivery_paths_agree(torch_mod):
         want = ou.decode(lp, sl, beam=K)
         got = dict(tokens=a[0].numpy(), scores=a[1].numpy(), timesteps=a[2].numpy(), lens=a[3].numpy())
         ou.assert_same(_with_nres(got, want), want, "delivery case %d" % seed)
+
+
+def test_logits_input_prepass(torch_mod):
+    """Raw-logit input (logits_input=True / log_input == 2, an extension): the device's float32 log_softmax is defined to
+    the bit (include/ctcdecode_amd.h ctcd_log_softmax) -- checked against its host twin -- and decoding logits equals the
+    reference decoding those log-probabilities."""
+    import ctcdecode_amd
+
+    torch = torch_mod
+    rng = np.random.default_rng(5)
+    for V in (1, 2, 29, 64, 65, 130, 1000):
+        x = (rng.standard_normal((3, 17, V)) * 4).astype(np.float32)
+        x[0, 1] -= 200.0
+        x[1, 2, ::3] = -np.inf
+        x[2, 3] = -np.inf
+        x[2, 4] *= 40.0  # exp(x - max) underflows for most labels
+        dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], device="cuda:0")
+        got = dec.log_softmax(torch.from_numpy(x)).cpu().numpy()
+        want = ou.log_softmax_rows(x)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "V=%d" % V
+        sl = np.array([17, 5, 0], np.int32)
+        got = dec.log_softmax(torch.from_numpy(x), torch.from_numpy(sl)).cpu().numpy()
+        for b in range(3):
+            assert np.array_equal(got[b, :sl[b]].view(np.uint32), want[b, :sl[b]].view(np.uint32)) and not got[b, sl[b]:].any()
+    for (B, T, V, K, kw) in [(4, 150, 29, 100, {}), (3, 60, 9, 16, dict(cutoff_top_n=4)), (2, 40, 300, 25, dict(cutoff_top_n=40, cutoff_prob=0.9))]:
+        logits = (rng.standard_normal((B, T, V)) * 2.5).astype(np.float32)
+        sl = np.array([T, T // 2, 0, 7][:B], np.int32)
+        dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], beam_width=K, logits_input=True, device="cuda:0", **kw)
+        out, sc, ts, ln = dec.decode(torch.from_numpy(logits), torch.from_numpy(sl))
+        got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+        want = ou.decode(ou.log_softmax_rows(logits), sl, beam=K, **kw)
+        ou.assert_same(_with_nres(got, want), want, "logits B%d T%d V%d" % (B, T, V))
+        # device-resident logits through the HBM-to-HBM entry as well
+        d2 = dec.decode_device(torch.from_numpy(logits).cuda(), torch.from_numpy(sl).cuda())
+        assert np.array_equal(d2[1].cpu().numpy().view(np.uint32), sc.numpy().view(np.uint32))
