@@ -150,7 +150,8 @@ def other_configs(torch, ctcdecode_amd, dev):
         if ps:
             r["prune_kernel_ms"] = round(min(ps[1:]), 3)
             r["prune_GBps"] = round(B * T * V * 4 / (min(ps[1:]) * 1e-3) / 1e9, 1)
-            r["prune_host_rows"] = int(ctcdecode_amd._native.lib.ctcd_last_prune_host_rows(dec._handle))
+            r["prune_flagged_rows"] = int(ctcdecode_amd._native.lib.ctcd_last_prune_flagged_rows(dec._handle))  # settled by the device's std::sort replay ...
+            r["prune_host_rows"] = int(ctcdecode_amd._native.lib.ctcd_last_prune_host_rows(dec._handle))  # ... except these
         out[name] = r
         del dec, lp
         torch.cuda.empty_cache()

@@ -1230,44 +1230,7 @@ struct Decoder {
       x.sync();
       return;
     }
-    int *cur = w.bins, *nxt = w.bins + 3 * kTaskCap, *small = w.surv;
-    int *cnt = w.vars + VAR_TAU;  // [0], [1]: pending ranges of the next round (by round parity), [2]: final ranges
-    if (tid == 0) {
-      cnt[0] = 0; cnt[1] = 0; cnt[2] = 0;
-      cur[0] = 0; cur[1] = n; cur[2] = 2 * stlemu::floor_lg(n);
-    }
-    x.sync();
-    int ntask = 1;
-    for (int round = 0; ntask > 0; ++round) {
-      int *c_next = cnt + (round & 1);
-      for (int k = tid; k < ntask; k += nt) {
-        const int first = cur[3 * k], last = cur[3 * k + 1], depth = cur[3 * k + 2];
-        if (depth == 0) {
-          stlemu::heap_select(v, first, last, last, before);
-          stlemu::heap_sort_down(v, first, last, before);
-          continue;
-        }
-        const int cut = stlemu::split_with_median_pivot(v, first, last, before);
-        for (int side = 0; side < 2; ++side) {
-          const int a = side ? cut : first, e = side ? last : cut;
-          if (e - a > 16) {
-            const int i = x.atomic_add(c_next, 1);
-            nxt[3 * i] = a; nxt[3 * i + 1] = e; nxt[3 * i + 2] = depth - 1;
-          } else if (e - a > 1) {
-            const int i = x.atomic_add(cnt + 2, 1);
-            small[2 * i] = a; small[2 * i + 1] = e;
-          }
-        }
-      }
-      x.sync();
-      ntask = x.uni(*c_next);
-      if (tid == 0) cnt[(round + 1) & 1] = 0;  // the counter of the round after next; nobody reads it any more
-      int *t = cur; cur = nxt; nxt = t;
-      x.sync();
-    }
-    const int nsmall = x.uni(cnt[2]);
-    for (int k = tid; k < nsmall; k += nt) stlemu::insertion_sort(v, small[2 * k], small[2 * k + 1], before);
-    x.sync();
+    stlemu::sort_parallel(x, v, n, before, w.bins, w.bins + 3 * kTaskCap, w.surv, w.vars + VAR_TAU);
   }
 
   // DecoderState::decode() + get_beam_search_result + binding.cpp:85-99 for one utterance.

@@ -832,6 +832,40 @@ __global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
 // conversion are decided as in prune_rows_kernel above.  Few registers per thread (nothing of the row is kept), so
 // eight workgroups share a CU and hide each other's latencies.
 // Requires V % 4 == 0 (16-byte aligned rows), V <= 1024 * F4, cutoff_top_n <= 64.
+// decoder_utils.cpp:25-32 for one frame, by one wave: the kept candidates (sidx[0, kept): their labels, best first) are cut
+// where the running sum of their probabilities reaches cutoff_prob (the reference accumulates log(1 + sum): its running
+// value starts at 0.0 in log space).  The device's exp()/log() may differ from the host C library's in the last place:
+// whenever the comparison with cutoff_prob could go either way before (or at) the stopping point, `flag` is raised and the
+// host decides the frame.
+__device__ __forceinline__ int prune_cumulative_cut(const PruneArgs &a, const float *x, const int *sidx, int kept, int lane, bool &flag) {
+  int stop = kept;
+  double carry = 0.0;
+  for (int i0 = 0; i0 < kept && stop == kept; i0 += 64) {
+    const int i = i0 + lane;
+    double p = 0.0;
+    if (i < kept) {
+      const double v = (double)x[sidx[i]];
+      p = a.log_input ? exp(v) : v;
+    }
+    double incl = p;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    const double cum = log(1.0 + carry + incl);
+    const bool near = i < kept && (fabs(cum - a.cutoff_prob) <= 1e-9 * (1.0 + fabs(cum)) || !(cum == cum));
+    const bool hit = i < kept && (cum >= a.cutoff_prob || i + 1 >= a.top_n);
+    const unsigned long long mh = __ballot(hit), mn = __ballot(near);
+    const int firsthit = mh ? __ffsll((long long)mh) - 1 : 64;
+    if (mn && (__ffsll((long long)mn) - 1) <= firsthit) flag = true;
+    if (mh) stop = i0 + firsthit + 1;
+    carry += __shfl(incl, 63, 64);
+  }
+  flag = __ballot(flag) != 0ull;
+  return stop;
+}
+
 template <int F4>
 __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
@@ -939,34 +973,7 @@ __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
       flag = __ballot(flag) != 0ull;
       int len = kept;
-      if (a.cutoff_prob < 1.0 && !flag) {  // decoder_utils.cpp:25-32, as in prune_rows_kernel
-        int stop = kept;
-        double carry = 0.0;
-        for (int i0 = 0; i0 < kept && stop == kept; i0 += 64) {
-          const int i = i0 + lane;
-          double p = 0.0;
-          if (i < kept) {
-            const double v = (double)x[sidx[i]];
-            p = a.log_input ? exp(v) : v;
-          }
-          double incl = p;
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            const double o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-          }
-          const double cum = log(1.0 + carry + incl);
-          const bool near = i < kept && (fabs(cum - a.cutoff_prob) <= 1e-9 * (1.0 + fabs(cum)) || !(cum == cum));
-          const bool hit = i < kept && (cum >= a.cutoff_prob || i + 1 >= a.top_n);
-          const unsigned long long mh = __ballot(hit), mn = __ballot(near);
-          const int firsthit = mh ? __ffsll((long long)mh) - 1 : 64;
-          if (mn && (__ffsll((long long)mn) - 1) <= firsthit) flag = true;
-          if (mh) stop = i0 + firsthit + 1;
-          carry += __shfl(incl, 63, 64);
-        }
-        len = stop;
-        flag = __ballot(flag) != 0ull;
-      }
+      if (a.cutoff_prob < 1.0 && !flag) len = prune_cumulative_cut(a, x, sidx, kept, lane, flag);
       if (lane == 0) {
         a.cnt[r] = len;
         if (flag) {
@@ -976,6 +983,183 @@ __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
       }
     }
     __syncthreads();  // the lists are reused by the next frame
+  }
+}
+
+// Flagged frames, second chance on the device.  Most flags are ties: equal values at or above the cut, whose order (and,
+// at the cut, which of them are kept) is whatever std::sort leaves behind -- a function of the whole row.  One workgroup
+// per flagged frame replays that std::sort call (decoder_utils.cpp:19-20: (index, double) pairs in index order, compared
+// on the value alone) with stl_emul.h's workgroup-parallel introsort, takes the first min(top_n, V) pairs and applies the
+// cumulative cut.  What remains for the host (n_host / host_rows): frames with a NaN, borderline libm roundings (the
+// prob -> log conversion, the cumulative sum next to cutoff_prob), rows too long for the workgroup's LDS.
+struct WgSortX {
+  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+  __device__ __forceinline__ int nt() const { return (int)blockDim.x; }
+  __device__ __forceinline__ void sync() { __syncthreads(); }
+  __device__ __forceinline__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+  __device__ __forceinline__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+};
+__host__ __device__ inline int prune_resolve_task_cap(int V) { return V / 17 + 2; }
+constexpr int kResolveBigCut = 256;    // ranges longer than this are split by the whole workgroup
+constexpr int kResolveMaxV = 65535;    // 16-bit positions and counters
+__host__ __device__ inline size_t prune_resolve_lds_bytes(int V, int n) {
+  // pairs | Lp, Rp | two task lists | final ranges | stack of long ranges | counters | the kept labels
+  return (size_t)V * 8 + (size_t)2 * (V + 2) * 2 + (size_t)6 * prune_resolve_task_cap(V) * 2 + (size_t)2 * (V / 2 + 1) * 2 + 3 * 64 * 4 + 64 +
+         (size_t)n * 4 + 64;
+}
+// std::sort(v, v + V, before) by one workgroup, element for element.  Long ranges first, one at a time, each split by all
+// threads: the t-th element from the left that is not better than the pivot is exchanged with the t-th from the right that
+// is not worse, until the two scans cross (the exchanges of the serial Hoare loop, found with two prefix counts -- the
+// scheme of beam_core.h replay_nth_element); the ranges that remain (<= kResolveBigCut) go through stlemu::sort_parallel,
+// one thread per range and round.
+template <class C>
+__device__ void resolve_sort_like_std(unsigned long long *v, int V, C before, uint16_t *Lp, uint16_t *Rp, uint16_t *cur, uint16_t *nxt,
+                                      uint16_t *small, int *cnt, int *bstack, uint32_t *wsum) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WgSortX x;
+  if (V <= 16) {
+    if (tid == 0) stlemu::sort(v, 0, V, before, bstack);
+    __syncthreads();
+    return;
+  }
+  int sp = 0, ntask = 0, nsmall = 0;  // (identical in every thread)
+  if (tid == 0) { bstack[0] = 0; bstack[1] = V; bstack[2] = 2 * stlemu::floor_lg(V); }
+  sp = 1;
+  __syncthreads();
+  while (sp > 0) {
+    --sp;
+    const int first = bstack[3 * sp], last = bstack[3 * sp + 1];
+    int depth = bstack[3 * sp + 2];
+    __syncthreads();  // (the slot is about to be overwritten by a push)
+    if (last - first <= kResolveBigCut) {
+      if (tid == 0) { cur[3 * ntask] = (uint16_t)first; cur[3 * ntask + 1] = (uint16_t)last; cur[3 * ntask + 2] = (uint16_t)depth; }
+      ++ntask;
+      continue;
+    }
+    if (depth == 0) {  // depth budget spent on a long range (adversarial input): the heap sort, by one thread
+      if (tid == 0) { stlemu::heap_select(v, first, last, last, before); stlemu::heap_sort_down(v, first, last, before); }
+      __syncthreads();
+      continue;
+    }
+    --depth;
+    if (tid == 0) stlemu::median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
+    __syncthreads();
+    const int lo = first + 1, m = last - lo;
+    const uint32_t kp = (uint32_t)(v[first] >> 32);
+    const int chunk = (m + 255) >> 8, i0 = min(tid * chunk, m), i1 = min(i0 + chunk, m);
+    uint32_t mine = 0;  // #left stops | #right stops << 16 in this thread's stretch
+    for (int i = i0; i < i1; ++i) {
+      const uint32_t k = (uint32_t)(v[lo + i] >> 32);
+      mine += (k <= kp ? 1u : 0u) + (k >= kp ? 0x10000u : 0u);
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int q = 0; q < 4; ++q) { const uint32_t t = wsum[q]; if (q < wave) base += t; tot += t; }
+    const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
+    uint32_t run = base + incl - mine;
+    for (int i = i0; i < i1; ++i) {
+      const uint32_t k = (uint32_t)(v[lo + i] >> 32);
+      if (k <= kp) { Lp[run & 0xFFFFu] = (uint16_t)(lo + i); run += 1u; }
+      if (k >= kp) { Rp[nR - 1 - (int)(run >> 16)] = (uint16_t)(lo + i); run += 0x10000u; }
+    }
+    if (tid == 0) Rp[nR] = (uint16_t)first;  // the pivot itself stops the right-to-left scan
+    __syncthreads();
+    // Iteration t of the serial loop stops its left scan at min(Lp[t], Rp[t-1]) (the element swapped into Rp[t-1] is
+    // itself a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
+    const int tmax = nL < nR + 1 ? nL : nR + 1;
+    auto crossed = [&](int t) { return t >= nL || t > nR || Lp[t] >= Rp[t]; };
+    for (int t = tid; t <= tmax; t += 256) {
+      if (!crossed(t)) {
+        stlemu::exch(v, (int)Lp[t], (int)Rp[t]);
+      } else if (t == 0 || !crossed(t - 1)) {
+        int c = t < nL ? (int)Lp[t] : 0x7fffffff;
+        if (t > 0 && (int)Rp[t - 1] < c) c = Rp[t - 1];
+        cnt[3] = c;
+      }
+    }
+    __syncthreads();
+    const int cut = cnt[3];
+    for (int side = 0; side < 2; ++side) {
+      const int a = side ? cut : first, e = side ? last : cut;
+      if (e - a > 16) {
+        if (tid == 0) { bstack[3 * sp] = a; bstack[3 * sp + 1] = e; bstack[3 * sp + 2] = depth; }
+        ++sp;
+      } else if (e - a > 1) {
+        if (tid == 0) { small[2 * nsmall] = (uint16_t)a; small[2 * nsmall + 1] = (uint16_t)e; }
+        ++nsmall;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[2] = nsmall; }
+  __syncthreads();
+  stlemu::sort_parallel(x, v, V, before, cur, nxt, small, cnt, ntask);
+}
+
+__global__ void __launch_bounds__(256) prune_resolve_kernel(PruneArgs a, unsigned *n_host, unsigned *host_rows) {
+  extern __shared__ __attribute__((aligned(16))) char rsm[];
+  __shared__ int s_bad;
+  __shared__ uint32_t s_wsum[4];
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int V = a.V, n = a.top_n < V ? a.top_n : V;
+  const int tcap = prune_resolve_task_cap(V);
+  unsigned long long *v = (unsigned long long *)rsm;
+  uint16_t *Lp = (uint16_t *)(v + V), *Rp = Lp + (V + 2), *cur = Rp + (V + 2), *nxt = cur + 3 * tcap, *small = nxt + 3 * tcap;
+  int *bstack = (int *)(((uintptr_t)(small + 2 * (V / 2 + 1)) + 15) & ~(uintptr_t)15);
+  int *cnt = bstack + 3 * 64, *sidx = cnt + 4;
+  const unsigned raw = *a.n_flag, nf = raw < a.flag_cap ? raw : a.flag_cap;
+  for (unsigned k = blockIdx.x; k < nf; k += gridDim.x) {
+    const long long r = (long long)a.flag_rows[k];
+    const float *row = a.in + (size_t)r * V;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    bool nan = false;
+    for (int i = tid; i < V; i += 256) {
+      const float f = row[i];
+      nan |= f != f;
+      v[i] = ((unsigned long long)prune_key(f) << 32) | (unsigned)i;
+    }
+    if (nan) s_bad = 1;
+    __syncthreads();
+    if (!s_bad) {
+      // decoder_utils.cpp:19-20: (index, double) pairs in index order, std::sort on the value alone, descending
+      resolve_sort_like_std(v, V, [](unsigned long long p, unsigned long long q) { return (uint32_t)(p >> 32) > (uint32_t)(q >> 32); }, Lp, Rp, cur,
+                            nxt, small, cnt, bstack, s_wsum);
+      if (tid < 64) {
+        bool flag = false;
+        int *och = a.ch + (size_t)r * a.stride;
+        float *olp = a.lp + (size_t)r * a.stride;
+        for (int q = lane; q < n; q += 64) {
+          const int idx = (int)(uint32_t)v[q];
+          float val = row[idx];
+          if (!a.log_input) {  // decoder_utils.cpp:42
+            const double y = log((double)val + (double)FLT_MIN);
+            val = (float)y;
+            const double eps = fabs(y) * 0x1p-50;
+            if ((float)(y - eps) != val || (float)(y + eps) != val || !(y == y)) flag = true;
+          }
+          och[q] = idx; olp[q] = val; sidx[q] = idx;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
+        flag = __ballot(flag) != 0ull;
+        int len = n;
+        if (a.cutoff_prob < 1.0 && !flag) len = prune_cumulative_cut(a, row, sidx, n, lane, flag);
+        if (lane == 0) {
+          if (flag) s_bad = 1;
+          else a.cnt[r] = len;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0 && s_bad) host_rows[atomicAdd(n_host, 1u)] = (unsigned)r;
+    __syncthreads();
   }
 }
 
@@ -1174,6 +1358,8 @@ struct ctcd_decoder {
   Buf pool, status, tables, logp, lsm, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
   Buf prune_in, prune_out, st_lens;  // own staging: the host-pointer entry points keep their tensors in stage_in/out
   long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
+  long long prune_flagged_rows = 0;  // frames the prune pass could not settle itself (device tie replay + host)
+  bool no_prune_resolve = false;     // tests: send every flagged frame to the host
   bool tables_ready = false;
   bool timing = false;
   bool profile = false, dbg_on = false;
@@ -1448,6 +1634,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
 
   const float *logp = probs;
   d->prune_host_rows = 0;
+  d->prune_flagged_rows = 0;
   if (dims.use_rank_table && T > 0) {
     // vocabulary prune pass (also converts the kept probabilities to log space when log_input == 0)
     const long long rows = (long long)B * T;
@@ -1474,14 +1661,18 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     const size_t psm_launch = wg_kernel ? (3 * (size_t)stride + 2 * kPruneCand) * 4 : psm;
     const int blocks_launch = wg_kernel ? (int)std::min<long long>(rows, 256 * 32) : blocks;
     HIP_TRY(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm_launch));
-    unsigned nf = 0;
-    unsigned *n_flag = nullptr, *flag_rows = nullptr;
+    unsigned nf = 0, nh = 0;
+    unsigned *n_flag = nullptr, *flag_rows = nullptr, *host_rows = nullptr;
     d->prune_timed = false;
+    const size_t rlds = prune_resolve_lds_bytes(V, std::min(cutoff_top_n, V));
+    const bool resolve_on_device = V <= kResolveMaxV && rlds + 1024 <= (size_t)d->max_lds && !d->no_prune_resolve;
+    if (resolve_on_device) HIP_TRY(hipFuncSetAttribute((const void *)prune_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
     for (int attempt = 0; attempt < 2; ++attempt) {  // (a second pass only when more frames were flagged than the list held)
       if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
       n_flag = (unsigned *)d->flags.p;
       flag_rows = (unsigned *)((char *)d->flags.p + 8);
-      HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
+      host_rows = flag_rows + cap;
+      HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));  // n_flag, n_host
       HIP_TRY(hipMemsetAsync(d->pr_cnt.p, 0, (size_t)rows * 4, stream));
       PruneArgs pa;
       pa.in = probs; pa.seq_lens = seq_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
@@ -1492,14 +1683,26 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       HIP_TRY(hipLaunchKernel(pfn, dim3(blocks_launch), dim3(wpb * 64), pargs, psm_launch, stream));
       HIP_TRY(hipGetLastError());
       if (d->timing) { HIP_TRY(hipEventRecord(d->ev3, stream)); d->prune_timed = true; }
-      HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
+      // flagged frames whose outcome only depends on std::sort's treatment of equal values are settled on the device
+      if (resolve_on_device) {
+        hipLaunchKernelGGL(prune_resolve_kernel, dim3(256), dim3(256), rlds, stream, pa, n_flag + 1, host_rows);
+        HIP_TRY(hipGetLastError());
+      }
+      unsigned both[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(both, n_flag, 8, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
+      nf = both[0];
+      nh = resolve_on_device ? both[1] : nf;
       if (nf <= cap) break;
       cap = nf;  // the set of flagged frames is a function of the input: the list now holds all of them
     }
     if (nf > cap) return fail(CTCD_EINTERNAL, "flagged-frame count changed between two passes over the same input");
-    if (nf) {  // toolchain-defined cases: let the toolchain decide (real std::sort, real libm) -- batched transfers, in
+    d->prune_flagged_rows = nf;
+    if (!resolve_on_device) host_rows = flag_rows;
+    if (nh) {  // toolchain-defined cases: let the toolchain decide (real std::sort, real libm) -- batched transfers, in
                // chunks so that the staging memory stays bounded however many frames are flagged
+      nf = nh;
+      flag_rows = host_rows;
       std::vector<unsigned> fr(nf);
       HIP_TRY(hipMemcpy(fr.data(), flag_rows, (size_t)nf * 4, hipMemcpyDeviceToHost));
       const size_t rec = 1 + 2 * (size_t)stride;  // per frame: count, labels, log-probs
@@ -2031,6 +2234,14 @@ int ctcd_debug_set_fixed_layout(ctcd_decoder *d, int on) {
   return CTCD_OK;
 }
 
+// Flagged prune frames: 1 (default) = the device replays std::sort for them, 0 = the host toolchain decides all of them
+// (the path that otherwise only sees libm-dependent frames).  Results are identical; the switch exists for the tests.
+int ctcd_debug_set_prune_resolve(ctcd_decoder *d, int on) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  d->no_prune_resolve = on == 0;
+  return CTCD_OK;
+}
+
 // Barrier timeline of batch item 0 (profiling build): call with out == NULL to arm frames [frame0, frame0 + nframes) of
 // the following decodes, with out != NULL (int64 [16][ctcd_debug_timeline_cap()]) to fetch: per wave, the shader clock
 // at arrival at / departure from each barrier, in program order.
@@ -2072,6 +2283,8 @@ int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, u
 
 // Number of frames of the last ctcd_beam_decode whose vocabulary prune was resolved on the host (ties / borderline).
 long long ctcd_last_prune_host_rows(ctcd_decoder *d) { return d ? d->prune_host_rows : -1; }
+// ... and the number the prune pass flagged in the first place (the rest were settled by the device's std::sort replay).
+long long ctcd_last_prune_flagged_rows(ctcd_decoder *d) { return d ? d->prune_flagged_rows : -1; }
 
 // Status words of the last ctcd_beam_decode on this decoder (device -> host); for callers of the async entry point.
 int ctcd_check_status(ctcd_decoder *d, int B) {

@@ -236,6 +236,61 @@ STLEMU_HD void sort(T *v, int first, int last, C before, int *stack) {
   }
 }
 
+// == std::sort(v, v + n, before), element for element -- also where `before` ties -- run by a whole workgroup.
+// Introsort's sub-ranges are disjoint once split, so the order in which they are finished cannot change the result:
+// every thread takes one pending range per round (median-of-three Hoare split, or the heap sort once the depth budget is
+// spent), and the closing insertion sort -- which never moves an element across a split point, because the comparison
+// is strict -- is done per final range (at most 16 elements) by one thread each.
+// X: execution policy with tid(), nt(), sync(), atomic_add(int *, int), uni(int).  Scratch (workgroup-shared): two task
+// arrays of 3 * task_cap entries (task_cap >= n / 17 + 1), `small` of 2 * (n / 2 + 1) entries (entry type I: int, or
+// uint16_t when n < 65536), cnt[3].  n > 16.
+// seeded_tasks >= 0: the caller has already split the largest ranges itself (e.g. with a workgroup-parallel partition):
+// cur[] holds that many pending ranges {first, last, depth budget}, small[] the cnt[2] final ranges found so far, and
+// cnt[0] == cnt[1] == 0.
+template <class X, class T, class C, class I>
+STLEMU_HD void sort_parallel(X &x, T *v, int n, C before, I *cur, I *nxt, I *small, int *cnt, int seeded_tasks = -1) {
+  const int tid = x.tid(), nt = x.nt();
+  int ntask = seeded_tasks;
+  if (seeded_tasks < 0) {
+    if (tid == 0) {
+      cnt[0] = 0; cnt[1] = 0; cnt[2] = 0;  // [0], [1]: pending ranges of the next round (by round parity), [2]: final ranges
+      cur[0] = (I)0; cur[1] = (I)n; cur[2] = (I)(2 * floor_lg(n));
+    }
+    x.sync();
+    ntask = 1;
+  }
+  for (int round = 0; ntask > 0; ++round) {
+    int *c_next = cnt + (round & 1);
+    for (int k = tid; k < ntask; k += nt) {
+      const int first = (int)cur[3 * k], last = (int)cur[3 * k + 1], depth = (int)cur[3 * k + 2];
+      if (depth == 0) {
+        heap_select(v, first, last, last, before);
+        heap_sort_down(v, first, last, before);
+        continue;
+      }
+      const int cut = split_with_median_pivot(v, first, last, before);
+      for (int side = 0; side < 2; ++side) {
+        const int a = side ? cut : first, e = side ? last : cut;
+        if (e - a > 16) {
+          const int i = x.atomic_add(c_next, 1);
+          nxt[3 * i] = (I)a; nxt[3 * i + 1] = (I)e; nxt[3 * i + 2] = (I)(depth - 1);
+        } else if (e - a > 1) {
+          const int i = x.atomic_add(cnt + 2, 1);
+          small[2 * i] = (I)a; small[2 * i + 1] = (I)e;
+        }
+      }
+    }
+    x.sync();
+    ntask = x.uni(*c_next);
+    if (tid == 0) cnt[(round + 1) & 1] = 0;  // the counter of the round after next; nobody reads it any more
+    I *t = cur; cur = nxt; nxt = t;
+    x.sync();
+  }
+  const int nsmall = x.uni(cnt[2]);
+  for (int k = tid; k < nsmall; k += nt) insertion_sort(v, (int)small[2 * k], (int)small[2 * k + 1], before);
+  x.sync();
+}
+
 // == std::partial_sort(v+first, v+middle, v+last, before)   (used by the tests to reach the heap code directly)
 template <class T, class C>
 STLEMU_HD void partial_sort(T *v, int first, int middle, int last, C before) {

@@ -142,9 +142,12 @@ int ctcd_stream_decode(ctcd_decoder *dec, ctcd_stream **states, const unsigned c
 /* Host check of the per-item status words written by the last ctcd_beam_decode (synchronises the device). */
 int ctcd_check_status(ctcd_decoder *dec, int B);
 
-/* Frames of the last ctcd_beam_decode whose vocabulary prune had to be decided by the host toolchain (equal values at
- * the cutoff_top_n boundary or among the kept ones -- the reference's order there is std::sort's -- or borderline
- * double roundings); 0 for the no-prune configurations. */
+/* Vocabulary prune bookkeeping of the last ctcd_beam_decode (0 for the no-prune configurations).  A frame in which equal
+ * values sit at the cutoff_top_n boundary or among the kept ones is ordered by whatever std::sort does with the whole
+ * row (decoder_utils.cpp:19-20): those frames are "flagged" by the prune pass and settled by a second device kernel that
+ * replays libstdc++'s std::sort exactly.  What reaches the HOST toolchain is only what depends on its libm: a borderline
+ * double rounding (prob -> log, the cumulative sum next to cutoff_prob), a NaN, or a row too long for the replay. */
+long long ctcd_last_prune_flagged_rows(ctcd_decoder *dec);
 long long ctcd_last_prune_host_rows(ctcd_decoder *dec);
 
 /* HIP-event timing of the decode kernel alone (events recorded on the launch stream). */
@@ -162,6 +165,9 @@ int ctcd_debug_get_profile(ctcd_decoder *dec, long long *out, int B);
 /* Test hook: 1 (default) = beams <= 128 over <= 32 labels run the kernel variant with a compile-time workspace layout,
  * 0 = always the run-time layout (identical results). */
 int ctcd_debug_set_fixed_layout(ctcd_decoder *dec, int on);
+/* Test hook: 1 (default) = flagged prune frames are settled by the device's std::sort replay, 0 = all of them go to the
+ * host toolchain (identical results). */
+int ctcd_debug_set_prune_resolve(ctcd_decoder *dec, int on);
 /* Tuning aid (instrumented build): per-wave shader-clock stamps at every workgroup barrier of batch item 0 during frames
  * [frame0, frame0 + nframes).  out == NULL arms the following decodes; out != NULL (int64 [16][ctcd_debug_timeline_cap()])
  * fetches the stamps, arrival and departure alternating, in program order (tools/barrier_timeline.py). */

@@ -115,6 +115,10 @@ PRUNED = [
     dict(B=2, T=50, V=40, K=12, seed=58, top_n=40, cutoff_prob=0.55, prob_input=True),
     dict(B=2, T=40, V=1000, K=10, seed=59, top_n=40, cutoff_prob=0.99, blank_bias=2.0),
     dict(B=3, T=50, V=64, K=8, seed=60, top_n=1),                          # blank may be pruned away entirely
+    dict(B=2, T=40, V=1000, K=10, seed=61, top_n=40, cutoff_prob=0.99, quant=0.25),  # configs[3] setting with tie-heavy frames
+    dict(B=2, T=40, V=200, K=10, seed=62, top_n=12, quant=1.0),            # (the wave-per-frame prune variant)
+    dict(B=2, T=40, V=300, K=10, seed=63, top_n=40, cutoff_prob=0.7, quant=0.5, prob_input=True),
+    dict(B=2, T=30, V=12, K=10, seed=64, top_n=5, quant=1.0),              # rows shorter than the introsort threshold
 ]
 
 
@@ -129,14 +133,21 @@ def test_vocabulary_pruning_against_oracle(torch_mod, c):
     want = ou.decode(x, which="restated", **kw)
     dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(c["V"])], cutoff_top_n=c["top_n"], cutoff_prob=c.get("cutoff_prob", 1.0),
                                        beam_width=c["K"], log_probs_input=not c.get("prob_input"))
-    out, sc, ts, ln = dec.decode(torch_mod.from_numpy(np.ascontiguousarray(x)))
-    got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
-    ou.assert_same(_with_nres(got, want), want)
-    host_rows = n.lib.ctcd_last_prune_host_rows(dec._handle)
-    if c.get("quant"):
-        assert host_rows > 0, "quantised inputs must exercise the host tie resolution"
-    elif not c.get("prob_input") and c.get("cutoff_prob", 1.0) == 1.0:
-        assert host_rows == 0
+    # frames whose order is std::sort's business (equal values at / above the cut) are flagged by the prune pass and then
+    # settled by the device's replay of std::sort; with the replay switched off the host toolchain decides them all
+    for device_replay in (True, False):
+        n.check(n.lib.ctcd_debug_set_prune_resolve(dec._handle, 1 if device_replay else 0))
+        out, sc, ts, ln = dec.decode(torch_mod.from_numpy(np.ascontiguousarray(x)))
+        got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+        ou.assert_same(_with_nres(got, want), want, "device replay %s" % device_replay)
+        flagged, host_rows = n.lib.ctcd_last_prune_flagged_rows(dec._handle), n.lib.ctcd_last_prune_host_rows(dec._handle)
+        assert host_rows <= flagged
+        if c.get("quant"):
+            assert flagged > 0, "quantised inputs must exercise the tie resolution"
+        if not device_replay:
+            assert host_rows == flagged
+        elif not c.get("prob_input") and c.get("cutoff_prob", 1.0) == 1.0:
+            assert host_rows == 0, "ties alone never reach the host"
 
 
 @pytest.mark.parametrize("threads", [128, 256, 1024])
@@ -232,7 +243,9 @@ def test_config4_shape_large_vocab(torch_mod):
     want = ou.decode(lp[sample], beam=K, cutoff_top_n=40, cutoff_prob=0.99, which=which, threads=os.cpu_count())
     ou.assert_same(_with_nres({k: v[sample] for k, v in got.items()}, want), want, "configs[3] sample vs " + which)
     assert (np.diff(got["scores"], axis=1) >= 0).all()
-    print("configs[3]: frames resolved on the host:", n.lib.ctcd_last_prune_host_rows(dec._handle), "of", B * T)
+    print("configs[3]: frames flagged / resolved on the host:", n.lib.ctcd_last_prune_flagged_rows(dec._handle),
+          n.lib.ctcd_last_prune_host_rows(dec._handle), "of", B * T)
+    assert n.lib.ctcd_last_prune_host_rows(dec._handle) == 0
 
 
 def test_edge_cases_on_gpu(torch_mod):
@@ -280,6 +293,10 @@ def test_host_pointer_entry_point(torch_mod):
     h = ctypes.c_void_p()
     n.check(n.lib.ctcd_create(ctypes.byref(h), 0))
     try:
+        n.check(n.lib.ctcd_beam_decode_host(h, lp.ctypes.data, None, B, T, V, K, 4, 1.0, 8, 0, 1,
+                                            tok.ctypes.data, ts.ctypes.data, sc.ctypes.data, ln.ctypes.data, nres.ctypes.data))
+        assert n.lib.ctcd_last_prune_flagged_rows(h) > 0 and n.lib.ctcd_last_prune_host_rows(h) == 0
+        n.check(n.lib.ctcd_debug_set_prune_resolve(h, 0))  # and with every flagged frame resolved on the host (own staging buffers)
         n.check(n.lib.ctcd_beam_decode_host(h, lp.ctypes.data, None, B, T, V, K, 4, 1.0, 8, 0, 1,
                                             tok.ctypes.data, ts.ctypes.data, sc.ctypes.data, ln.ctypes.data, nres.ctypes.data))
         assert n.lib.ctcd_last_prune_host_rows(h) > 0
@@ -490,3 +507,38 @@ def test_logits_input_prepass(torch_mod):
         # device-resident logits through the HBM-to-HBM entry as well
         d2 = dec.decode_device(torch.from_numpy(logits).cuda(), torch.from_numpy(sl).cuda())
         assert np.array_equal(d2[1].cpu().numpy().view(np.uint32), sc.numpy().view(np.uint32))
+
+
+def test_prune_tie_replay_patterns(torch_mod):
+    """Frames whose kept labels depend entirely on what std::sort does with equal values (the device replays libstdc++'s
+    introsort for them: workgroup-parallel Hoare partitions for the long ranges, stl_emul.h below that): constant rows,
+    sorted rows, few distinct values, long rows -- against the reference's real std::sort."""
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    which = "reference" if ou.have_reference() else "restated"
+    rng = np.random.default_rng(17)
+    for V, top_n in [(1000, 40), (5000, 40), (10000, 40), (260, 64), (40, 7)]:
+        T = 24
+        rows = np.empty((T, V), np.float32)
+        for t in range(T):
+            kind = t % 6
+            if kind == 0:
+                rows[t] = -3.0                                           # every value equal
+            elif kind == 1:
+                rows[t] = -np.arange(V, dtype=np.float32) // 7           # descending plateaus
+            elif kind == 2:
+                rows[t] = (np.arange(V, dtype=np.float32) // 5) - V      # ascending plateaus
+            elif kind == 3:
+                rows[t] = rng.integers(0, 3, V).astype(np.float32) - 4   # three distinct values
+            elif kind == 4:
+                rows[t] = np.where(np.arange(V) % 2 == 0, -1.0, -2.0)    # alternating
+            else:
+                rows[t] = np.round(rng.standard_normal(V) * 2) - 6       # quantised noise
+        lp = np.stack([rows, rows[::-1].copy()])
+        want = ou.decode(lp, beam=12, cutoff_top_n=top_n, which=which)
+        dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=top_n, beam_width=12, log_probs_input=True)
+        out, sc, ts, ln = dec.decode(torch_mod.from_numpy(lp))
+        got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+        ou.assert_same(_with_nres(got, want), want, "V=%d vs %s" % (V, which))
+        assert n.lib.ctcd_last_prune_flagged_rows(dec._handle) > 0 and n.lib.ctcd_last_prune_host_rows(dec._handle) == 0

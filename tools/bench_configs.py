@@ -27,6 +27,7 @@ def run(torch, ctcdecode_amd, name, B, T, V, K, top_n=40, cutoff_prob=1.0, blank
     r = {"name": name, "B": B, "T": T, "V": V, "beam": K, "cutoff_top_n": top_n, "cutoff_prob": cutoff_prob, "blank_bias": blank_bias,
          "ms_per_batch": round(dt * 1e3, 3), "decode_kernel_ms": round(dec.last_kernel_ms(), 3), "utt_per_s": round(B / dt, 1),
          "us_per_frame": round(dec.last_kernel_ms() * 1e3 / T, 3), "mean_top_len": float(res[3][:, 0].float().mean()),
+         "prune_flagged_rows": int(ctcdecode_amd._native.lib.ctcd_last_prune_flagged_rows(dec._handle)),
          "prune_host_rows": int(ctcdecode_amd._native.lib.ctcd_last_prune_host_rows(dec._handle))}
     print(json.dumps(r), flush=True)
     return r
