@@ -167,15 +167,15 @@ CTC_HD P *carve_ptr(char *&p, size_t count) {
 }
 
 // Lay the workspace out in `base` (LDS on the GPU).  Returns bytes used; call with base == nullptr to size it.
-// BIG: the arrays that only the rare paths touch per slot (info words, and the scratch of the exact replay) live in
+// BIG != 0: the arrays that only the rare paths touch per slot (info words, and the scratch of the exact replay) live in
 // `far` (HBM, per utterance) instead, so that wide beams still fit the 160 KiB of LDS; *far_bytes gets their size.
-// level (BIG only): 1 = the rare-path per-slot arrays in HBM; 2 = also the slot keys and the rarely read per-entry arrays
+// BIG == 1: the rare-path per-slot arrays in HBM; BIG == 2: also the slot keys and the rarely read per-entry arrays
 // (dead-interior bookkeeping, existing-child ranks): the widest beams, slowly.
-template <bool BIG>
-CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_bytes, int level = 1) {
+template <int BIG>
+CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_bytes) {
   char *p = base;
   char *q = BIG ? far : nullptr;
-  const bool deep = BIG && level >= 2;
+  constexpr bool deep = BIG >= 2;  // (a compile-time choice: every array keeps a static address space, LDS or global)
   const size_t K = (size_t)d.K, S = (size_t)d.S_max();
   const size_t Kr = ((K * 4 + 15) / 16) * 16;
   Beam *bs[2] = {&w.cur, &w.nxt};

@@ -428,7 +428,6 @@ struct KernelArgs {
   int tl_cap, tl_f0, tl_nf;
   char *far;                // BIG layout: per-utterance HBM scratch, far_stride bytes each
   long long far_stride;
-  int far_level;            // BIG layout: 1 or 2 (beam_core.h carve)
   // streaming (ctcd_stream_decode): per item, the HBM block that holds its parked beam + node pool
   char **st_base;           // [B] or null
   const int *st_poolcap;    // [B] nodes the pool of each stream can hold
@@ -453,7 +452,7 @@ __host__ __device__ constexpr Dims fixed_layout_dims(bool lm = false) { return D
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
 
 // PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
-template <int PROF, bool BIG, int LAYOUT, bool PRUNED, int NT = 0, bool LM = false>
+template <int PROF, int BIG, int LAYOUT, bool PRUNED, int NT = 0, bool LM = false>
 __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -461,8 +460,8 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   const int b = (int)blockIdx.x;
   if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
   Work w;
-  if (LAYOUT == 1) carve<false>(w, smem, nullptr, fixed_layout_dims(LM), nullptr);
-  else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr, a.far_level);
+  if (LAYOUT == 1) carve<0>(w, smem, nullptr, fixed_layout_dims(LM), nullptr);
+  else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
   __shared__ long long prof[16];
   __shared__ long long tlbuf[PROF == 2 ? 16 * kTimelineCap : 1];
   __shared__ int tlcnt[16];
@@ -470,7 +469,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   if (PROF == 2 && a.tl && b == 0)
     for (int i = threadIdx.x; i < 16 * kTimelineCap; i += blockDim.x) tlbuf[i] = 0;
   if (PROF == 1 && threadIdx.x < 16) prof[threadIdx.x] = 0;
-  DevX<PROF, BIG, NT> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
+  DevX<PROF, BIG != 0, NT> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
                     (PROF == 2 && b == 0 && a.tl) ? tlbuf : nullptr, tlcnt, kTimelineCap, a.tl_f0, a.tl_nf};
   int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
@@ -1488,7 +1487,7 @@ const char *ctcd_version(void) { return "ctcdecode_amd 0.1 (gfx950)"; }
 int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob) {
   if (beam <= 0 || V <= 0 || cutoff_top_n <= 0) return CTCD_EINVAL;
   Work w;
-  const size_t n = carve<false>(w, nullptr, nullptr, make_dims(beam, V, cutoff_top_n, cutoff_prob), nullptr);
+  const size_t n = carve<0>(w, nullptr, nullptr, make_dims(beam, V, cutoff_top_n, cutoff_prob), nullptr);
   return n > 0x7fffffffu ? 0x7fffffff : (int)n;
 }
 
@@ -1556,15 +1555,15 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   // (the LM tier has the fixed-layout kernel at 1024 threads only)
   const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout && (!scorer || threads == 1024);
   const Dims ldims = fixed ? fixed_layout_dims(scorer != nullptr) : dims;
-  size_t lds = carve<false>(wtmp, nullptr, nullptr, ldims, nullptr);
+  size_t lds = carve<0>(wtmp, nullptr, nullptr, ldims, nullptr);
   bool big = false;
   int far_level = 1;
   if (lds + 2048 > (size_t)d->max_lds) {  // wide beam: rare-path arrays go to HBM scratch
     big = true;
-    lds = carve<true>(wtmp, nullptr, nullptr, dims, &far_bytes, 1);
+    lds = carve<1>(wtmp, nullptr, nullptr, dims, &far_bytes);
     if (lds + 2048 > (size_t)d->max_lds) {  // wider still: the slot keys and the rarely read per-entry arrays follow them
       far_level = 2;
-      lds = carve<true>(wtmp, nullptr, nullptr, dims, &far_bytes, 2);
+      lds = carve<2>(wtmp, nullptr, nullptr, dims, &far_bytes);
     }
     far_bytes = (far_bytes + 255) / 256 * 256;
   }
@@ -1822,26 +1821,30 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if ((rc = d->prof.ensure((size_t)B * 16 * 8))) return rc;
     a.prof = (long long *)d->prof.p;
   }
-  a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes; a.far_level = far_level;
+  a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
   const bool pruned_mode = a.pr_cnt != nullptr;
   const void *fn;
 #define CTC_PICK(PROF_)                                                                                                  \
-  (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, true, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, true, 0, false>)    \
-       : fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, false, 1, true> : (const void *)ctc_beam_decode_kernel<PROF_, false, 1, false>) \
-               : (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, false, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, false, 0, false>))
+  (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, false>)    \
+       : fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 0, 1, true> : (const void *)ctc_beam_decode_kernel<PROF_, 0, 1, false>) \
+               : (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 0, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, 0, 0, false>))
   fn = d->profile ? CTC_PICK(1) : CTC_PICK(0);
+  if (big && far_level == 2) {  // the widest beams: their own instantiation (every workspace array keeps a static address space)
+    if (d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the widest-beam layout");
+    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false>;
+  }
   if (!d->profile && fixed && !big && threads == 1024)  // the usual case: workgroup size folded into the code
-    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<0, false, 1, false, 1024>;
+    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
   if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes only
     if (big || !fixed || pruned_mode) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels, no pruning");
     if (threads != 1024) return fail(CTCD_EUNSUPPORTED, "barrier timeline: 1024 threads per workgroup (the product configuration)");
-    fn = (const void *)ctc_beam_decode_kernel<2, false, 1, false, 1024>;
+    fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024>;
   }
 #undef CTC_PICK
   if (scorer) {
-    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, false, 0, false, 0, true>;
+    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 0, 0, false, 0, true>;
     if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
-      fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, false, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, false, 1, false, 1024, true>;
+      fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
   }
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));

@@ -220,7 +220,7 @@ extern "C" int ctccore_decode_compact_f32(const float *probs, const int32_t *seq
   d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0; d.lm = 0;
   Work w;
   size_t far_bytes = 0;
-  std::vector<char> mem(carve<false>(w, nullptr, nullptr, d, &far_bytes) + 64);
+  std::vector<char> mem(carve<0>(w, nullptr, nullptr, d, &far_bytes) + 64);
   std::vector<int32_t> hdr((size_t)B * 4, 0), ent((size_t)B * beam * 4, 0);
   std::vector<uint32_t> rag((size_t)B * beam * T + 1);
   unsigned count = 0;
@@ -229,7 +229,7 @@ extern "C" int ctccore_decode_compact_f32(const float *probs, const int32_t *seq
     std::vector<int> pool_up(pool.size());
     int len = seq_lens ? seq_lens[b] : T;
     len = std::max(0, std::min(len, T));
-    carve<false>(w, mem.data(), nullptr, d, nullptr);
+    carve<0>(w, mem.data(), nullptr, d, nullptr);
     HostX x;
     const OutRefs outs{nullptr, nullptr, out_scores, out_lens, n_results, beam, T, hdr.data(), ent.data(), rag.data(), &count, (unsigned)(rag.size() - 1)};
     int st = decode_utterance<true>(x, w, d, blank_id, probs + (size_t)b * T * V, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(),
@@ -270,7 +270,8 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
     size_t far_bytes = 0;
     const bool big = getenv("CTC_HOST_BIG") != nullptr;  // exercise the HBM-scratch layouts too (CTC_HOST_BIG=1 or 2)
     const int flevel = big && getenv("CTC_HOST_BIG")[0] == '2' ? 2 : 1;
-    std::vector<char> mem((big ? carve<true>(w, nullptr, nullptr, d, &far_bytes, flevel) : carve<false>(w, nullptr, nullptr, d, &far_bytes)) + 64);
+    std::vector<char> mem((!big ? carve<0>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
+                                                                                   : carve<1>(w, nullptr, nullptr, d, &far_bytes)) + 64);
     std::vector<char> far(far_bytes + 64);
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
     std::vector<int> pool_up(pool.size());
@@ -281,7 +282,9 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
       if (b >= B) return;
       int len = seq_lens ? seq_lens[b] : T;
       len = std::max(0, std::min(len, T));
-      if (big) carve<true>(w, mem.data(), far.data(), d, nullptr, flevel); else carve<false>(w, mem.data(), nullptr, d, nullptr);
+      if (!big) carve<0>(w, mem.data(), nullptr, d, nullptr);
+      else if (flevel == 2) carve<2>(w, mem.data(), far.data(), d, nullptr);
+      else carve<1>(w, mem.data(), far.data(), d, nullptr);
       HostX x;
       const float *rows = probs + (size_t)b * T * V;
       PrunedRows pr{pcnt.data(), pch.data(), plp.data(), d.Vc_max};
@@ -327,7 +330,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
   d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0; d.lm = 0;
   Work w;
   size_t far_bytes = 0;
-  std::vector<char> mem(carve<false>(w, nullptr, nullptr, d, &far_bytes) + 64);
+  std::vector<char> mem(carve<0>(w, nullptr, nullptr, d, &far_bytes) + 64);
   for (int b = 0; b < B; ++b) {
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
     std::vector<int> pool_up(pool.size());
@@ -336,7 +339,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       const int lo = bounds[c], hi = bounds[c + 1];
       // a fresh workspace every chunk, as a new kernel launch would have
       std::fill(mem.begin(), mem.end(), (char)0x5a);
-      carve<false>(w, mem.data(), nullptr, d, nullptr);
+      carve<0>(w, mem.data(), nullptr, d, nullptr);
       HostX x;
       StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u};
