@@ -1824,6 +1824,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
   const bool pruned_mode = a.pr_cnt != nullptr;
   const void *fn;
+#if defined(CTC_QUICK_BUILD)
+  // Experiment builds (tools/build_variants.sh, seconds instead of minutes): only the north-star class kernel and its
+  // barrier-timeline twin exist; everything else is refused.
+  if (big || !fixed || pruned_mode || scorer || threads != 1024 || (d->profile && !d->tl_armed))
+    return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD: only the fixed-layout, no-prune, no-LM, 1024-thread kernel was compiled");
+  fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
+#else
 #define CTC_PICK(PROF_)                                                                                                  \
   (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, false>)    \
        : fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 0, 1, true> : (const void *)ctc_beam_decode_kernel<PROF_, 0, 1, false>) \
@@ -1846,6 +1853,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
       fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
   }
+#endif
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
   void *kargs[] = {&a};
