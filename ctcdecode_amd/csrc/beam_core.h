@@ -151,7 +151,7 @@ struct Work {
   int *surv;       // 3K: slots of the survivors | their rank in slot (= DFS) order | inverse of that ranking
   uint64_t *ek;    // S_max: (key48 << 16 | slot) in DFS order, for the exact replay
   uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition
-  int *bins;       // kBins fine buckets, then kBins/16 coarse ones (each the sum of 16 fine buckets)
+  int *bins;       // kBins buckets of the select histogram (+ kBins/16 more words: with them, the task lists of the final sorts)
   uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
   int *lslot;      // kListCap: their slots
   uint32_t *bitmap;  // one bit per slot: survives (select fast path)
@@ -554,8 +554,8 @@ struct Decoder {
     if (key >= wd.lo) {
       const uint32_t bk = (key - wd.lo) >> wd.shift;
       const int bb = bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1;
-      x.atomic_add(&w.bins[bb], 1);
-      x.atomic_add(&w.bins[kBins + (bb >> 4)], 1);
+      x.atomic_add(&w.bins[bb], 1);  // (one LDS atomic per candidate: a second, coarse level of counters kept by atomics as
+                                     //  well cost 2.5 % of the frame -- many lanes hit the same few coarse words)
     }
   }
 
@@ -601,7 +601,7 @@ struct Decoder {
   CTC_HD bool select_kth(int S, int K, int *pv, const Window &wd) {
     const int tid = x.tid(), nt = x.nt();
     // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
-    //    [2] #keys in the window, [3] #keys in b*.  Two-level: the coarse buckets locate the group of 16 fine ones.
+    //    [2] #keys in the window, [3] #keys in b*.  Two-level: sums of 16 buckets locate the group, then the bucket.
     //    Ends with a barrier.  The histogram is cleared before another round; after the last one step() clears it
     //    (with the other per-frame resets, on waves that are idle while the next beam is emitted).
     x.find_bucket(w.bins, K, &w.vars[VAR_FB0]);
@@ -645,7 +645,7 @@ struct Decoder {
       }
       // another histogram round over [lo, hi)
       first = false;
-      for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
+      for (int i = tid; i < kBins; i += nt) w.bins[i] = 0;
       x.sync();  // the histogram has been cleared by every thread
       const uint64_t width = hi - lo;
       shift = width <= (uint64_t)kBins ? 0 : ceil_log2_u64(width) - kBinsLog;
@@ -656,7 +656,6 @@ struct Decoder {
           const uint32_t bk = dk >> shift;
           const int bb = bk < (uint32_t)(kBins - 1) ? (int)bk : kBins - 1;
           x.atomic_add(&w.bins[bb], 1);
-          x.atomic_add(&w.bins[kBins + (bb >> 4)], 1);
         }
       }
       x.sync();
@@ -1098,7 +1097,7 @@ struct Decoder {
         const bool spare = roles && nt > 3 * ne;
         if (!spare || tid >= 3 * ne) {
           const int t0 = spare ? tid - 3 * ne : tid, tstep = spare ? nt - 3 * ne : nt;
-          for (int i = t0; i < kBins + kBins / 16; i += tstep) w.bins[i] = 0;
+          for (int i = t0; i < kBins; i += tstep) w.bins[i] = 0;
           for (int i = t0; i < 2 * n; i += tstep) w.hit[i] = 0;
           int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;
           for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }

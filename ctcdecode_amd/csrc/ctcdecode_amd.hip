@@ -349,16 +349,18 @@ struct DevX {
     sync();
   }
 
-  // Histogram complete (caller synced): bins[0, 1024) fine buckets, bins[1024, 1088) coarse sums of 16.  Wave 0 finds the
-  // bucket holding the need-th largest key: a suffix scan over the 64 coarse buckets (one per lane) picks the group,
-  // a 16-lane suffix scan inside it picks the bucket.  Everyone gets out[0..3] = {bucket or -1, #keys above it, #keys
+  // Histogram complete (caller synced): bins[0, 1024).  Wave 0 finds the bucket holding the need-th largest key: every
+  // lane adds up 16 consecutive buckets, a suffix scan over those 64 sums picks the group, a 16-lane suffix scan inside
+  // it picks the bucket.  Everyone gets out[0..3] = {bucket or -1, #keys above it, #keys
   // total, #keys in it} after the closing barrier.
   __device__ __forceinline__ void find_bucket(const int *bins, int need, int *out) {
     if (threadIdx.x < 64) {
       __builtin_amdgcn_s_setprio(3);
       const int lane = (int)threadIdx.x;
       const int c = 63 - lane;  // lane 0 owns the TOP coarse bucket: a prefix scan over lanes is a suffix sum over buckets
-      const int cv = bins[ctcbeam::kBins + c];
+      const int4 *f4 = reinterpret_cast<const int4 *>(bins + 16 * c);  // its 16 fine buckets: four 128-bit reads, one round trip
+      const int4 q0 = f4[0], q1 = f4[1], q2 = f4[2], q3 = f4[3];
+      const int cv = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) + ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));
       const int incl = wave_scan(cv, 0, [](int a, int b) { return a + b; });
       const int total = __builtin_amdgcn_readlane(incl, 63);
       const unsigned long long m = __ballot(incl >= need);

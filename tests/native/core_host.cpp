@@ -59,7 +59,7 @@ struct HostX {
   void find_bucket(int *bins, int need, int *out) {
     using ctcbeam::kBins;
     int run = 0, bstar = -1, above = 0, inb = 0, total = 0;
-    for (int c = 0; c < kBins / 16; ++c) total += bins[kBins + c];
+    for (int b = 0; b < kBins; ++b) total += bins[b];
     for (int b = kBins - 1; b >= 0; --b) {
       const int v = bins[b];
       if (run + v >= need) { bstar = b; above = run; inb = v; break; }
