@@ -724,24 +724,24 @@ struct Decoder {
       if (tid == 0) stlemu::median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
       x.sync();
       // Hoare partition of [first+1, last) around v[first]: the t-th element from the left that is not better than
-      // the pivot is exchanged with the t-th from the right that is not worse, until the two scans cross.
+      // the pivot is exchanged with the t-th from the right that is not worse, until the two scans cross.  Every thread
+      // counts the stops of both kinds in its own stretch of the range; one prefix over the threads turns the counts
+      // into the stops' ranks.
       const int lo = first + 1, m = last - lo;
       const uint64_t kp = v[first] >> 16;
-      for (int i = tid; i <= m; i += nt) {
-        uint32_t f = 0;
-        if (i < m) {
-          const uint64_t k = v[lo + i] >> 16;
-          f = (k <= kp ? 1u : 0u) | (k >= kp ? 0x10000u : 0u);
-        }
-        w.pos[i] = f;
+      const int chunk = ceil_div_p2(m, nt), i0 = tid * chunk < m ? tid * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
+      uint32_t mine = 0;  // #left stops | #right stops << 16
+      for (int i = i0; i < i1; ++i) {
+        const uint64_t k = v[lo + i] >> 16;
+        mine += (k <= kp ? 1u : 0u) + (k >= kp ? 0x10000u : 0u);
       }
-      x.sync();
-      const uint32_t tot = x.scan_excl(w.pos, m + 1);
+      uint32_t run, tot;
+      x.block_scan_u32(mine, &run, &tot);
       const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
-      for (int i = tid; i < m; i += nt) {
-        const uint32_t p0 = w.pos[i], p1 = w.pos[i + 1];
-        if ((p1 ^ p0) & 0xFFFFu) Lp[p0 & 0xFFFFu] = (uint16_t)(lo + i);
-        if ((p1 ^ p0) >> 16) Rp[nR - 1 - (int)(p0 >> 16)] = (uint16_t)(lo + i);
+      for (int i = i0; i < i1; ++i) {
+        const uint64_t k = v[lo + i] >> 16;
+        if (k <= kp) { Lp[run & 0xFFFFu] = (uint16_t)(lo + i); run += 1u; }
+        if (k >= kp) { Rp[nR - 1 - (int)(run >> 16)] = (uint16_t)(lo + i); run += 0x10000u; }
       }
       if (tid == 0) Rp[nR] = (uint16_t)first;  // the pivot itself stops the right-to-left scan
       x.sync();
@@ -1044,12 +1044,13 @@ struct Decoder {
     // threshold; when the outcome depends on it, an exact replay of std::nth_element followed by a ranking by slot.
     const int n_new = N < K ? N : K;
     if (CTC_RARE(exact)) {
-      for (int s = tid; s <= S; s += nt) w.pos[s] = (s < S && info_type(w.sinfo[s]) != T_HOLE) ? 1u : 0u;
-      x.sync();
-      x.scan_excl(w.pos, S + 1);
-      for (int s = tid; s < S; s += nt)
-        if (w.pos[s + 1] != w.pos[s]) w.ek[w.pos[s]] = (slot_key48(s) << 16) | (uint64_t)s;
-      x.sync();
+      {  // the candidates in DFS (= slot) order: (48-bit key, slot) of every slot that is not a hole
+        const uint32_t *sinfo = w.sinfo;
+        const uint32_t *skey = w.skey;
+        uint64_t *ek = w.ek;
+        x.compact_slots_to(S, [=](int s) -> bool { return info_type(sinfo[s]) != T_HOLE; },
+                           [=](int r, int s) { ek[r] = (key48(skey[s], sinfo[s]) << 16) | (uint64_t)s; });
+      }
       replay_nth_element(N, K);
       for (int k = tid; k < K; k += nt) { rk[k] = 0; ord[k] = (int)(w.ek[k] & 0xFFFFu); }  // ord: nth_element order
       x.sync();

@@ -295,6 +295,11 @@ struct DevX {
   // no atomics, no sorting.  Starts and ends with a barrier-consistent state (caller synced before; syncs after).
   template <class Pred>
   __device__ __forceinline__ void compact_slots(int S, int *out, Pred pred) {
+    compact_slots_to(S, pred, [=](int r, int s) { out[r] = s; });
+  }
+  // ... the general form: emit(r, s) is called once for every slot s that passes, r = its rank among them
+  template <class Pred, class Emit>
+  __device__ __forceinline__ void compact_slots_to(int S, Pred pred, Emit emit) {
     const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
@@ -316,10 +321,10 @@ struct DevX {
       tot += CTC_DPP(0, tot, 0x114, 0xf); tot += CTC_DPP(0, tot, 0x118, 0xf);
       const int base = wave > 0 ? __builtin_amdgcn_readlane(tot, wave - 1) : 0;
 #define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
-      if (f0) out[base + CTC_BELOW(m0)] = s0;
-      if (f1) out[base + c0 + CTC_BELOW(m1)] = s1;
-      if (f2) out[base + c0 + c1 + CTC_BELOW(m2)] = s2;
-      if (f3) out[base + c0 + c1 + c2 + CTC_BELOW(m3)] = s3;
+      if (f0) emit(base + CTC_BELOW(m0), s0);
+      if (f1) emit(base + c0 + CTC_BELOW(m1), s1);
+      if (f2) emit(base + c0 + c1 + CTC_BELOW(m2), s2);
+      if (f3) emit(base + c0 + c1 + c2 + CTC_BELOW(m3), s3);
       sync();
       return;
     }
@@ -342,7 +347,7 @@ struct DevX {
       const int s = first + it * 64 + lane;
       const bool f = it < 64 ? ((flags >> it) & 1ull) != 0ull : (s < S && pred(s));
       const unsigned long long m = __ballot(f);
-      if (f) out[base + CTC_BELOW(m)] = s;
+      if (f) emit(base + CTC_BELOW(m), s);
       base += __popcll(m);
     }
 #undef CTC_BELOW
@@ -379,6 +384,23 @@ struct DevX {
       __builtin_amdgcn_s_setprio(0);
     }
     sync();
+  }
+
+  // Exclusive prefix (in thread order) and total of one 32-bit value per thread; contains one barrier.  (Used with two
+  // 16-bit counters packed into the word.)
+  __device__ __forceinline__ void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) {
+    const int t = (int)threadIdx.x, wave = t >> 6, nw = (nt() + 63) >> 6;
+    const uint32_t incl = (uint32_t)wave_scan((int)mine, 0, [](int a, int b) { return a + b; });
+    int *row = red + parity * 16;
+    parity ^= 1;
+    if ((t & 63) == 63) row[wave] = (int)incl;
+    sync();
+    uint32_t tot = (t & 63) < nw ? (uint32_t)row[t & 63] : 0u;
+    tot += (uint32_t)CTC_DPP(0, tot, 0x111, 0xf); tot += (uint32_t)CTC_DPP(0, tot, 0x112, 0xf);
+    tot += (uint32_t)CTC_DPP(0, tot, 0x114, 0xf); tot += (uint32_t)CTC_DPP(0, tot, 0x118, 0xf);
+    const uint32_t below = wave > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)tot, wave - 1) : 0u;
+    *base_out = below + incl - mine;
+    *total_out = (uint32_t)__builtin_amdgcn_readlane((int)tot, nw - 1);
   }
 
   // In-place exclusive prefix sum of a[0, n) in LDS; returns the total.  Each thread owns a contiguous chunk.

@@ -100,6 +100,13 @@ struct HostX {
     for (int s = 0; s < S; ++s)
       if (pred(s)) out[k++] = s;
   }
+  template <class Pred, class Emit>
+  void compact_slots_to(int S, Pred pred, Emit emit) {
+    int k = 0;
+    for (int s = 0; s < S; ++s)
+      if (pred(s)) emit(k++, s);
+  }
+  void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) { *base_out = 0; *total_out = mine; }
   void wave_max_to(int *p, uint32_t v) { *p = (int)std::max((uint32_t)*p, v); }
   void wave_min_to(int *p, uint32_t v) { *p = (int)std::min((uint32_t)*p, v); }
   unsigned global_add(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
