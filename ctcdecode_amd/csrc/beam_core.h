@@ -712,55 +712,86 @@ struct Decoder {
   }
 
   // ------------------------------------------------------------------------------------------------ exact replay
+  // One partition step of std::nth_element on v[first, last) (median of three to the front, unguarded Hoare partition of
+  // the rest: stl_emul.h split_with_median_pivot) by the whole workgroup.  Lp, Rp: scratch for last - first + 1 positions
+  // each.  Returns the cut.
+  CTC_HD int hoare_round(uint64_t *v, int first, int last, uint16_t *Lp, uint16_t *Rp) {
+    const int tid = x.tid(), nt = x.nt();
+    auto before = [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); };
+    if (tid == 0) stlemu::median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
+    x.sync();
+    // Hoare partition of [first+1, last) around v[first]: the t-th element from the left that is not better than the
+    // pivot is exchanged with the t-th from the right that is not worse, until the two scans cross.  Every thread counts
+    // the stops of both kinds in its own stretch of the range; one prefix over the threads turns the counts into the
+    // stops' ranks.
+    const int lo = first + 1, m = last - lo;
+    const uint64_t kp = v[first] >> 16;
+    const int chunk = ceil_div_p2(m, nt), i0 = tid * chunk < m ? tid * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
+    uint32_t mine = 0;  // #left stops | #right stops << 16
+    for (int i = i0; i < i1; ++i) {
+      const uint64_t k = v[lo + i] >> 16;
+      mine += (k <= kp ? 1u : 0u) + (k >= kp ? 0x10000u : 0u);
+    }
+    uint32_t run, tot;
+    x.block_scan_u32(mine, &run, &tot);
+    const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
+    for (int i = i0; i < i1; ++i) {
+      const uint64_t k = v[lo + i] >> 16;
+      if (k <= kp) { Lp[run & 0xFFFFu] = (uint16_t)(lo + i); run += 1u; }
+      if (k >= kp) { Rp[nR - 1 - (int)(run >> 16)] = (uint16_t)(lo + i); run += 0x10000u; }
+    }
+    if (tid == 0) Rp[nR] = (uint16_t)first;  // the pivot itself stops the right-to-left scan
+    x.sync();
+    // Iteration t of the serial loop stops its left scan at min(Lp[t], Rp[t-1]) (the element swapped into Rp[t-1]
+    // is itself a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
+    const int tmax = nL < nR + 1 ? nL : nR + 1;
+    auto crossed = [&](int t) { return t >= nL || t > nR || Lp[t] >= Rp[t]; };
+    for (int t = tid; t <= tmax; t += nt) {
+      if (!crossed(t)) {
+        stlemu::exch(v, (int)Lp[t], (int)Rp[t]);
+      } else if (t == 0 || !crossed(t - 1)) {
+        int c = t < nL ? (int)Lp[t] : kIntMax;
+        if (t > 0 && (int)Rp[t - 1] < c) c = Rp[t - 1];
+        w.vars[VAR_CUT] = c;
+      }
+    }
+    x.sync();
+    return x.uni(w.vars[VAR_CUT]);
+  }
+
   // std::nth_element(begin, begin+K, end, prefix_compare) on the DFS-ordered candidate list (w.ek[0, N)).
   CTC_HD void replay_nth_element(int N, int K) {
     const int tid = x.tid(), nt = x.nt();
     uint64_t *v = w.ek;
     auto before = [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); };
     int first = 0, last = N, depth = 2 * stlemu::floor_lg(N);
-    uint16_t *Lp = w.lr, *Rp = w.lr + N + 1;
-    while (last - first > kSerialCut && depth > 0) {
+    // Wide-beam layouts keep the candidate list in HBM: every barrier of a round then also waits for global memory.  Once
+    // the range is short enough it moves into the LDS block of the NEXT beam (nothing lives there until the emission),
+    // positions rebased to the range's start, and moves back when the selection is done.
+    const int stage_cap = x.far() ? (int)((w.beam_blk - 16) / 12) : 0;  // 8 B per element + two 16-bit position lists
+    while (last - first > kSerialCut && depth > 0 && last - first > stage_cap) {
       --depth;
-      if (tid == 0) stlemu::median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
-      x.sync();
-      // Hoare partition of [first+1, last) around v[first]: the t-th element from the left that is not better than
-      // the pivot is exchanged with the t-th from the right that is not worse, until the two scans cross.  Every thread
-      // counts the stops of both kinds in its own stretch of the range; one prefix over the threads turns the counts
-      // into the stops' ranks.
-      const int lo = first + 1, m = last - lo;
-      const uint64_t kp = v[first] >> 16;
-      const int chunk = ceil_div_p2(m, nt), i0 = tid * chunk < m ? tid * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
-      uint32_t mine = 0;  // #left stops | #right stops << 16
-      for (int i = i0; i < i1; ++i) {
-        const uint64_t k = v[lo + i] >> 16;
-        mine += (k <= kp ? 1u : 0u) + (k >= kp ? 0x10000u : 0u);
-      }
-      uint32_t run, tot;
-      x.block_scan_u32(mine, &run, &tot);
-      const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
-      for (int i = i0; i < i1; ++i) {
-        const uint64_t k = v[lo + i] >> 16;
-        if (k <= kp) { Lp[run & 0xFFFFu] = (uint16_t)(lo + i); run += 1u; }
-        if (k >= kp) { Rp[nR - 1 - (int)(run >> 16)] = (uint16_t)(lo + i); run += 0x10000u; }
-      }
-      if (tid == 0) Rp[nR] = (uint16_t)first;  // the pivot itself stops the right-to-left scan
-      x.sync();
-      // Iteration t of the serial loop stops its left scan at min(Lp[t], Rp[t-1]) (the element swapped into Rp[t-1]
-      // is itself a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
-      const int tmax = nL < nR + 1 ? nL : nR + 1;
-      auto crossed = [&](int t) { return t >= nL || t > nR || Lp[t] >= Rp[t]; };
-      for (int t = tid; t <= tmax; t += nt) {
-        if (!crossed(t)) {
-          stlemu::exch(v, (int)Lp[t], (int)Rp[t]);
-        } else if (t == 0 || !crossed(t - 1)) {
-          int c = t < nL ? (int)Lp[t] : kIntMax;
-          if (t > 0 && (int)Rp[t - 1] < c) c = Rp[t - 1];
-          w.vars[VAR_CUT] = c;
-        }
-      }
-      x.sync();
-      const int cut = x.uni(w.vars[VAR_CUT]);
+      const int cut = hoare_round(v, first, last, w.lr, w.lr + N + 1);
       if (cut <= K) first = cut; else last = cut;
+    }
+    if (x.far() && last - first > kSerialCut && depth > 0) {
+      const int m0 = last - first, base = first;
+      uint64_t *sv = reinterpret_cast<uint64_t *>(w.nxt.node);
+      uint16_t *sLp = reinterpret_cast<uint16_t *>(sv + m0), *sRp = sLp + m0 + 1;
+      for (int i = tid; i < m0; i += nt) sv[i] = v[base + i];
+      x.sync();
+      int f2 = 0, l2 = m0;
+      const int K2 = K - base;
+      while (l2 - f2 > kSerialCut && depth > 0) {
+        --depth;
+        const int cut = hoare_round(sv, f2, l2, sLp, sRp);
+        if (cut <= K2) f2 = cut; else l2 = cut;
+      }
+      if (tid == 0) stlemu::introselect(sv, f2, K2, l2, depth, before);
+      x.sync();
+      for (int i = tid; i < m0; i += nt) v[base + i] = sv[i];
+      x.sync();
+      return;
     }
     if (tid == 0) stlemu::introselect(v, first, K, last, depth, before);
     x.sync();

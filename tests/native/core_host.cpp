@@ -19,6 +19,8 @@
 namespace {
 
 struct HostX {
+  bool far_ = false;  // the workspace layout under test keeps the exact-replay arrays "far" (CTC_HOST_BIG)
+  bool far() const { return far_; }
   int tid() const { return 0; }
   int nt() const { return 1; }
   void sync() {}
@@ -293,6 +295,7 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
       else if (flevel == 2) carve<2>(w, mem.data(), far.data(), d, nullptr);
       else carve<1>(w, mem.data(), far.data(), d, nullptr);
       HostX x;
+      x.far_ = big;
       const float *rows = probs + (size_t)b * T * V;
       PrunedRows pr{pcnt.data(), pch.data(), plp.data(), d.Vc_max};
       if (pruned)
