@@ -1025,19 +1025,21 @@ struct WgSortX {
 };
 __host__ __device__ inline int prune_resolve_task_cap(int V) { return V / 17 + 2; }
 constexpr int kResolveBigCut = 256;    // ranges longer than this are split by the whole workgroup
+constexpr int kResolveThreads = 1024;  // (the row fills most of a CU's LDS: one workgroup per CU whatever its size)
 constexpr int kResolveMaxV = 65535;    // 16-bit positions and counters
 __host__ __device__ inline size_t prune_resolve_lds_bytes(int V, int n) {
   // pairs | Lp, Rp | two task lists | final ranges | stack of long ranges | counters | the kept labels
   return (size_t)V * 8 + (size_t)2 * (V + 2) * 2 + (size_t)6 * prune_resolve_task_cap(V) * 2 + (size_t)2 * (V / 2 + 1) * 2 + 3 * 64 * 4 + 64 +
          (size_t)n * 4 + 64;
 }
-// std::sort(v, v + V, before) by one workgroup, element for element.  Long ranges first, one at a time, each split by all
+// The first `limit` places of std::sort(v, v + V, before) by one workgroup, element for element (ranges of the introsort
+// that start beyond them are left alone: the prune pass keeps only the best top_n of a row).  Long ranges first, one at a time, each split by all
 // threads: the t-th element from the left that is not better than the pivot is exchanged with the t-th from the right that
 // is not worse, until the two scans cross (the exchanges of the serial Hoare loop, found with two prefix counts -- the
 // scheme of beam_core.h replay_nth_element); the ranges that remain (<= kResolveBigCut) go through stlemu::sort_parallel,
 // one thread per range and round.
 template <class C>
-__device__ void resolve_sort_like_std(unsigned long long *v, int V, C before, uint16_t *Lp, uint16_t *Rp, uint16_t *cur, uint16_t *nxt,
+__device__ void resolve_sort_like_std(unsigned long long *v, int V, int limit, C before, uint16_t *Lp, uint16_t *Rp, uint16_t *cur, uint16_t *nxt,
                                       uint16_t *small, int *cnt, int *bstack, uint32_t *wsum) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WgSortX x;
@@ -1070,7 +1072,7 @@ __device__ void resolve_sort_like_std(unsigned long long *v, int V, C before, ui
     __syncthreads();
     const int lo = first + 1, m = last - lo;
     const uint32_t kp = (uint32_t)(v[first] >> 32);
-    const int chunk = (m + 255) >> 8, i0 = min(tid * chunk, m), i1 = min(i0 + chunk, m);
+    const int chunk = (m + kResolveThreads - 1) / kResolveThreads, i0 = min(tid * chunk, m), i1 = min(i0 + chunk, m);
     uint32_t mine = 0;  // #left stops | #right stops << 16 in this thread's stretch
     for (int i = i0; i < i1; ++i) {
       const uint32_t k = (uint32_t)(v[lo + i] >> 32);
@@ -1085,7 +1087,7 @@ __device__ void resolve_sort_like_std(unsigned long long *v, int V, C before, ui
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint32_t base = 0, tot = 0;
-    for (int q = 0; q < 4; ++q) { const uint32_t t = wsum[q]; if (q < wave) base += t; tot += t; }
+    for (int q = 0; q < kResolveThreads / 64; ++q) { const uint32_t t = wsum[q]; if (q < wave) base += t; tot += t; }
     const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
     uint32_t run = base + incl - mine;
     for (int i = i0; i < i1; ++i) {
@@ -1099,7 +1101,7 @@ __device__ void resolve_sort_like_std(unsigned long long *v, int V, C before, ui
     // itself a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
     const int tmax = nL < nR + 1 ? nL : nR + 1;
     auto crossed = [&](int t) { return t >= nL || t > nR || Lp[t] >= Rp[t]; };
-    for (int t = tid; t <= tmax; t += 256) {
+    for (int t = tid; t <= tmax; t += kResolveThreads) {
       if (!crossed(t)) {
         stlemu::exch(v, (int)Lp[t], (int)Rp[t]);
       } else if (t == 0 || !crossed(t - 1)) {
@@ -1112,6 +1114,7 @@ __device__ void resolve_sort_like_std(unsigned long long *v, int V, C before, ui
     const int cut = cnt[3];
     for (int side = 0; side < 2; ++side) {
       const int a = side ? cut : first, e = side ? last : cut;
+      if (a >= limit) continue;  // only the first `limit` places of the sorted row are read (stl_emul.h sort_parallel)
       if (e - a > 16) {
         if (tid == 0) { bstack[3 * sp] = a; bstack[3 * sp + 1] = e; bstack[3 * sp + 2] = depth; }
         ++sp;
@@ -1124,13 +1127,13 @@ __device__ void resolve_sort_like_std(unsigned long long *v, int V, C before, ui
   }
   if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[2] = nsmall; }
   __syncthreads();
-  stlemu::sort_parallel(x, v, V, before, cur, nxt, small, cnt, ntask);
+  stlemu::sort_parallel(x, v, V, before, cur, nxt, small, cnt, ntask, limit);
 }
 
-__global__ void __launch_bounds__(256) prune_resolve_kernel(PruneArgs a, unsigned *n_host, unsigned *host_rows) {
+__global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArgs a, unsigned *n_host, unsigned *host_rows) {
   extern __shared__ __attribute__((aligned(16))) char rsm[];
   __shared__ int s_bad;
-  __shared__ uint32_t s_wsum[4];
+  __shared__ uint32_t s_wsum[kResolveThreads / 64];
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int V = a.V, n = a.top_n < V ? a.top_n : V;
   const int tcap = prune_resolve_task_cap(V);
@@ -1145,7 +1148,7 @@ __global__ void __launch_bounds__(256) prune_resolve_kernel(PruneArgs a, unsigne
     if (tid == 0) s_bad = 0;
     __syncthreads();
     bool nan = false;
-    for (int i = tid; i < V; i += 256) {
+    for (int i = tid; i < V; i += kResolveThreads) {
       const float f = row[i];
       nan |= f != f;
       v[i] = ((unsigned long long)prune_key(f) << 32) | (unsigned)i;
@@ -1154,8 +1157,8 @@ __global__ void __launch_bounds__(256) prune_resolve_kernel(PruneArgs a, unsigne
     __syncthreads();
     if (!s_bad) {
       // decoder_utils.cpp:19-20: (index, double) pairs in index order, std::sort on the value alone, descending
-      resolve_sort_like_std(v, V, [](unsigned long long p, unsigned long long q) { return (uint32_t)(p >> 32) > (uint32_t)(q >> 32); }, Lp, Rp, cur,
-                            nxt, small, cnt, bstack, s_wsum);
+      resolve_sort_like_std(v, V, n, [](unsigned long long p, unsigned long long q) { return (uint32_t)(p >> 32) > (uint32_t)(q >> 32); }, Lp, Rp,
+                            cur, nxt, small, cnt, bstack, s_wsum);
       if (tid < 64) {
         bool flag = false;
         int *och = a.ch + (size_t)r * a.stride;
@@ -1709,7 +1712,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       if (d->timing) { HIP_TRY(hipEventRecord(d->ev3, stream)); d->prune_timed = true; }
       // flagged frames whose outcome only depends on std::sort's treatment of equal values are settled on the device
       if (resolve_on_device) {
-        hipLaunchKernelGGL(prune_resolve_kernel, dim3(256), dim3(256), rlds, stream, pa, n_flag + 1, host_rows);
+        hipLaunchKernelGGL(prune_resolve_kernel, dim3(256), dim3(kResolveThreads), rlds, stream, pa, n_flag + 1, host_rows);
         HIP_TRY(hipGetLastError());
       }
       unsigned both[2] = {0, 0};

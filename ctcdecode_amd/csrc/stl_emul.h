@@ -247,8 +247,12 @@ STLEMU_HD void sort(T *v, int first, int last, C before, int *stack) {
 // seeded_tasks >= 0: the caller has already split the largest ranges itself (e.g. with a workgroup-parallel partition):
 // cur[] holds that many pending ranges {first, last, depth budget}, small[] the cnt[2] final ranges found so far, and
 // cnt[0] == cnt[1] == 0.
+// limit: only the first `limit` positions of the sorted array are wanted (a prefix of std::sort's result, not a
+// std::partial_sort): sub-ranges are disjoint once split and the closing insertion sort never moves an element across a
+// split point, so a range that starts at or beyond `limit` can be left as it is.
 template <class X, class T, class C, class I>
-STLEMU_HD void sort_parallel(X &x, T *v, int n, C before, I *cur, I *nxt, I *small, int *cnt, int seeded_tasks = -1) {
+STLEMU_HD void sort_parallel(X &x, T *v, int n, C before, I *cur, I *nxt, I *small, int *cnt, int seeded_tasks = -1,
+                             int limit = 0x7fffffff) {
   const int tid = x.tid(), nt = x.nt();
   int ntask = seeded_tasks;
   if (seeded_tasks < 0) {
@@ -271,6 +275,7 @@ STLEMU_HD void sort_parallel(X &x, T *v, int n, C before, I *cur, I *nxt, I *sma
       const int cut = split_with_median_pivot(v, first, last, before);
       for (int side = 0; side < 2; ++side) {
         const int a = side ? cut : first, e = side ? last : cut;
+        if (a >= limit) continue;  // (only v[0, limit) is wanted: a range that starts beyond it never influences it)
         if (e - a > 16) {
           const int i = x.atomic_add(c_next, 1);
           nxt[3 * i] = (I)a; nxt[3 * i + 1] = (I)e; nxt[3 * i + 2] = (I)(depth - 1);
