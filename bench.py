@@ -125,6 +125,29 @@ def time_e2e(torch, dec, lp_cpu, reps=5, warm=2):
     return ts[len(ts) // 2]
 
 
+def time_pipelined(torch, ctcdecode_amd, dev, lp, labels, V, K, inflight=2, steps=24, warm=6):
+    """The same batches with `inflight` launches in flight (one decoder + stream each): the kernel time of a launch is set by
+    its slowest utterance (ties at the beam boundary cost an exact std::nth_element replay), so a lone launch leaves CUs
+    idle towards its end; the next launch's workgroups fill them.  An extra, not the headline: `value` times launches
+    one at a time, which is what its roofline duration and the rocprofv3 summary describe."""
+    decs = [ctcdecode_amd.CTCBeamDecoder(labels, cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev) for _ in range(inflight)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)]
+
+    def run(n):
+        for i in range(n):
+            with torch.cuda.stream(streams[i % inflight]):
+                decs[i % inflight].decode_device(lp, None, check=False)
+        torch.cuda.synchronize()
+
+    run(warm)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    for d in decs:
+        ctcdecode_amd._native.check(ctcdecode_amd._native.lib.ctcd_check_status(d._handle, lp.shape[0]))
+    return dt
+
+
 def other_configs(torch, ctcdecode_amd, dev):
     """Kernel time of the other BASELINE.json configurations' per-GPU shapes (not bench lines: one or two launches each)."""
     out = {}
@@ -310,6 +333,12 @@ def main():
             e2e = time_e2e(torch, dec, lp_cpu)
             line["e2e"] = {"what": "drop-in decode(): CPU float32 tensor in, four CPU tensors out (SURVEY 8(d) primary definition)",
                            "ms_per_batch": round(e2e * 1e3, 3), "value": round(B / e2e, 1), "unit": "utterances/s"}
+            try:
+                pl = time_pipelined(torch, ctcdecode_amd, dev, lp, [str(i) for i in range(V)], V, K)
+                line["pipelined"] = {"what": "the same batches with 2 launches in flight on 2 streams (a serving loop; not the headline: see DESIGN.md 6)",
+                                     "launches_in_flight": 2, "ms_per_batch": round(pl * 1e3, 3), "value": round(B / pl, 1), "unit": "utterances/s"}
+            except Exception as e:
+                line["pipelined"] = {"error": str(e)[:200]}
             try:
                 line["other_configs"] = other_configs(torch, ctcdecode_amd, dev)
             except Exception as e:
