@@ -488,14 +488,15 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   if (LAYOUT == 1) carve<0>(w, smem, nullptr, fixed_layout_dims(LM), nullptr);
   else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
   __shared__ long long prof[16];
-  __shared__ long long tlbuf[PROF == 2 ? 16 * kTimelineCap : 1];
+  constexpr int kTlCap = LM ? kTimelineCap / 2 : kTimelineCap;  // (the LM tier's workspace leaves 8 KB for the stamps)
+  __shared__ long long tlbuf[PROF == 2 ? 16 * kTlCap : 1];
   __shared__ int tlcnt[16];
-  if (PROF == 2 && threadIdx.x < 16) tlcnt[threadIdx.x] = kTimelineCap;
+  if (PROF == 2 && threadIdx.x < 16) tlcnt[threadIdx.x] = kTlCap;
   if (PROF == 2 && a.tl && b == 0)
-    for (int i = threadIdx.x; i < 16 * kTimelineCap; i += blockDim.x) tlbuf[i] = 0;
+    for (int i = threadIdx.x; i < 16 * kTlCap; i += blockDim.x) tlbuf[i] = 0;
   if (PROF == 1 && threadIdx.x < 16) prof[threadIdx.x] = 0;
   DevX<PROF, BIG != 0, NT> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
-                    (PROF == 2 && b == 0 && a.tl) ? tlbuf : nullptr, tlcnt, kTimelineCap, a.tl_f0, a.tl_nf};
+                    (PROF == 2 && b == 0 && a.tl) ? tlbuf : nullptr, tlcnt, kTlCap, a.tl_f0, a.tl_nf};
   int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();
@@ -538,7 +539,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   if (threadIdx.x == 0) a.status[b] = st;
   if (PROF == 2 && a.tl && b == 0) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 16 * kTimelineCap; i += blockDim.x) a.tl[i] = tlbuf[i];
+    for (int i = threadIdx.x; i < 16 * kTlCap; i += blockDim.x) a.tl[i] = tlbuf[i];  // (LM build: [16][kTimelineCap / 2])
   }
   if (PROF == 1 && threadIdx.x < 16) a.prof[(size_t)b * 16 + threadIdx.x] = prof[threadIdx.x];
 }
@@ -1598,7 +1599,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (lds + 2048 > (size_t)d->max_lds)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) needs " + std::to_string(lds) + " B of LDS, more than one workgroup has");
   if (big && scorer) return fail(CTCD_EUNSUPPORTED, "the LM tier does not fit this beam width / vocabulary in LDS yet");
-  if (scorer && d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the LM tier");
+  if (scorer && d->profile && !d->tl_armed) return fail(CTCD_EUNSUPPORTED, "the phase-timer kernel builds do not include the LM tier (the barrier timeline does)");
   if (big && (rc = d->far.ensure((size_t)B * far_bytes))) return rc;
 
   // outputs: everything outside the valid region is defined as 0
@@ -1880,6 +1881,10 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 0, 0, false, 0, true>;
     if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
       fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
+    if (d->profile && d->tl_armed) {  // (shape conditions checked above)
+      if (!fixed) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels");
+      fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true>;
+    }
   }
 #endif
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

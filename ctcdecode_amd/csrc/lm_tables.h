@@ -78,7 +78,14 @@ CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *
   float prob = 0.f;
   uint32_t nx = 0;
   bool hit = false;
+  // Every table word that MAY be needed is requested before anything is waited for: the unigram fall-back (it depends on the
+  // word alone) here, a level's back-off weight and failure link together with its first probe below -- on the GPU each
+  // dependent global access is a round trip of more than a thousand clocks on the critical path of a frame.
+  const float uni_p = L.uni_prob[word];
+  const uint32_t uni_s = L.uni_state[word];
   while (q != 0 && !hit) {
+    const float bo_q = L.st_bo[q];
+    const uint32_t fail_q = L.st_fail[q];
     uint32_t h = ng_hash(q, word) & L.ng_mask;
     for (;;) {
       const NgSlot s = L.ng[h];
@@ -94,13 +101,13 @@ CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *
       h = (h + 1) & L.ng_mask;
     }
     if (!hit) {
-      if (nb < kMaxOrder) bos[nb++] = L.st_bo[q];
-      q = L.st_fail[q];
+      if (nb < kMaxOrder) bos[nb++] = bo_q;
+      q = fail_q;
     }
   }
   if (!hit) {
-    prob = L.uni_prob[word];
-    nx = L.uni_state[word];
+    prob = uni_p;
+    nx = uni_s;
   }
   float r = prob;
   for (int i = nb - 1; i >= 0; --i) r += bos[i];  // float32, from the shorter context to the longer (lm/model.cc)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--frame0", type=int, default=500)
     ap.add_argument("--frames", type=int, default=6)
     ap.add_argument("--out", default="")
+    ap.add_argument("--lm", default="", help="ARPA model: time the LM tier's kernel (labels _ ' space a..z)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -41,7 +42,12 @@ def main():
 
     g = torch.Generator(device="cpu").manual_seed(1234)
     lp = torch.randn((a.batch, a.T, a.V), generator=g).log_softmax(-1).cuda()
-    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(a.V)], cutoff_top_n=a.V, beam_width=a.beam, log_probs_input=True)
+    labels = [str(i) for i in range(a.V)]
+    kw = {}
+    if a.lm:
+        labels = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
+        kw = dict(model_path=a.lm, alpha=0.5, beta=1.0)
+    dec = ctcdecode_amd.CTCBeamDecoder(labels, cutoff_top_n=a.V, beam_width=a.beam, log_probs_input=True, **kw)
     if a.threads:
         dec.set_threads(a.threads)
     dec.set_timing(True)
@@ -55,6 +61,9 @@ def main():
     cap = _native.lib.ctcd_debug_timeline_cap()
     buf = np.zeros((16, cap), np.int64)
     _native.check(_native.lib.ctcd_debug_timeline(dec._handle, 0, 0, buf.ctypes.data_as(ctypes.c_void_p)))
+    if a.lm:  # the LM build of the timeline kernel records half as many stamps per wave
+        cap //= 2
+        buf = buf.reshape(-1)[:16 * cap].reshape(16, cap)
     nw = int((buf[:, 0] != 0).sum())
     n = int((buf[0] != 0).sum())
     per = n // a.frames
