@@ -542,3 +542,24 @@ def test_prune_tie_replay_patterns(torch_mod):
         got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
         ou.assert_same(_with_nres(got, want), want, "V=%d vs %s" % (V, which))
         assert n.lib.ctcd_last_prune_flagged_rows(dec._handle) > 0 and n.lib.ctcd_last_prune_host_rows(dec._handle) == 0
+
+
+def test_streaming_with_logits_input(torch_mod):
+    """The raw-logit pre-pass is per frame, so chunked feeding through the streaming API gives the one-shot result."""
+    import ctcdecode_amd
+
+    rng = np.random.default_rng(23)
+    B, T, V, K = 3, 90, 29, 40
+    logits = (rng.standard_normal((B, T, V)) * 2).astype(np.float32)
+    want = ou.decode(ou.log_softmax_rows(logits), beam=K)
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], beam_width=K, logits_input=True)
+    states = [ctcdecode_amd.DecoderState(dec) for _ in range(B)]
+    x = torch_mod.from_numpy(logits)
+    bounds = [0, 1, 40, 40, 77, T]
+    for i in range(len(bounds) - 1):
+        out, sc, ts, ln = dec.decode(x[:, bounds[i]:bounds[i + 1]], states, [i == len(bounds) - 2] * B)
+    L = out.shape[2]
+    got = dict(tokens=np.zeros((B, K, T), np.int32), timesteps=np.zeros((B, K, T), np.int32), scores=sc.numpy(), lens=ln.numpy(), nres=want["nres"])
+    got["tokens"][:, : out.shape[1], :L] = out.numpy()
+    got["timesteps"][:, : out.shape[1], :L] = ts.numpy()
+    ou.assert_same(got, want, "chunked logits")
