@@ -226,7 +226,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            # (no device_id=: binding the group to the device at init makes every collective wait for ALL work queued on
+            #  the device -- the next batch's decode kernel included -- instead of for its own stream only)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -240,15 +242,43 @@ def main():
     dec.set_timing(True)
 
     gatherer = None
+    compact = use_dist and a.gather != "none" and a.gather_format == "compact"
+    # N > 1, device backend, overlapped compact gather: the host looks at batch i (status words, label count, the gather's
+    # bookkeeping; on rank 0 the expansion) only AFTER batch i+1's kernel is queued, and the collectives run on a side
+    # stream behind batch i's own event -- the kernels still run one after another on one stream, as at N = 1, but the
+    # GPU never waits for the host.  Two decoder objects alternate (a decoder's workspace and compact buffers belong to
+    # the batch in flight).
+    lookahead = compact and a.gather == "overlap" and backend != "gloo"
     if use_dist and a.gather != "none":
         from ctcdecode_amd.distributed import make_gatherer
 
-        gatherer = make_gatherer(a.gather_format, B, K, T, V, dev, dst=0, depth=2, decoder=dec)
-    compact = gatherer is not None and a.gather_format == "compact"
+        gatherer = make_gatherer(a.gather_format, B, K, T, V, dev, dst=0, depth=2, decoder=dec,
+                                 stream=torch.cuda.Stream(device=dev) if lookahead else None)
+    decs = [dec]
+    if lookahead:
+        dec2 = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=V, beam_width=K, blank_id=0, log_probs_input=True, device=dev)
+        if a.threads:
+            dec2.set_threads(a.threads)
+        decs.append(dec2)
+    pending = []  # [(decoder, ticket)] of the batch whose kernel is queued but whose results the host has not handled yet
+    nlaunch = [0]
+
+    def handle_pending():
+        while pending:
+            d, ticket = pending.pop(0)
+            gatherer.submit(d.finish_compact(ticket), ready=ticket["event"])
 
     def step():
         # N > 1 with the compact gather: a rank produces its results in compact form (nothing padded is written on it);
         # rank 0 rebuilds the padded tensors of ALL ranks in its HBM.  N = 1: the padded tensors are written by the decode.
+        if lookahead:
+            gatherer.wait()  # (the gathers of two batches ago read this decoder's buffers: long finished, now confirmed)
+            d = decs[nlaunch[0] % 2]
+            nlaunch[0] += 1
+            ticket = d.decode_compact_async(lp, None)
+            handle_pending()
+            pending.append((d, ticket))
+            return None
         res = dec.decode_compact(lp, None) if compact else dec.decode_device(lp, None, check=False)
         if gatherer is not None:
             gatherer.submit(res)
@@ -258,10 +288,11 @@ def main():
 
     def fence():
         if gatherer is not None:
+            handle_pending()
             gatherer.wait()  # every submitted gather has completed (part of the timed work)
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            dist.barrier(device_ids=[dev.index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -347,7 +378,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(lp_cpu.numpy(), K, a.cpu_seconds)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
-        dist.barrier()
+        dist.barrier(device_ids=[dev.index]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -226,6 +226,55 @@ class CTCBeamDecoder(object):
             n = int(cnt.item())
         return hdr, ent, self._c_labels[:n], scores, out_len
 
+    def decode_compact_async(self, probs, seq_lens=None):
+        """``decode_compact`` without waiting: the kernel, then the copies of the status words and of the label count into
+        page-locked memory, are enqueued on the current stream and an event is recorded behind them.  Returns a ticket for
+        ``finish_compact``; the caller may queue the NEXT batch (on another decoder object: this one's workspace is in use)
+        before looking at this one -- how a serving loop keeps the GPU busy while the host handles the previous results."""
+        if probs.dim() != 3:
+            raise ValueError("probs must be [batch, time, labels]")
+        probs = probs.to(device=self._device, dtype=torch.float32).contiguous()
+        B, T, V = probs.shape
+        if V != self._num_labels:
+            raise ValueError("probs.shape[2] (%d) does not match the number of labels (%d)" % (V, self._num_labels))
+        if seq_lens is not None:
+            seq_lens = seq_lens.to(device=self._device, dtype=torch.int32).contiguous()
+        K = self._beam_width
+        cap = int(_native.lib.ctcd_compact_label_capacity(B, K, T))
+        with torch.cuda.device(self._device):
+            if getattr(self, "_c_labels", None) is None or self._c_labels.numel() < max(cap, 1):
+                self._c_labels = torch.empty((max(cap, 1),), dtype=torch.int32, device=self._device)  # worst case, reused
+            hdr = torch.empty((B, 4), dtype=torch.int32, device=self._device)
+            ent = torch.empty((B, K, 4), dtype=torch.int32, device=self._device)
+            cnt = torch.empty((1,), dtype=torch.int32, device=self._device)
+            scores = torch.empty((B, K), dtype=torch.float32, device=self._device)
+            out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
+            stream = torch.cuda.current_stream(self._device)
+            _native.check(_native.lib.ctcd_beam_decode_compact(
+                self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K, self._num_processes,
+                float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
+                self._scorer.handle if self._scorer is not None else None, hdr.data_ptr(), ent.data_ptr(), self._c_labels.data_ptr(),
+                cnt.data_ptr(), cap, scores.data_ptr(), out_len.data_ptr(), None, stream.cuda_stream))
+            status = torch.empty((max(B, 1),), dtype=torch.int32, pin_memory=True)
+            cnt_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+            _native.check(_native.lib.ctcd_fetch_status_async(self._handle, B, status.data_ptr(), stream.cuda_stream))
+            cnt_host.copy_(cnt, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return dict(B=B, hdr=hdr, ent=ent, labels=self._c_labels, cnt=cnt, scores=scores, lens=out_len, status=status, cnt_host=cnt_host,
+                    event=ev, keep=(probs, seq_lens))
+
+    def finish_compact(self, ticket):
+        """Waits for a ``decode_compact_async`` batch (its own event only, not the stream) and returns what ``decode_compact``
+        returns: (c_hdr, c_ent, c_labels[:n], scores, out_lens)."""
+        ticket["event"].synchronize()
+        st = ticket["status"][:ticket["B"]]
+        if ticket["B"] and bool((st != 0).any()):
+            b = int((st != 0).nonzero()[0])
+            raise _native.NativeError("ctcdecode_amd: decoder status %d for item %d" % (int(st[b]), b))
+        n = int(ticket["cnt_host"][0])
+        return ticket["hdr"], ticket["ent"], ticket["labels"][:n], ticket["scores"], ticket["lens"]
+
     def expand_compact(self, hdr, ent, labels, T):
         """(c_hdr, c_ent, c_labels) of any number of items -> (output [B,K,T], timesteps [B,K,T]) in HBM."""
         B, K = int(ent.shape[0]), int(ent.shape[1])

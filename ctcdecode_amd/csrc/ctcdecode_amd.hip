@@ -2330,6 +2330,19 @@ long long ctcd_last_prune_host_rows(ctcd_decoder *d) { return d ? d->prune_host_
 // ... and the number the prune pass flagged in the first place (the rest were settled by the device's std::sort replay).
 long long ctcd_last_prune_flagged_rows(ctcd_decoder *d) { return d ? d->prune_flagged_rows : -1; }
 
+// The same words, fetched without blocking: the copy into `host_status` (B words, page-locked memory for a truly
+// asynchronous copy) is enqueued on `stream` -- pass the stream the decode was launched on, before enqueuing anything else
+// there -- and the caller waits for its own event; 0 = ST_OK for an item, anything else is a failure code.  A pipelined
+// caller (the next batch's kernel already queued behind) inspects a batch's outcome this way without draining the stream.
+int ctcd_fetch_status_async(ctcd_decoder *d, int B, int32_t *host_status, void *stream_) {
+  if (!d || B < 0 || (B > 0 && !host_status)) return fail(CTCD_EINVAL, "bad arguments");
+  if (B == 0) return CTCD_OK;
+  CTC_ON_DEVICE(d->device);
+  if (!d->status.p || d->status.cap < (size_t)B * 4) return fail(CTCD_EINVAL, "no decode of that many items has been launched");
+  HIP_TRY(hipMemcpyAsync(host_status, d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+  return CTCD_OK;
+}
+
 // Status words of the last ctcd_beam_decode on this decoder (device -> host); for callers of the async entry point.
 int ctcd_check_status(ctcd_decoder *d, int B) {
   if (!d || B < 0) return fail(CTCD_EINVAL, "bad arguments");

@@ -111,7 +111,7 @@ class CompactGatherer(object):
     launches them asynchronously; ``wait`` drains and, on ``dst``, leaves the expanded tensors of the last batch in
     ``self.last`` = (output, scores, timesteps, out_lens)."""
 
-    def __init__(self, decoder, T, dst=0, group=None, depth=2):
+    def __init__(self, decoder, T, dst=0, group=None, depth=2, stream=None):
         self.dec, self.T, self.dst, self.group = decoder, T, dst, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -119,14 +119,36 @@ class CompactGatherer(object):
         self._host_only = dist.get_backend(group) == "gloo"
         self._inflight = []
         self.last = None
+        # Optional side stream (device backends): the collectives, and on ``dst`` the expansion kernel, are issued there
+        # behind the event of the batch they belong to, so they neither wait for nor delay the NEXT batch's decode kernel,
+        # which the caller has already queued on its own stream.
+        self.stream = None if self._host_only else stream
+
+    def _on_stream(self):
+        import contextlib
+
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def _xfer(self, t):
         return t.cpu() if self._host_only and t.is_cuda else t
 
-    def submit(self, compact):
+    def submit(self, compact, ready=None):
+        """``ready``: event recorded behind the batch's decode (``decode_compact_async``); with a side stream the gather
+        waits for that event instead of for everything queued on the caller's stream."""
+        with self._on_stream():
+            if self.stream is not None:
+                if ready is not None:
+                    self.stream.wait_event(ready)
+                else:
+                    self.stream.wait_stream(torch.cuda.current_stream(compact[0].device))
+                for t in compact:
+                    t.record_stream(self.stream)
+            self._submit(compact)
+
+    def _submit(self, compact):
         hdr, ent, labels, scores, lens = compact
         while len(self._inflight) >= self.depth:
-            self._finish(self._inflight.pop(0))
+            self._finish_one(self._inflight.pop(0))
         dev = hdr.device
         # the label buffers differ in length: agree on the longest (one all_reduce of a single word), pad, gather
         nmax = torch.tensor([labels.numel()], dtype=torch.int64, device="cpu" if self._host_only else dev)
@@ -144,6 +166,10 @@ class CompactGatherer(object):
         self._inflight.append((works, recv if self.rank == self.dst else send, dev))  # (sources stay alive until the gather is done)
 
     def _finish(self, item):
+        with self._on_stream():
+            self._finish_one(item)
+
+    def _finish_one(self, item):
         works, recv, dev = item
         for wk in works:
             wk.wait()
@@ -165,14 +191,16 @@ class CompactGatherer(object):
     def wait(self):
         while self._inflight:
             self._finish(self._inflight.pop(0))
+        if self.stream is not None:  # what ``self.last`` holds was produced on the side stream
+            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
 
 
-def make_gatherer(fmt, B, K, T, V, device, dst=0, group=None, depth=2, decoder=None):
+def make_gatherer(fmt, B, K, T, V, device, dst=0, group=None, depth=2, decoder=None, stream=None):
     """The gatherer bench.py / a serving loop uses: ``fmt`` = "full" (the four padded tensors travel) or "compact"
     (the trie-compact form travels; needs the ``decoder`` to expand it on ``dst``)."""
     if fmt == "full":
         shapes = [((B, K, T), torch.int32), ((B, K), torch.float32), ((B, K, T), torch.int32), ((B, K), torch.int32)]
         return ResultGatherer(shapes, device, dst=dst, group=group, depth=depth)
     if fmt == "compact":
-        return CompactGatherer(decoder, T, dst=dst, group=group, depth=depth)
+        return CompactGatherer(decoder, T, dst=dst, group=group, depth=depth, stream=stream)
     raise ValueError("unknown gather format %r" % (fmt,))

@@ -141,6 +141,10 @@ int ctcd_stream_decode(ctcd_decoder *dec, ctcd_stream **states, const unsigned c
 
 /* Host check of the per-item status words written by the last ctcd_beam_decode (synchronises the device). */
 int ctcd_check_status(ctcd_decoder *dec, int B);
+/* ... without blocking: enqueues the copy of the B status words (0 = ok) into `host_status` (page-locked memory) on
+ * `stream` -- the launch stream, before anything else is enqueued there; the caller synchronises on its own event.  For
+ * pipelined callers that queue the next batch before looking at this one. */
+int ctcd_fetch_status_async(ctcd_decoder *dec, int B, int32_t *host_status, void *stream);
 
 /* Vocabulary prune bookkeeping of the last ctcd_beam_decode (0 for the no-prune configurations).  A frame in which equal
  * values sit at the cutoff_top_n boundary or among the kept ones is ordered by whatever std::sort does with the whole

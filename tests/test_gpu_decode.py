@@ -563,3 +563,32 @@ def test_streaming_with_logits_input(torch_mod):
     got["tokens"][:, : out.shape[1], :L] = out.numpy()
     got["timesteps"][:, : out.shape[1], :L] = ts.numpy()
     ou.assert_same(got, want, "chunked logits")
+
+
+def test_async_compact_decode_tickets(torch_mod):
+    """decode_compact_async / finish_compact (the non-blocking form a pipelined caller uses: the next batch is queued on
+    another decoder before the host looks at this one): same results as the blocking calls, in any completion order."""
+    import ctcdecode_amd
+
+    torch = torch_mod
+    B, T, V, K = 5, 120, 29, 32
+    decs = [ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], beam_width=K, log_probs_input=True, device="cuda:0") for _ in range(2)]
+    lps = [ou.synth_logprobs(B, T, V, 7100 + i) for i in range(4)]
+    sl = np.array([T, 3, 0, T - 1, 60], np.int32)
+    tickets = []
+    for i, lp in enumerate(lps):  # two batches in flight at any time
+        if len(tickets) == 2:
+            j, d, tk = tickets.pop(0)
+            hdr, ent, labels, sc, ln = d.finish_compact(tk)
+            out, ts = d.expand_compact(hdr, ent, labels, T)
+            want = ou.decode(lps[j], sl, beam=K)
+            got = dict(tokens=out.cpu().numpy(), timesteps=ts.cpu().numpy(), scores=sc.cpu().numpy(), lens=ln.cpu().numpy())
+            ou.assert_same(_with_nres(got, want), want, "ticket %d" % j)
+        d = decs[i % 2]
+        tickets.append((i, d, d.decode_compact_async(torch.from_numpy(lp), torch.from_numpy(sl))))
+    for j, d, tk in tickets:
+        hdr, ent, labels, sc, ln = d.finish_compact(tk)
+        out, ts = d.expand_compact(hdr, ent, labels, T)
+        want = ou.decode(lps[j], sl, beam=K)
+        got = dict(tokens=out.cpu().numpy(), timesteps=ts.cpu().numpy(), scores=sc.cpu().numpy(), lens=ln.cpu().numpy())
+        ou.assert_same(_with_nres(got, want), want, "ticket %d" % j)
