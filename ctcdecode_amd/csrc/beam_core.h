@@ -1122,16 +1122,20 @@ struct Decoder {
     {
       const int ne = (n_new + 63) & ~63;
       const bool roles = nt >= 3 * ne;
-      const int role = roles ? (tid >= ne) + (tid >= 2 * ne) + (tid >= 3 * ne) : -1;  // 3 = no part
+      // (LM tier: a fourth part -- the scorer state of the new entries, whose dependent table look-ups are the longest
+      //  chain of the emission -- gets its own waves when there are enough)
+      const int nroles = (LM && nt >= 4 * ne) ? 4 : 3;
+      const int role = roles ? (tid >= ne) + (tid >= 2 * ne) + (tid >= 3 * ne) + (tid >= 4 * ne) : -1;  // nroles and above = no part
       const bool r_lcp = role <= 0, r_struct = role < 0 || role == 1, r_prob = role < 0 || role == 2;
+      const bool r_lm = LM && (nroles == 4 && roles ? role == 3 : r_prob);
       r_prob_any = r_prob;
       // Per-frame resets for the next step, on the threads that have no part in the emission (all of them otherwise):
       // the select histogram, the existing-children masks (last read in phase B), the paint buffers and counters of
       // the other parity.
       {
-        const bool spare = roles && nt > 3 * ne;
-        if (!spare || tid >= 3 * ne) {
-          const int t0 = spare ? tid - 3 * ne : tid, tstep = spare ? nt - 3 * ne : nt;
+        const bool spare = roles && nt > nroles * ne;
+        if (!spare || tid >= nroles * ne) {
+          const int t0 = spare ? tid - nroles * ne : tid, tstep = spare ? nt - nroles * ne : nt;
           for (int i = t0; i < kBins; i += tstep) w.bins[i] = 0;
           for (int i = t0; i < 2 * n; i += tstep) w.hit[i] = 0;
           int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;
@@ -1139,7 +1143,7 @@ struct Decoder {
           if (t0 == 0) reset_pvars(pvars(in.t + 1));
         }
       }
-      for (int k = roles ? tid - role * ne : tid; k < n_new && role < 3; k += roles ? ne : nt) {
+      for (int k = roles ? tid - role * ne : tid; k < n_new && role < nroles; k += roles ? ne : nt) {
         const int s = surv[k];
         const uint32_t inf = w.sinfo[s];
         const uint32_t type = info_type(inf);
@@ -1200,8 +1204,8 @@ struct Decoder {
             o_b = CTC_NEG_MAX; o_nb = logp; o_sc = logp;
           }
           nb.bprev[k] = o_b; nb.nbprev[k] = o_nb; nb.score[k] = o_sc; nb.lpc[k] = o_lpc;
-          if (LM) lm_emit(b, (self || child) ? j : w.anc[j], self ? -1 : c, nb, k);
         }
+        if (r_lm) lm_emit(b, (self || child) ? j : w.anc[j], self ? -1 : c, nb, k);
         if (r_prob) {
           const uint32_t ks = w.skey[s];
           kloc = ks > kloc ? ks : kloc;
