@@ -258,3 +258,21 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["config"]["ranks"] == 2 and d["value"] > 0 and d["config"]["global_batch"] == 64
+
+
+@pytest.mark.gpu
+def test_bench_gather_behind_next_decode_rccl_one_rank():
+    """The N > 1 loop of bench.py on a one-rank RCCL group (the GPU box has one device; RCCL refuses two ranks on it): async
+    compact decode tickets, status words fetched without draining the stream, collectives + expansion on a side stream."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--backend", "nccl", "--steps", "4", "--warmup", "2",
+                        "--batch", "64", "--frames", "300", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and "gather=overlap/compact, backend=nccl" in d["config"]["parallelism"]
