@@ -1098,7 +1098,7 @@ struct Decoder {
       x.sync();
       x.mark(6);
     } else if (have_bitmap) {
-      x.expand_bitmap(w.bitmap, (S + 63) / 64, surv);
+      x.template expand_bitmap<LM>(w.bitmap, (S + 63) / 64, surv);
       x.mark(3);
     } else {
       const uint32_t *skey = w.skey, *sinfo = w.sinfo;

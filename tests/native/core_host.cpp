@@ -91,6 +91,7 @@ struct HostX {
       lslot[li] = s;
     }
   }
+  template <bool CLUSTERED = false>
   void expand_bitmap(const uint32_t *bitmap, int nwords64, int *out) {
     int k = 0;
     for (int s = 0; s < nwords64 * 64; ++s)
