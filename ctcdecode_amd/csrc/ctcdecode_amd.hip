@@ -669,6 +669,32 @@ __device__ __forceinline__ uint32_t prune_key(float v) {  // order of the double
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Inclusive prefix sum of a double over the 64 lanes of a wave with DPP moves on the two halves of the value (a
+// ds_bpermute-based shuffle costs an LDS round trip per step; this runs while the other waves of the workgroup wait).
+__device__ __forceinline__ double f64_dpp(double v, const int ctrl_sel) {
+  union { double d; int i[2]; } in, out;
+  in.d = v;
+  switch (ctrl_sel) {  // (the DPP control word is an immediate)
+    case 0: out.i[0] = CTC_DPP(0, in.i[0], 0x111, 0xf); out.i[1] = CTC_DPP(0, in.i[1], 0x111, 0xf); break;  // row_shr:1
+    case 1: out.i[0] = CTC_DPP(0, in.i[0], 0x112, 0xf); out.i[1] = CTC_DPP(0, in.i[1], 0x112, 0xf); break;  // row_shr:2
+    case 2: out.i[0] = CTC_DPP(0, in.i[0], 0x114, 0xf); out.i[1] = CTC_DPP(0, in.i[1], 0x114, 0xf); break;  // row_shr:4
+    case 3: out.i[0] = CTC_DPP(0, in.i[0], 0x118, 0xf); out.i[1] = CTC_DPP(0, in.i[1], 0x118, 0xf); break;  // row_shr:8
+    case 4: out.i[0] = CTC_DPP(0, in.i[0], 0x142, 0xa); out.i[1] = CTC_DPP(0, in.i[1], 0x142, 0xa); break;  // row_bcast:15 -> rows 1, 3
+    default: out.i[0] = CTC_DPP(0, in.i[0], 0x143, 0xc); out.i[1] = CTC_DPP(0, in.i[1], 0x143, 0xc); break; // row_bcast:31 -> rows 2, 3
+  }
+  return out.d;  // (lanes without a source receive +0.0: the identity)
+}
+__device__ __forceinline__ double wave_scan_f64_sum(double v) {
+  v += f64_dpp(v, 0); v += f64_dpp(v, 1); v += f64_dpp(v, 2); v += f64_dpp(v, 3); v += f64_dpp(v, 4); v += f64_dpp(v, 5);
+  return v;
+}
+__device__ __forceinline__ double f64_from_lane(double v, int lane_idx) {
+  union { double d; int i[2]; } in, out;
+  in.d = v;
+  out.i[0] = __builtin_amdgcn_readlane(in.i[0], lane_idx); out.i[1] = __builtin_amdgcn_readlane(in.i[1], lane_idx);
+  return out.d;
+}
+
 __device__ __forceinline__ double log_add_f64(double a, double b) {  // decoder_utils.h:47-54 with T = double
   const double neg = -1.7976931348623157e308;
   if (a <= neg) return b;
@@ -862,7 +888,7 @@ __global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
         const int firsthit = mh ? __ffsll((long long)mh) - 1 : 64;
         if (mn && (__ffsll((long long)mn) - 1) <= firsthit) flag = true;  // ambiguous before (or at) the stopping point
         if (mh) stop = i0 + firsthit + 1;
-        carry += __shfl(incl, 63, 64);
+        carry += f64_from_lane(incl, 63);
       }
       len = stop;
       flag = __ballot(flag) != 0ull;
@@ -898,15 +924,10 @@ __device__ __forceinline__ int prune_cumulative_cut(const PruneArgs &a, const fl
     const int i = i0 + lane;
     double p = 0.0;
     if (i < kept) {
-      const double v = (double)x[sidx[i]];
+      const double v = (double)(sidx ? x[sidx[i]] : x[i]);  // (sidx == nullptr: x[] already holds the kept values, best first)
       p = a.log_input ? exp(v) : v;
     }
-    double incl = p;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double o = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += o;
-    }
+    const double incl = wave_scan_f64_sum(p);
     const double cum = log(1.0 + carry + incl);
     const bool near = i < kept && (fabs(cum - a.cutoff_prob) <= 1e-9 * (1.0 + fabs(cum)) || !(cum == cum));
     const bool hit = i < kept && (cum >= a.cutoff_prob || i + 1 >= a.top_n);
@@ -914,7 +935,7 @@ __device__ __forceinline__ int prune_cumulative_cut(const PruneArgs &a, const fl
     const int firsthit = mh ? __ffsll((long long)mh) - 1 : 64;
     if (mn && (__ffsll((long long)mn) - 1) <= firsthit) flag = true;
     if (mh) stop = i0 + firsthit + 1;
-    carry += __shfl(incl, 63, 64);
+    carry += f64_from_lane(incl, 63);
   }
   flag = __ballot(flag) != 0ull;
   return stop;
@@ -928,13 +949,16 @@ __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = a.top_n < a.V ? a.top_n : a.V;
   const int nq = (n + 3) >> 2;  // per-wave share
-  uint32_t *lkey = (uint32_t *)psm;
-  int *lidx = (int *)lkey + a.stride;
-  int *sidx = lidx + a.stride;
-  uint32_t *ckey = (uint32_t *)(sidx + a.stride);
+  // LDS: the kept values in final order (for the cumulative cut) | spare | (unused) | candidate keys | their labels | their values
+  float *sval = (float *)psm;
+  uint32_t *ckey = (uint32_t *)(sval + ((3 * a.stride + 3) & ~3));  // (16-byte aligned: read four keys at a time)
   int *cidx = (int *)ckey + kPruneCand;
+  float *cval = (float *)(cidx + kPruneCand);
   const int nv4 = a.V >> 2;
-  constexpr int kChunk = F4 < 5 ? F4 : 5;  // 128-bit loads in flight per thread
+#ifndef CTC_EXP_PRUNE_CHUNK
+#define CTC_EXP_PRUNE_CHUNK 5
+#endif
+  constexpr int kChunk = F4 < CTC_EXP_PRUNE_CHUNK ? F4 : CTC_EXP_PRUNE_CHUNK;  // 128-bit loads in flight per thread
   for (long long r = blockIdx.x; r < a.rows; r += gridDim.x) {
     if (a.seq_lens) {
       const long long b = r / a.T;
@@ -984,7 +1008,7 @@ __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
         for (int e = 0; e < 4; ++e)
           if (kk[e] >= bound && kk[e] != 0u) {
             const int p = atomicAdd(&s_cnt, 1);
-            if (p < kPruneCand) { ckey[p] = kk[e]; cidx[p] = 4 * i4 + e; }
+            if (p < kPruneCand) { ckey[p] = kk[e]; cidx[p] = 4 * i4 + e; cval[p] = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
           }
       }
     }
@@ -997,28 +1021,33 @@ __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
       float *olp = a.lp + (size_t)r * a.stride;
       if (!flag) {
         // every lane ranks its own candidates among all of them: rank = #greater; the n-th largest has rank < n <= rank + #equal
+        // (everything this wave needs from here on sits in LDS -- the other three waves of the workgroup wait for it, so a
+        //  global access or a chain of dependent LDS reads here is paid by the whole row: the keys are read four at a
+        //  time, the values come from the list the second sweep filled)
+        for (int p = ns + lane; p < ((ns + 3) & ~3); p += 64) ckey[p] = 0u;  // pad to a multiple of four, below every real key
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         for (int q0 = 0; q0 < ns; q0 += 64) {
           const int q = q0 + lane;
-          const uint32_t mine = q < ns ? ckey[q] : 0u;
+          const uint32_t mine = q < ns ? ckey[q] : 0xFFFFFFFFu;
           int gg = 0, ee = 0;
-          for (int o = 0; o < ns; ++o) {
-            const uint32_t k = ckey[o];
-            gg += k > mine;
-            ee += k == mine;
+          for (int o = 0; o < ns; o += 4) {
+            const uint4 k4 = *reinterpret_cast<const uint4 *>(ckey + o);
+            gg += (k4.x > mine) + (k4.y > mine) + (k4.z > mine) + (k4.w > mine);
+            ee += (k4.x == mine) + (k4.y == mine) + (k4.z == mine) + (k4.w == mine);
           }
           const bool keep = q < ns && gg < n;
           if (keep && gg + ee > n) flag = true;   // equal values straddle the cut: std::sort decides which of them are kept
           if (keep && ee > 1) flag = true;        // equal kept values: their order is std::sort's business
           if (keep && ee == 1) {
             const int idx = cidx[q];
-            float v = x[idx];
+            float v = cval[q];
             if (!a.log_input) {  // decoder_utils.cpp:42
               const double y = log((double)v + (double)FLT_MIN);
               v = (float)y;
               const double eps = fabs(y) * 0x1p-50;
               if ((float)(y - eps) != v || (float)(y + eps) != v || !(y == y)) flag = true;
             }
-            och[gg] = idx; olp[gg] = v; sidx[gg] = idx;
+            och[gg] = idx; olp[gg] = v; sval[gg] = cval[q];  // (sval: the row's own value, before any prob -> log conversion)
           }
           kept += __popcll(__ballot(keep));
         }
@@ -1027,7 +1056,7 @@ __global__ void __launch_bounds__(256) prune_rows_wg_kernel(PruneArgs a) {
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
       flag = __ballot(flag) != 0ull;
       int len = kept;
-      if (a.cutoff_prob < 1.0 && !flag) len = prune_cumulative_cut(a, x, sidx, kept, lane, flag);
+      if (a.cutoff_prob < 1.0 && !flag) len = prune_cumulative_cut(a, sval, nullptr, kept, lane, flag);
       if (lane == 0) {
         a.cnt[r] = len;
         if (flag) {
@@ -1715,8 +1744,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
           : V <= 4096 ? (const void *)prune_rows_wg_kernel<4> : V <= 10240 ? (const void *)prune_rows_wg_kernel<10>
           : (const void *)prune_rows_wg_kernel<16>;
     }
-    const size_t psm_launch = wg_kernel ? (3 * (size_t)stride + 2 * kPruneCand) * 4 : psm;
-    const int blocks_launch = wg_kernel ? (int)std::min<long long>(rows, 256 * 32) : blocks;
+    const size_t psm_launch = wg_kernel ? (3 * (size_t)stride + 3 * kPruneCand + 4) * 4 : psm;
+#ifndef CTC_EXP_PRUNE_GRID
+#define CTC_EXP_PRUNE_GRID (256 * 32)
+#endif
+    const int blocks_launch = wg_kernel ? (int)std::min<long long>(rows, CTC_EXP_PRUNE_GRID) : blocks;
     HIP_TRY(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm_launch));
     unsigned nf = 0, nh = 0;
     unsigned *n_flag = nullptr, *flag_rows = nullptr, *host_rows = nullptr;
