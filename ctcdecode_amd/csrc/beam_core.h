@@ -577,7 +577,6 @@ struct Decoder {
     for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
     x.sync();
     x.mark(14);
-    if (tid < inb) x.template prio<3>();
     for (int q = tid; q < inb; q += nt) {
       const uint32_t mine = w.list[q];
       int g = 0, e = 0;
@@ -594,7 +593,6 @@ struct Decoder {
         x.atomic_or(&w.bitmap[sl >> 5], 1u << (sl & 31));
       }
     }
-    x.template prio<0>();
     x.sync();
   }
 
@@ -973,7 +971,6 @@ struct Decoder {
     }
     x.mark(1);
     if (!split || tid >= n1) {
-      if (split) x.template prio<2>();
       const int t2 = split ? tid - n1 : tid, nt2 = split ? nt - n1 : nt;
       const int sh = ceil_log2_u32((uint32_t)(Vnb > 1 ? Vnb : 1));
       const int lp2 = 1 << sh;                       // lanes per parent (power of two >= Vnb)
@@ -1035,7 +1032,6 @@ struct Decoder {
       }
       if (LM) x.wave_add(&pv[P_NCAND], ncand);
     }
-    if (split) x.template prio<0>();
     x.sync();
     if (!small_vocab) {  // children that already exist leave a hole in their parent's group; then the histogram
       for (int j = tid; j < n; j += nt) {

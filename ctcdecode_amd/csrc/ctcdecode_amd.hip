@@ -132,8 +132,8 @@ struct DevX {
     out[2] = __builtin_amdgcn_readfirstlane(v.z); out[3] = __builtin_amdgcn_readfirstlane(v.w);
   }
   __device__ __forceinline__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-  // issue priority of this wave among the waves of its SIMD (0 = default .. 3): raised while a wave is the only one
-  // doing a phase's work, so that the other waves' bookkeeping does not delay it
+  // issue priority of this wave among the waves of its SIMD (0 = default .. 3).  (Raising it for the wave that works
+  // alone in a phase, or for the child-scoring waves of phase B, was measured: neutral to 0.6 % slower -- not used.)
   template <int P>
   __device__ __forceinline__ void prio() const { __builtin_amdgcn_s_setprio(P); }
   // a pointer the compiler must treat as new: what it points to is (re)loaded after this point, not kept live before it
@@ -298,7 +298,6 @@ struct DevX {
       return;
     }
     if (threadIdx.x < 64) {
-      __builtin_amdgcn_s_setprio(3);
       const int lane = (int)threadIdx.x;
       int running = 0;
       for (int w0 = 0; w0 < nwords64; w0 += 64) {
@@ -314,7 +313,6 @@ struct DevX {
         }
         running += __builtin_amdgcn_readlane(incl, 63);
       }
-      __builtin_amdgcn_s_setprio(0);
     }
     sync();
   }
@@ -390,7 +388,6 @@ struct DevX {
   // total, #keys in it} after the closing barrier.
   __device__ __forceinline__ void find_bucket(const int *bins, int need, int *out) {
     if (threadIdx.x < 64) {
-      __builtin_amdgcn_s_setprio(3);
       const int lane = (int)threadIdx.x;
       const int c = 63 - lane;  // lane 0 owns the TOP coarse bucket: a prefix scan over lanes is a suffix sum over buckets
       const int4 *f4 = reinterpret_cast<const int4 *>(bins + 16 * c);  // its 16 fine buckets: four 128-bit reads, one round trip
@@ -411,7 +408,6 @@ struct DevX {
         const int l2 = __ffsll((long long)mf) - 1;
         if (lane == l2) { out[0] = cstar * 16 + (15 - lane); out[1] = fincl - fv; out[2] = total; out[3] = fv; }
       }
-      __builtin_amdgcn_s_setprio(0);
     }
     sync();
   }
