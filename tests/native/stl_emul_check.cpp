@@ -38,6 +38,35 @@ static void check_all(const std::vector<int> &key, std::mt19937 &g) {
     ++g_checked;
     if (a != b) { ++g_bad; fprintf(stderr, "re-sort mismatch n=%d\n", n); }
   }
+  // sort_parallel (the workgroup form, run here by one "thread"): whole array, a prefix (`limit`: only ranges that reach
+  // the first `limit` places are sorted -- what the prune pass's tie replay asks for), 16-bit task lists
+  if (n > 16 && n < 65536) {
+    struct SeqX {
+      int tid() const { return 0; }
+      int nt() const { return 1; }
+      void sync() {}
+      int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
+      int uni(int v) const { return v; }
+    } sx;
+    std::vector<uint32_t> want = base;
+    std::sort(want.begin(), want.end(), cmp);
+    const int cap = n / 17 + 2;
+    for (int rep = 0; rep < 3; ++rep) {
+      const int limit = rep == 0 ? 0x7fffffff : rep == 1 ? std::min(n, 40) : 1 + (int)(g() % n);
+      std::vector<uint32_t> b = base;
+      int cnt[4] = {0, 0, 0, 0};
+      if (rep == 2) {
+        std::vector<uint16_t> cur(3 * cap), nxt(3 * cap), small(2 * (n / 2 + 1));
+        stlemu::sort_parallel(sx, b.data(), n, cmp, cur.data(), nxt.data(), small.data(), cnt, -1, limit);
+      } else {
+        std::vector<int> cur(3 * cap), nxt(3 * cap), small(2 * (n / 2 + 1));
+        stlemu::sort_parallel(sx, b.data(), n, cmp, cur.data(), nxt.data(), small.data(), cnt, -1, limit);
+      }
+      ++g_checked;
+      const int upto = std::min(n, limit);
+      if (!std::equal(b.begin(), b.begin() + upto, want.begin())) { ++g_bad; fprintf(stderr, "sort_parallel mismatch n=%d limit=%d\n", n, limit); }
+    }
+  }
   // nth_element at a few positions
   for (int rep = 0; rep < 4 && n > 0; ++rep) {
     int nth = rep == 0 ? n / 2 : rep == 1 ? std::min(n, 100) % (n + 1) : (int)(g() % (n + 1));
