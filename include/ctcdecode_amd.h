@@ -48,8 +48,11 @@ typedef struct ctcd_decoder ctcd_decoder;
 int ctcd_create(ctcd_decoder **out, int device_id);
 void ctcd_destroy(ctcd_decoder *dec);
 
-/* Decode a batch whose tensors all live in the HBM of the decoder's device.  Asynchronous on `stream` unless
- * log_input == 0 or n_results/status need host inspection; call hipStreamSynchronize before reading. */
+/* Decode a batch whose tensors all live in the HBM of the decoder's device.  Asynchronous on `stream` -- call
+ * hipStreamSynchronize (or ctcd_check_status / ctcd_fetch_status_async) before reading -- except that the two pre-passes
+ * read their exception counters back before the decode kernel is queued: vocabulary pruning (cutoff_top_n < V or
+ * cutoff_prob < 1: frames flagged for the std::sort replay / the host toolchain) and probability input (log_input == 0:
+ * elements whose log rounds ambiguously); see DESIGN.md 5. */
 int ctcd_beam_decode(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                      int num_processes /* accepted for signature parity; unused on the GPU */, double cutoff_prob,
                      int cutoff_top_n, int blank_id, int log_input, int32_t *out_tokens, int32_t *out_timesteps,
