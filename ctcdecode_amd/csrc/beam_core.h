@@ -714,47 +714,7 @@ struct Decoder {
   // the rest: stl_emul.h split_with_median_pivot) by the whole workgroup.  Lp, Rp: scratch for last - first + 1 positions
   // each.  Returns the cut.
   CTC_HD int hoare_round(uint64_t *v, int first, int last, uint16_t *Lp, uint16_t *Rp) {
-    const int tid = x.tid(), nt = x.nt();
-    auto before = [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); };
-    if (tid == 0) stlemu::median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
-    x.sync();
-    // Hoare partition of [first+1, last) around v[first]: the t-th element from the left that is not better than the
-    // pivot is exchanged with the t-th from the right that is not worse, until the two scans cross.  Every thread counts
-    // the stops of both kinds in its own stretch of the range; one prefix over the threads turns the counts into the
-    // stops' ranks.
-    const int lo = first + 1, m = last - lo;
-    const uint64_t kp = v[first] >> 16;
-    const int chunk = ceil_div_p2(m, nt), i0 = tid * chunk < m ? tid * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
-    uint32_t mine = 0;  // #left stops | #right stops << 16
-    for (int i = i0; i < i1; ++i) {
-      const uint64_t k = v[lo + i] >> 16;
-      mine += (k <= kp ? 1u : 0u) + (k >= kp ? 0x10000u : 0u);
-    }
-    uint32_t run, tot;
-    x.block_scan_u32(mine, &run, &tot);
-    const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
-    for (int i = i0; i < i1; ++i) {
-      const uint64_t k = v[lo + i] >> 16;
-      if (k <= kp) { Lp[run & 0xFFFFu] = (uint16_t)(lo + i); run += 1u; }
-      if (k >= kp) { Rp[nR - 1 - (int)(run >> 16)] = (uint16_t)(lo + i); run += 0x10000u; }
-    }
-    if (tid == 0) Rp[nR] = (uint16_t)first;  // the pivot itself stops the right-to-left scan
-    x.sync();
-    // Iteration t of the serial loop stops its left scan at min(Lp[t], Rp[t-1]) (the element swapped into Rp[t-1]
-    // is itself a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
-    const int tmax = nL < nR + 1 ? nL : nR + 1;
-    auto crossed = [&](int t) { return t >= nL || t > nR || Lp[t] >= Rp[t]; };
-    for (int t = tid; t <= tmax; t += nt) {
-      if (!crossed(t)) {
-        stlemu::exch(v, (int)Lp[t], (int)Rp[t]);
-      } else if (t == 0 || !crossed(t - 1)) {
-        int c = t < nL ? (int)Lp[t] : kIntMax;
-        if (t > 0 && (int)Rp[t - 1] < c) c = Rp[t - 1];
-        w.vars[VAR_CUT] = c;
-      }
-    }
-    x.sync();
-    return x.uni(w.vars[VAR_CUT]);
+    return stlemu::hoare_round_parallel(x, v, first, last, [](uint64_t e) { return e >> 16; }, Lp, Rp, &w.vars[VAR_CUT]);
   }
 
   // std::nth_element(begin, begin+K, end, prefix_compare) on the DFS-ordered candidate list (w.ek[0, N)).

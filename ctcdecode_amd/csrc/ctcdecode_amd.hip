@@ -1075,6 +1075,24 @@ __global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
 // cumulative cut.  What remains for the host (n_host / host_rows): frames with a NaN, borderline libm roundings (the
 // prob -> log conversion, the cumulative sum next to cutoff_prob), rows too long for the workgroup's LDS.
 struct WgSortX {
+  uint32_t *wsum;  // one word per wave (shared)
+  // exclusive prefix (in thread order) and total of one word per thread; contains a barrier
+  __device__ __forceinline__ void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) {
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int q = 0; q < nw; ++q) { const uint32_t t = wsum[q]; if (q < wave) base += t; tot += t; }
+    *base_out = base + incl - mine;
+    *total_out = tot;
+    __syncthreads();  // (wsum is reused by the next round)
+  }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
   __device__ __forceinline__ int nt() const { return (int)blockDim.x; }
   __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -1090,104 +1108,6 @@ __host__ __device__ inline size_t prune_resolve_lds_bytes(int V, int n) {
   return (size_t)V * 8 + (size_t)2 * (V + 2) * 2 + (size_t)6 * prune_resolve_task_cap(V) * 2 + (size_t)2 * (V / 2 + 1) * 2 + 3 * 64 * 4 + 64 +
          (size_t)n * 4 + 64;
 }
-// The first `limit` places of std::sort(v, v + V, before) by one workgroup, element for element (ranges of the introsort
-// that start beyond them are left alone: the prune pass keeps only the best top_n of a row).  Long ranges first, one at a time, each split by all
-// threads: the t-th element from the left that is not better than the pivot is exchanged with the t-th from the right that
-// is not worse, until the two scans cross (the exchanges of the serial Hoare loop, found with two prefix counts -- the
-// scheme of beam_core.h replay_nth_element); the ranges that remain (<= kResolveBigCut) go through stlemu::sort_parallel,
-// one thread per range and round.
-template <class C>
-__device__ void resolve_sort_like_std(unsigned long long *v, int V, int limit, C before, uint16_t *Lp, uint16_t *Rp, uint16_t *cur, uint16_t *nxt,
-                                      uint16_t *small, int *cnt, int *bstack, uint32_t *wsum) {
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  WgSortX x;
-  if (V <= 16) {
-    if (tid == 0) stlemu::sort(v, 0, V, before, bstack);
-    __syncthreads();
-    return;
-  }
-  int sp = 0, ntask = 0, nsmall = 0;  // (identical in every thread)
-  if (tid == 0) { bstack[0] = 0; bstack[1] = V; bstack[2] = 2 * stlemu::floor_lg(V); }
-  sp = 1;
-  __syncthreads();
-  while (sp > 0) {
-    --sp;
-    const int first = bstack[3 * sp], last = bstack[3 * sp + 1];
-    int depth = bstack[3 * sp + 2];
-    __syncthreads();  // (the slot is about to be overwritten by a push)
-    if (last - first <= kResolveBigCut) {
-      if (tid == 0) { cur[3 * ntask] = (uint16_t)first; cur[3 * ntask + 1] = (uint16_t)last; cur[3 * ntask + 2] = (uint16_t)depth; }
-      ++ntask;
-      continue;
-    }
-    if (depth == 0) {  // depth budget spent on a long range (adversarial input): the heap sort, by one thread
-      if (tid == 0) { stlemu::heap_select(v, first, last, last, before); stlemu::heap_sort_down(v, first, last, before); }
-      __syncthreads();
-      continue;
-    }
-    --depth;
-    if (tid == 0) stlemu::median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
-    __syncthreads();
-    const int lo = first + 1, m = last - lo;
-    const uint32_t kp = (uint32_t)(v[first] >> 32);
-    const int chunk = (m + kResolveThreads - 1) / kResolveThreads, i0 = min(tid * chunk, m), i1 = min(i0 + chunk, m);
-    uint32_t mine = 0;  // #left stops | #right stops << 16 in this thread's stretch
-    for (int i = i0; i < i1; ++i) {
-      const uint32_t k = (uint32_t)(v[lo + i] >> 32);
-      mine += (k <= kp ? 1u : 0u) + (k >= kp ? 0x10000u : 0u);
-    }
-    uint32_t incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += o;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-    for (int q = 0; q < kResolveThreads / 64; ++q) { const uint32_t t = wsum[q]; if (q < wave) base += t; tot += t; }
-    const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
-    uint32_t run = base + incl - mine;
-    for (int i = i0; i < i1; ++i) {
-      const uint32_t k = (uint32_t)(v[lo + i] >> 32);
-      if (k <= kp) { Lp[run & 0xFFFFu] = (uint16_t)(lo + i); run += 1u; }
-      if (k >= kp) { Rp[nR - 1 - (int)(run >> 16)] = (uint16_t)(lo + i); run += 0x10000u; }
-    }
-    if (tid == 0) Rp[nR] = (uint16_t)first;  // the pivot itself stops the right-to-left scan
-    __syncthreads();
-    // Iteration t of the serial loop stops its left scan at min(Lp[t], Rp[t-1]) (the element swapped into Rp[t-1] is
-    // itself a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
-    const int tmax = nL < nR + 1 ? nL : nR + 1;
-    auto crossed = [&](int t) { return t >= nL || t > nR || Lp[t] >= Rp[t]; };
-    for (int t = tid; t <= tmax; t += kResolveThreads) {
-      if (!crossed(t)) {
-        stlemu::exch(v, (int)Lp[t], (int)Rp[t]);
-      } else if (t == 0 || !crossed(t - 1)) {
-        int c = t < nL ? (int)Lp[t] : 0x7fffffff;
-        if (t > 0 && (int)Rp[t - 1] < c) c = Rp[t - 1];
-        cnt[3] = c;
-      }
-    }
-    __syncthreads();
-    const int cut = cnt[3];
-    for (int side = 0; side < 2; ++side) {
-      const int a = side ? cut : first, e = side ? last : cut;
-      if (a >= limit) continue;  // only the first `limit` places of the sorted row are read (stl_emul.h sort_parallel)
-      if (e - a > 16) {
-        if (tid == 0) { bstack[3 * sp] = a; bstack[3 * sp + 1] = e; bstack[3 * sp + 2] = depth; }
-        ++sp;
-      } else if (e - a > 1) {
-        if (tid == 0) { small[2 * nsmall] = (uint16_t)a; small[2 * nsmall + 1] = (uint16_t)e; }
-        ++nsmall;
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[2] = nsmall; }
-  __syncthreads();
-  stlemu::sort_parallel(x, v, V, before, cur, nxt, small, cnt, ntask, limit);
-}
-
 __global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArgs a, unsigned *n_host, unsigned *host_rows) {
   extern __shared__ __attribute__((aligned(16))) char rsm[];
   __shared__ int s_bad;
@@ -1200,6 +1120,7 @@ __global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArg
   int *bstack = (int *)(((uintptr_t)(small + 2 * (V / 2 + 1)) + 15) & ~(uintptr_t)15);
   int *cnt = bstack + 3 * 64, *sidx = cnt + 4;
   const unsigned raw = *a.n_flag, nf = raw < a.flag_cap ? raw : a.flag_cap;
+  WgSortX x{s_wsum};
   for (unsigned k = blockIdx.x; k < nf; k += gridDim.x) {
     const long long r = (long long)a.flag_rows[k];
     const float *row = a.in + (size_t)r * V;
@@ -1215,8 +1136,10 @@ __global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArg
     __syncthreads();
     if (!s_bad) {
       // decoder_utils.cpp:19-20: (index, double) pairs in index order, std::sort on the value alone, descending
-      resolve_sort_like_std(v, V, n, [](unsigned long long p, unsigned long long q) { return (uint32_t)(p >> 32) > (uint32_t)(q >> 32); }, Lp, Rp,
-                            cur, nxt, small, cnt, bstack, s_wsum);
+      // (stl_emul.h: long ranges split by the whole workgroup, the rest by one thread per range; only the ranges that reach
+      //  the first n places -- the prune pass keeps the best top_n of a row)
+      stlemu::sort_prefix_parallel(x, v, V, n, kResolveBigCut, [](unsigned long long e) { return (uint32_t)(e >> 32); }, Lp, Rp, cur, nxt, small,
+                                   cnt, bstack);
       if (tid < 64) {
         bool flag = false;
         int *och = a.ch + (size_t)r * a.stride;

@@ -296,6 +296,107 @@ STLEMU_HD void sort_parallel(X &x, T *v, int n, C before, I *cur, I *nxt, I *sma
   x.sync();
 }
 
+// One partition step of introsort / introselect -- median of three to the front, unguarded Hoare partition of the rest
+// (split_with_median_pivot) -- on v[first, last) by a whole workgroup.  Elements are ordered by key_of(e), larger first.
+// Every thread counts, in its own stretch of the range, the stops of the two scans (left-to-right: elements not better
+// than the pivot; right-to-left: elements not worse); one prefix over the threads turns the counts into the stops' ranks;
+// the t-th stop from the left is exchanged with the t-th from the right until the scans cross -- the exchanges of the
+// serial loop.  X additionally provides block_scan_u32(mine, &exclusive_prefix, &total) (contains a barrier).
+// Lp, Rp: scratch for last - first + 1 positions each (16 bit: n < 65536); *cutvar: one shared word.  Returns the cut.
+template <class X, class T, class KeyOf>
+STLEMU_HD int hoare_round_parallel(X &x, T *v, int first, int last, KeyOf key_of, uint16_t *Lp, uint16_t *Rp, int *cutvar) {
+  const int tid = x.tid(), nt = x.nt();
+  auto before = [&](const T &a, const T &b) { return key_of(a) > key_of(b); };
+  if (tid == 0) median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
+  x.sync();
+  const int lo = first + 1, m = last - lo;
+  const auto kp = key_of(v[first]);
+  const int chunk = (m + nt - 1) / nt, i0 = tid * chunk < m ? tid * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
+  uint32_t mine = 0;  // #left stops | #right stops << 16
+  for (int i = i0; i < i1; ++i) {
+    const auto k = key_of(v[lo + i]);
+    mine += (k <= kp ? 1u : 0u) + (k >= kp ? 0x10000u : 0u);
+  }
+  uint32_t run, tot;
+  x.block_scan_u32(mine, &run, &tot);
+  const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
+  for (int i = i0; i < i1; ++i) {
+    const auto k = key_of(v[lo + i]);
+    if (k <= kp) { Lp[run & 0xFFFFu] = (uint16_t)(lo + i); run += 1u; }
+    if (k >= kp) { Rp[nR - 1 - (int)(run >> 16)] = (uint16_t)(lo + i); run += 0x10000u; }
+  }
+  if (tid == 0) Rp[nR] = (uint16_t)first;  // the pivot itself stops the right-to-left scan
+  x.sync();
+  // Iteration t of the serial loop stops its left scan at min(Lp[t], Rp[t-1]) (the element swapped into Rp[t-1] is itself
+  // a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
+  const int tmax = nL < nR + 1 ? nL : nR + 1;
+  auto crossed = [&](int t) { return t >= nL || t > nR || Lp[t] >= Rp[t]; };
+  for (int t = tid; t <= tmax; t += nt) {
+    if (!crossed(t)) {
+      exch(v, (int)Lp[t], (int)Rp[t]);
+    } else if (t == 0 || !crossed(t - 1)) {
+      int c = t < nL ? (int)Lp[t] : 0x7fffffff;
+      if (t > 0 && (int)Rp[t - 1] < c) c = Rp[t - 1];
+      *cutvar = c;
+    }
+  }
+  x.sync();
+  return x.uni(*cutvar);
+}
+
+// The first `limit` places of std::sort(v, v + n) (key_of(e), larger first) by one workgroup, element for element.  Ranges
+// longer than big_cut are split one at a time by all threads (hoare_round_parallel; a stack of pending long ranges in
+// bstack, 3 * 64 ints), the ones that remain go through sort_parallel, one thread per range and round.  Ranges that start
+// at or beyond `limit` are left alone.  n < 65536; scratch as for sort_parallel with 16-bit lists, cnt[4].
+template <class X, class T, class KeyOf>
+STLEMU_HD void sort_prefix_parallel(X &x, T *v, int n, int limit, int big_cut, KeyOf key_of, uint16_t *Lp, uint16_t *Rp, uint16_t *cur,
+                                    uint16_t *nxt, uint16_t *small, int *cnt, int *bstack) {
+  const int tid = x.tid();
+  auto before = [&](const T &a, const T &b) { return key_of(a) > key_of(b); };
+  if (n <= 16) {
+    if (tid == 0) sort(v, 0, n, before, bstack);
+    x.sync();
+    return;
+  }
+  int sp = 0, ntask = 0, nsmall = 0;  // (identical in every thread)
+  if (tid == 0) { bstack[0] = 0; bstack[1] = n; bstack[2] = 2 * floor_lg(n); }
+  sp = 1;
+  x.sync();
+  while (sp > 0) {
+    --sp;
+    const int first = x.uni(bstack[3 * sp]), last = x.uni(bstack[3 * sp + 1]);
+    int depth = x.uni(bstack[3 * sp + 2]);
+    x.sync();  // (the slot is about to be overwritten by a push)
+    if (last - first <= big_cut) {
+      if (tid == 0) { cur[3 * ntask] = (uint16_t)first; cur[3 * ntask + 1] = (uint16_t)last; cur[3 * ntask + 2] = (uint16_t)depth; }
+      ++ntask;
+      continue;
+    }
+    if (depth == 0) {  // depth budget spent on a long range (adversarial input): the heap sort, by one thread
+      if (tid == 0) { heap_select(v, first, last, last, before); heap_sort_down(v, first, last, before); }
+      x.sync();
+      continue;
+    }
+    --depth;
+    const int cut = hoare_round_parallel(x, v, first, last, key_of, Lp, Rp, cnt + 3);
+    for (int side = 0; side < 2; ++side) {
+      const int a = side ? cut : first, e = side ? last : cut;
+      if (a >= limit) continue;  // only the first `limit` places are wanted (sort_parallel)
+      if (e - a > 16) {
+        if (tid == 0) { bstack[3 * sp] = a; bstack[3 * sp + 1] = e; bstack[3 * sp + 2] = depth; }
+        ++sp;
+      } else if (e - a > 1) {
+        if (tid == 0) { small[2 * nsmall] = (uint16_t)a; small[2 * nsmall + 1] = (uint16_t)e; }
+        ++nsmall;
+      }
+    }
+    x.sync();
+  }
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[2] = nsmall; }
+  x.sync();
+  sort_parallel(x, v, n, before, cur, nxt, small, cnt, ntask, limit);
+}
+
 // == std::partial_sort(v+first, v+middle, v+last, before)   (used by the tests to reach the heap code directly)
 template <class T, class C>
 STLEMU_HD void partial_sort(T *v, int first, int middle, int last, C before) {

@@ -66,6 +66,31 @@ static void check_all(const std::vector<int> &key, std::mt19937 &g) {
       const int upto = std::min(n, limit);
       if (!std::equal(b.begin(), b.begin() + upto, want.begin())) { ++g_bad; fprintf(stderr, "sort_parallel mismatch n=%d limit=%d\n", n, limit); }
     }
+    // sort_prefix_parallel: long ranges through the workgroup form of the Hoare partition (two prefix counts instead of
+    // two scans), the rest through sort_parallel -- the prune pass's tie replay, run here by one "thread"
+    struct SeqX2 {
+      int tid() const { return 0; }
+      int nt() const { return 1; }
+      void sync() {}
+      int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
+      int uni(int v) const { return v; }
+      void block_scan_u32(uint32_t mine, uint32_t *base, uint32_t *total) { *base = 0; *total = mine; }
+    } sx2;
+    for (int rep = 0; rep < 3; ++rep) {
+      const int limit = rep == 0 ? n : rep == 1 ? std::min(n, 40) : 1 + (int)(g() % n);
+      const int big_cut = rep == 2 ? 17 + (int)(g() % 300) : 256;
+      // (index, key) pairs in index order, as the prune pass builds them: key in the high half
+      std::vector<unsigned long long> pv(n);
+      for (int i = 0; i < n; ++i) pv[i] = ((unsigned long long)(uint32_t)(key[i] + 0x40000000) << 32) | (unsigned)i;
+      std::vector<uint16_t> Lp(n + 2), Rp(n + 2), cur(3 * cap), nxt(3 * cap), small(2 * (n / 2 + 1));
+      int cnt[4] = {0, 0, 0, 0}, bstack[3 * 64];
+      stlemu::sort_prefix_parallel(sx2, pv.data(), n, limit, big_cut, [](unsigned long long e) { return (uint32_t)(e >> 32); }, Lp.data(), Rp.data(),
+                                   cur.data(), nxt.data(), small.data(), cnt, bstack);
+      ++g_checked;
+      bool ok = true;
+      for (int i = 0; i < std::min(n, limit); ++i) ok = ok && (uint32_t)pv[i] == want[i];
+      if (!ok) { ++g_bad; fprintf(stderr, "sort_prefix_parallel mismatch n=%d limit=%d big_cut=%d\n", n, limit, big_cut); }
+    }
   }
   // nth_element at a few positions
   for (int rep = 0; rep < 4 && n > 0; ++rep) {
