@@ -954,10 +954,7 @@ __global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
   int *cidx = (int *)ckey + kPruneCand;
   float *cval = (float *)(cidx + kPruneCand);
   const int nv4 = a.V >> 2;
-#ifndef CTC_EXP_PRUNE_CHUNK
-#define CTC_EXP_PRUNE_CHUNK 5
-#endif
-  constexpr int kChunk = F4 < CTC_EXP_PRUNE_CHUNK ? F4 : CTC_EXP_PRUNE_CHUNK;  // 128-bit loads in flight per thread
+  constexpr int kChunk = F4 < 5 ? F4 : 5;  // 128-bit loads in flight per thread (measured: 2, 4 and 10 are slower)
   for (long long r = blockIdx.x; r < a.rows; r += gridDim.x) {
     if (a.seq_lens) {
       const long long b = r / a.T;
@@ -1667,10 +1664,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
           : (const void *)prune_rows_wg_kernel<16>;
     }
     const size_t psm_launch = wg_kernel ? (3 * (size_t)stride + 3 * kPruneCand + 4) * 4 : psm;
-#ifndef CTC_EXP_PRUNE_GRID
-#define CTC_EXP_PRUNE_GRID (256 * 32)
-#endif
-    const int blocks_launch = wg_kernel ? (int)std::min<long long>(rows, CTC_EXP_PRUNE_GRID) : blocks;
+    // (measured: a persistent grid of 1280 or 2560 workgroups is slower, 16 k / 32 k the same)
+    const int blocks_launch = wg_kernel ? (int)std::min<long long>(rows, 256 * 32) : blocks;
     HIP_TRY(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm_launch));
     unsigned nf = 0, nh = 0;
     unsigned *n_flag = nullptr, *flag_rows = nullptr, *host_rows = nullptr;
