@@ -118,11 +118,15 @@ struct Dims {
 // the step after next without racing with threads that still read this one.
 enum {
   VAR_STATUS = 0, VAR_CUT, VAR_TAUC,
+  VAR_DANGER,  // sticky: this utterance has seen a log-probability that can make log_sum_exp depend on the order of its
+               // arguments (decoder_utils.h:47-54); see Decoder::enter_danger
   VAR_FB0 = 4, VAR_FB1, VAR_FB2, VAR_FB3,   // 16-byte aligned groups: read back with one LDS access (X::uni4)
   VAR_TAU = 8, VAR_G, VAR_E, VAR_SPARE,
   VAR_PAR0 = 12,  // first per-parity set
   P_NPIN = 0, P_LCOUNT, P_NMAXKEY, P_NMINKEY, P_NCAND, P_SIZE = 8,
-  VAR_COUNT = VAR_PAR0 + 2 * P_SIZE
+  VAR_LASTN = VAR_PAR0 + 2 * P_SIZE,  // #candidates / #slots of the frame decoded last in this launch (-1: none yet):
+  VAR_LASTS,                          // what enter_danger needs to replay that frame's std::nth_element after the fact
+  VAR_COUNT = VAR_LASTN + 4
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
 constexpr int kBinsLog = 10;
@@ -156,6 +160,7 @@ struct Work {
   int *lslot;      // kListCap: their slots
   uint32_t *bitmap;  // one bit per slot: survives (select fast path)
   int *fin, *sstack;
+  int *apos;       // K: position of every beam entry in the reference's `prefixes` array (maintained in danger mode only)
   int *vars;
 };
 
@@ -216,6 +221,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
   w.lslot = carve_ptr<int>(p, kListCap + 4); w.bitmap = carve_ptr<uint32_t>(p, 2 * ((S + 63) / 64 + 17));
   w.fin = carve_ptr<int>(p, K);
+  w.apos = carve_ptr<int>(BIG ? q : p, K);  // (read in danger mode only: HBM scratch in the wide-beam layouts)
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
   char *&r = BIG ? q : p;
@@ -229,14 +235,14 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
 // Persistent decoder state of one audio stream (the reference's DecoderState object kept alive between decode()
 // calls, ctc_beam_search_decoder.h:73-124 / ctcdecode/__init__.py:253-272), stored in HBM between launches:
 // hdr[0..7] = {frames fed so far (abs_time_step, ctc_beam_search_decoder.cpp:69), beam size, pool count, window log,
-// best key, fin valid, reserved...}; arrays = the 13 beam arrays then fin, K entries each (kStateArrays).  The node pool lives in
+// best key, danger mode (enter_danger), worst key, reserved}; arrays = the 13 beam arrays then fin, K entries each (kStateArrays).  The node pool lives in
 // the same allocation and is passed separately.
 struct StreamState {
   int *hdr;
   int *arrays;
   int finish;  // this call ends the stream: run DecoderState::decode()
 };
-enum { SH_FRAMES = 0, SH_N, SH_POOL, SH_WLOG, SH_MAXKEY, SH_FINVALID, SH_MINKEY, SH_WORDS = 8 };
+enum { SH_FRAMES = 0, SH_N, SH_POOL, SH_WLOG, SH_MAXKEY, SH_DANGER, SH_MINKEY, SH_WORDS = 8 };
 constexpr int kStateArrays = 14;                               // without the LM tier
 constexpr int kStateArraysLm = kStateArrays + kBeamArraysLm;   // with it: the LM arrays follow fin
 CTC_HD int state_arrays(int lm) { return lm ? kStateArraysLm : kStateArrays; }
@@ -329,6 +335,7 @@ struct Decoder {
   uint32_t st_maxkey = 0;
   uint32_t st_minkey = 0;  // LM tier: key of the worst score in the beam (min_cutoff, ctc_beam_search_decoder.cpp:79)
   int st_par = 0;  // which copy of the beam is current
+  int st_danger = 0;  // "danger mode" (see enter_danger): every frame replays std::nth_element and keeps apos[] / fin[]
 
   template <class P>
   CTC_HD static P *shifted(P *q, size_t bytes) { return reinterpret_cast<P *>(reinterpret_cast<char *>(q) + bytes); }
@@ -435,6 +442,85 @@ struct Decoder {
     put_f64(acc, &dst.acc_lo[k], &dst.acc_hi[k]);
   }
 
+  // ---- danger mode ---------------------------------------------------------------------------------------------------
+  // log_sum_exp (decoder_utils.h:47-54) returns "the other argument" when one is <= -FLT_MAX, so for the pair
+  // {-FLT_MAX, -inf} its value depends on the ORDER of the arguments.  A prefix whose parent is in the beam receives two
+  // contributions to log_prob_nb_cur per frame -- the repeat of its own last label (ctc_beam_search_decoder.cpp:103-106)
+  // and the extension of its parent (:108-139) -- in the order in which the two sit in the reference's `prefixes` array:
+  // the permutation std::nth_element (:150-154) left there (with a scorer: the frame's std::sort, :75-76, on top of it).
+  // That order matters only once a -inf has come into play, which needs a log-probability that is -inf / NaN or so large
+  // that a sum can overflow: lp_bad().  Rows are checked where they are staged into LDS; the first bad one raises
+  // VAR_DANGER, and from then on ("danger mode", sticky for the utterance / stream) every frame replays std::nth_element
+  // exactly and records the array order: fin[p] = beam entry at position p, apos[j] = position of entry j.  Ordinary
+  // inputs (log-softmax outputs, probabilities) never get here and pay one compare per staged value.
+  CTC_HD static bool lp_bad(float v) { return !((ctcmath::f32_to_bits(v) & 0x7fffffffu) <= 0x60ad78ecu); }  // !(|v| <= 1e20f), NaN included
+  CTC_HD bool lm_params_extreme() const {  // (alpha, beta so large that scores can overflow without any bad row)
+    if (!LM) return false;
+    const double a = lm->alpha, bt = lm->beta;
+    return !(a > -1e15 && a < 1e15 && bt > -1e15 && bt < 1e15);
+  }
+  CTC_HD void note_lp(float v) const {
+    if (CTC_RARE(lp_bad(v))) w.vars[VAR_DANGER] = 1;
+  }
+  // The order std::nth_element leaves N candidates (w.skey / w.sinfo over S slots) in: fin[p] / apos[] of the K survivors.
+  // rk[p] = DFS rank (= index in the next beam) of the survivor at array position p is left in w.surv + K as well.
+  CTC_HD void nth_element_order(int S, int N, int K) {
+    const int tid = x.tid(), nt = x.nt();
+    int *rk = w.surv + K, *ord = w.surv + 2 * K;
+    {  // the candidates in DFS (= slot) order: (48-bit key, slot) of every slot that is not a hole
+      const uint32_t *sinfo = w.sinfo;
+      const uint32_t *skey = w.skey;
+      uint64_t *ek = w.ek;
+      x.compact_slots_to(S, [=](int s) -> bool { return info_type(sinfo[s]) != T_HOLE; },
+                         [=](int r, int s) { ek[r] = (key48(skey[s], sinfo[s]) << 16) | (uint64_t)s; });
+    }
+    replay_nth_element(N, K);
+    for (int k = tid; k < K; k += nt) { rk[k] = 0; ord[k] = (int)(w.ek[k] & 0xFFFFu); }  // ord: nth_element order
+    x.sync();
+  }
+  // Called when VAR_DANGER has just been seen set: the frame decoded last (if any in this launch) was pruned without
+  // recording its permutation; its slots are still in place, so the replay is done now.
+  CTC_HD void enter_danger() {
+    const int tid = x.tid(), nt = x.nt(), K = d.K;
+    st_danger = 1;
+    select_beams();  // (the replay may stage its ranges in the block of the beam that is not current)
+    const int N = x.uni(w.vars[VAR_LASTN]), S = x.uni(w.vars[VAR_LASTS]);
+    if (N < 0) return;  // nothing decoded in this launch yet: init() / load_state() left the order of the incoming beam
+    x.sync();
+    if (N > K) {
+      nth_element_order(S, N, K);
+      int *ord = w.surv + 2 * K;
+      for (int q = tid; q < K; q += nt) {  // rank by slot = index in the current beam
+        const int mine = ord[q];
+        int r = 0;
+        for (int o = 0; o < K; ++o) r += ord[o] < mine;
+        w.fin[q] = r;
+        w.apos[r] = q;
+      }
+    } else {
+      for (int q = tid; q < st_n; q += nt) { w.fin[q] = q; w.apos[q] = q; }  // iterate_to_vec order, nothing pruned
+    }
+    x.sync();
+  }
+  CTC_HD void poll_danger() {
+    if (CTC_RARE(x.uni(w.vars[VAR_DANGER]) != 0 && !st_danger)) enter_danger();
+  }
+  // With a scorer the frame starts by sorting `prefixes` (ctc_beam_search_decoder.cpp:75-76): the contributions of this
+  // frame then come in THAT order.  apos[] := position after the sort (fin[] keeps the order std::nth_element left).
+  CTC_HD void lm_sorted_order(const Beam &b, int n) {
+    const int tid = x.tid(), nt = x.nt();
+    uint64_t *pk = w.ek;
+    for (int p = tid; p < n; p += nt) {
+      const int a = w.fin[p];
+      pk[p] = (key48(ord_f32(b.score[a]), mk_info(b.ch[a], 0, 0)) << 16) | (uint64_t)a;
+    }
+    x.sync();
+    sort_like_std(pk, n, [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); });
+    for (int p = tid; p < n; p += nt) w.apos[(int)(pk[p] & 0xFFFFu)] = p;
+    for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;  // (the sort's task lists live in the histogram)
+    x.sync();
+  }
+
   // ctc_beam_search_decoder.cpp:43-44 : root prefix, score = log_prob_b_prev = 0
   CTC_HD void init() {
     st_par = 0;
@@ -456,7 +542,10 @@ struct Decoder {
       w.vars[VAR_STATUS] = ST_OK;
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
+      w.vars[VAR_DANGER] = lm_params_extreme() ? 1 : 0; w.vars[VAR_LASTN] = -1; w.vars[VAR_LASTS] = 0;
+      w.apos[0] = 0; w.fin[0] = 0;
     }
+    st_danger = 0;
     st_n = 1; st_pool = 1; st_wlog = 32;  // first select looks at the whole key range
     st_maxkey = ord_f32(0.f);
     st_minkey = ord_f32(0.f);
@@ -474,6 +563,7 @@ struct Decoder {
     st_n = x.uni(ss.hdr[SH_N]); st_pool = x.uni(ss.hdr[SH_POOL]); st_wlog = x.uni(ss.hdr[SH_WLOG]);
     st_maxkey = (uint32_t)x.uni(ss.hdr[SH_MAXKEY]);
     st_minkey = (uint32_t)x.uni(ss.hdr[SH_MINKEY]);
+    st_danger = x.uni(ss.hdr[SH_DANGER]);
     st_par = 0;
     select_beams();
     Beam &b = w.cur;
@@ -482,7 +572,9 @@ struct Decoder {
     for (int i = tid; i < st_n; i += nt) {
       for (int a = 0; a < 9; ++a) ia[a][i] = ss.arrays[a * K + i];
       for (int a = 0; a < 4; ++a) fa[a][i] = ctcmath::bits_to_f32((uint32_t)ss.arrays[(9 + a) * K + i]);
-      w.fin[i] = ss.arrays[13 * K + i];
+      const int f = ss.arrays[13 * K + i];  // the last frame of every chunk records the order std::nth_element left:
+      w.fin[i] = f;                          // array position i holds beam entry f
+      w.apos[f] = i;
       if (LM) {
         int *la[kBeamArraysLm] = {b.lmst, b.lmcl, b.acc_lo, b.acc_hi, b.dn, b.dmlo, b.dmhi, b.dfc, b.spc_lo, b.spc_hi, b.spst, b.spcl};
         for (int a = 0; a < kBeamArraysLm; ++a) la[a][i] = ss.arrays[(kStateArrays + a) * K + i];
@@ -492,6 +584,7 @@ struct Decoder {
       w.vars[VAR_STATUS] = ST_OK;
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
+      w.vars[VAR_DANGER] = st_danger; w.vars[VAR_LASTN] = -1; w.vars[VAR_LASTS] = 0;
     }
     for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
     for (int i = tid; i < 2 * K; i += nt) { w.hit[i] = 0; w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
@@ -517,6 +610,7 @@ struct Decoder {
     if (tid == 0) {
       ss.hdr[SH_FRAMES] = frames; ss.hdr[SH_N] = st_n; ss.hdr[SH_POOL] = st_pool; ss.hdr[SH_WLOG] = st_wlog;
       ss.hdr[SH_MAXKEY] = (int)st_maxkey; ss.hdr[SH_MINKEY] = (int)st_minkey;
+      ss.hdr[SH_DANGER] = st_danger;
     }
   }
 
@@ -787,6 +881,7 @@ struct Decoder {
       full_beam = n == K;
     }
     auto cut = [&](float lp, float prefix_score) { return LM && full_beam && lp + prefix_score < min_cutoff; };
+    if (LM && CTC_RARE(st_danger)) lm_sorted_order(b, n);
 
     // ---- A1: per beam entry, from the LCP array alone: the end of its subtree range (first later entry whose LCP
     // with its predecessor is shallower than the entry), found by a wave-wide search; every entry then "paints" its
@@ -881,7 +976,8 @@ struct Decoder {
         const float sc = b.score[j], nbp = b.nbprev[j];
         float bcur = (brank >= 0 && !cut(lp_blank, sc)) ? lp_blank + sc : CTC_NEG_MAX;             // :97-101
         float nbcur = CTC_NEG_MAX;
-        if (r >= 0 && !cut(w.clp[r], sc)) nbcur = w.clp[r] + nbp;  // :103-106 -- log_sum_exp(-FLT_MAX, y) returns y (decoder_utils.h:50)
+        const bool has_rep = r >= 0 && !cut(w.clp[r], sc);
+        if (has_rep) nbcur = w.clp[r] + nbp;  // :103-106 -- log_sum_exp(-FLT_MAX, y) returns y (decoder_utils.h:50)
         const int P = w.anc[j];
         const int pr = w.pinr[j];
         if (pr >= 0) {
@@ -894,7 +990,9 @@ struct Decoder {
             }
             float logp = child_logp(P, c, lp);
             if (LM && lm_scores(c)) logp = lm_apply(logp, lm_window(b, P, c));  // :120-137
-            nbcur = lse(nbcur, logp);                                        // :138-139
+            // :138-139.  (danger mode: the parent sits before the entry in `prefixes` -> its extension was added first)
+            if (CTC_RARE(st_danger) && has_rep && w.apos[P] < w.apos[j]) nbcur = lse(logp, nbcur);
+            else nbcur = lse(nbcur, logp);
           }
         }
         w.b_new[j] = bcur;
@@ -1027,6 +1125,7 @@ struct Decoder {
       exact = true;
 #endif
       if (CTC_RARE(last)) exact = true;  // decode() sorts the array exactly as nth_element left it (:164-190)
+      if (CTC_RARE(st_danger)) exact = true;  // the next frame adds its contributions in that order (enter_danger)
     }
     x.mark(5);
 
@@ -1034,16 +1133,7 @@ struct Decoder {
     // threshold; when the outcome depends on it, an exact replay of std::nth_element followed by a ranking by slot.
     const int n_new = N < K ? N : K;
     if (CTC_RARE(exact)) {
-      {  // the candidates in DFS (= slot) order: (48-bit key, slot) of every slot that is not a hole
-        const uint32_t *sinfo = w.sinfo;
-        const uint32_t *skey = w.skey;
-        uint64_t *ek = w.ek;
-        x.compact_slots_to(S, [=](int s) -> bool { return info_type(sinfo[s]) != T_HOLE; },
-                           [=](int r, int s) { ek[r] = (key48(skey[s], sinfo[s]) << 16) | (uint64_t)s; });
-      }
-      replay_nth_element(N, K);
-      for (int k = tid; k < K; k += nt) { rk[k] = 0; ord[k] = (int)(w.ek[k] & 0xFFFFu); }  // ord: nth_element order
-      x.sync();
+      nth_element_order(S, N, K);
       for (int q = tid; q < K; q += nt) {  // rank by slot
         const int mine = ord[q];
         int r = 0;
@@ -1096,7 +1186,10 @@ struct Decoder {
           for (int i = t0; i < 2 * n; i += tstep) w.hit[i] = 0;
           int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;
           for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }
-          if (t0 == 0) reset_pvars(pvars(in.t + 1));
+          if (t0 == 0) {
+            reset_pvars(pvars(in.t + 1));
+            w.vars[VAR_LASTN] = N; w.vars[VAR_LASTS] = S;  // (enter_danger)
+          }
         }
       }
       for (int k = roles ? tid - role * ne : tid; k < n_new && role < nroles; k += roles ? ne : nt) {
@@ -1173,8 +1266,12 @@ struct Decoder {
       x.wave_max_to(&pv[P_NMAXKEY], kloc);
       if (LM) x.wave_min_to(&pv[P_NMINKEY], kmin);
     }
-    if (CTC_RARE(last)) {  // the order std::nth_element left the survivors in (identity when it was not called)
-      for (int q = tid; q < n_new; q += nt) w.fin[q] = exact ? rk[q] : q;
+    if (CTC_RARE(last || st_danger)) {  // the order std::nth_element left the survivors in (identity when it was not called)
+      for (int q = tid; q < n_new; q += nt) {
+        const int r = exact ? rk[q] : q;
+        w.fin[q] = r;
+        w.apos[r] = q;
+      }
     }
     // un-register this step's candidates from the rank table -- only once every wave has finished emitting (the emit
     // loop above still looks characters up in it)
@@ -1182,7 +1279,7 @@ struct Decoder {
       x.sync();
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
     }
-    if (stage && tid < d.V) w.clpbuf[((in.t + 1) & 1) * d.Vc_max + tid] = stage_val;
+    if (stage && tid < d.V) { w.clpbuf[((in.t + 1) & 1) * d.Vc_max + tid] = stage_val; note_lp(stage_val); }
     x.mark(7);
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
     x.mark(9);
@@ -1207,6 +1304,7 @@ struct Decoder {
     x.dump(in.t, n_new, nb.node, nb.dep, nb.lcp, nb.score);
     x.mark(8);
     st_par ^= 1;
+    if (IDENT) poll_danger();  // the row staged above is the next frame's (the other modes stage -- and poll -- between steps)
     return ST_OK;
   }
 
@@ -1460,8 +1558,9 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     }
   }
   if (IDENT && prefetch && len > 0) {  // frame 0 goes straight to LDS; from then on step() stages frame t+1
-    if (tid < d.V) w.clpbuf[(t0 & 1) * d.Vc_max + tid] = pre_lp;
+    if (tid < d.V) { w.clpbuf[(t0 & 1) * d.Vc_max + tid] = pre_lp; dec.note_lp(pre_lp); }
     x.sync();
+    dec.poll_danger();
   }
   for (int t = 0; t < len; ++t) {
     StepIn in;
@@ -1482,14 +1581,15 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
         stage = t + 1 < len;
         if (stage && tid < d.V) pre_lp = rows[(size_t)(t + 1) * d.V + tid];  // consumed at the end of this frame
       } else {
-        for (int r = tid; r < d.V; r += nt) w.clp[r] = rows[(size_t)t * d.V + r];
+        for (int r = tid; r < d.V; r += nt) { const float v = rows[(size_t)t * d.V + r]; w.clp[r] = v; dec.note_lp(v); }
         x.sync();
+        dec.poll_danger();
       }
     } else {
       in.identity = 0;
       if (prefetch) {
         in.Vc = x.uni(pre_cnt);
-        if (tid < in.Vc) { w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid; }
+        if (tid < in.Vc) { w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid; dec.note_lp(pre_lp); }
         if (t + 1 < len) {
           pre_cnt = pr->cnt[t + 1];
           if (tid < width) { pre_ch = pr->ch[(size_t)(t + 1) * width + tid]; pre_lp = pr->lp[(size_t)(t + 1) * width + tid]; }
@@ -1498,13 +1598,16 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
         in.Vc = x.uni(pr->cnt[t]);
         for (int r = tid; r < in.Vc; r += nt) {
           const int c = pr->ch[(size_t)t * width + r];
+          const float v = pr->lp[(size_t)t * width + r];
           w.cch[r] = c;
-          w.clp[r] = pr->lp[(size_t)t * width + r];
+          w.clp[r] = v;
           w.rank_of[c] = (int16_t)r;
+          dec.note_lp(v);
         }
       }
       x.sync();
       in.blank_rank = x.uni((int)w.rank_of[blank]);
+      dec.poll_danger();
     }
     x.tick();
     x.mark(10);

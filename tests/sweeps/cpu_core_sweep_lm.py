@@ -19,6 +19,10 @@ while time.time() - t0 < budget:
     seed = int(rng.integers(0, 1 << 30))
     lp = ou.synth_logprobs(2, T, V, seed, quant=quant)
     lp[:, :, labels.index(" ")] += np.float32(rng.choice([0.0, 1.0, 2.0]))
+    if "--degenerate" in sys.argv:  # whole frames of -inf, overflowing sums ... (tests/degenerate_util.py)
+        import degenerate_util as du
+        meta, lp = du.make_case(rng, V=V, labels_space=labels.index(" "))
+        K, T, seed = meta["K"], meta["T"], (meta["seed"], meta["kind"])
     top_n = int(rng.choice([40, 40, 5]))
     sl = rng.integers(0, T + 3, size=2).astype(np.int32) if n % 5 == 0 else None
     kw = dict(seq_lens=sl, beam=K, cutoff_top_n=top_n, blank_id=0)

@@ -14,11 +14,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--degenerate", action="store_true", help="whole frames of -inf, overflowing sums ... (tests/degenerate_util.py)")
     a = ap.parse_args()
     import numpy as np
     import torch
 
     import ctcdecode_amd
+    import degenerate_util as du
     import oracle_util as ou
 
     rng = np.random.default_rng(a.seed)
@@ -37,6 +39,10 @@ def main():
         if K * (min(V, top_n) + 2) > 60000:
             continue
         lp = ou.synth_logprobs(B, T, V, 7000 + it, quant=quant, blank_bias=bias, blank_id=blank)
+        if a.degenerate:
+            meta, lp = du.make_case(rng, V=V if V <= 29 else 29, T=max(T, 2) if T < 120 else 60)
+            K, blank, B = min(K, 128), meta["blank"], 2
+            V, T = lp.shape[2], lp.shape[1]
         sl = rng.integers(0, T + 5, size=B).astype(np.int32) if it % 3 == 0 else None
         kw = dict(beam=K, blank_id=blank, cutoff_top_n=top_n, cutoff_prob=cutoff)
         want = ou.decode(lp, sl, which="restated", want_stats=True, **kw)

@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--degenerate", action="store_true", help="whole frames of -inf, overflowing sums ... (tests/degenerate_util.py)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -41,6 +42,10 @@ def main():
         lp = ou.synth_logprobs(B, T, V, 17000 + it, quant=quant, blank_id=blank)
         if " " in labels:
             lp[:, :, labels.index(" ")] += np.float32(rng.choice([0.0, 1.0, 2.0]))
+        if a.degenerate and " " in labels and blank == 0:
+            import degenerate_util as du
+            meta, lp = du.make_case(rng, V=V, labels_space=labels.index(" "))
+            B, T, K, prob_in = 2, lp.shape[1], min(K, 128), False
         x = np.exp(lp).astype(np.float32) if prob_in else lp
         sl = rng.integers(0, T + 5, size=B).astype(np.int32) if it % 3 == 0 else None
         path = os.path.join(DATA, arpa)

@@ -5,6 +5,7 @@ check the same source running as a workgroup."""
 import numpy as np
 import pytest
 
+import degenerate_util as du
 import golden_util as gu
 import oracle_util as ou
 
@@ -80,6 +81,52 @@ def test_core_edge_cases(name, lp, kw):
 @pytest.mark.parametrize("name,lp,kw", EDGE, ids=[e[0] for e in EDGE])
 def test_oracle_edge_cases_against_live_reference(name, lp, kw):
     ou.assert_same(ou.decode(lp, which="restated", **kw), ou.decode(lp, which="reference", **kw), name)
+
+
+def _degenerate_sweep(n, seed, reference_every=0, prune=False, chunked=False):
+    rng = np.random.default_rng(seed)
+    kinds = set()
+    for it in range(n):
+        meta, lp = du.make_case(rng)
+        kw = dict(beam=meta["K"], blank_id=meta["blank"])
+        sl = None
+        if prune:
+            kw.update(cutoff_top_n=int(rng.choice([40, max(1, meta["V"] // 2), 3, 1])), cutoff_prob=float(rng.choice([1.0, 1.0, 0.9, 0.5])))
+            sl = rng.integers(0, meta["T"] + 3, size=2).astype(np.int32) if it % 3 == 0 else None
+        want = ou.decode(lp, sl, which="restated", **kw)
+        if chunked:
+            bounds = sorted(set(int(v) for v in rng.integers(0, meta["T"] + 1, size=int(rng.integers(0, 6)))))
+            got = ou.decode_core_host_chunked(lp, bounds, **kw)
+        else:
+            got = ou.decode_core_host(lp, sl, **kw)
+        ou.assert_same(want, got, "degenerate case %d %s %s" % (it, meta, kw))
+        if reference_every and it % reference_every == 0 and ou.have_reference():
+            ou.assert_same(want, ou.decode(lp, sl, which="reference", **kw), "oracle vs live reference, case %d %s" % (it, meta))
+        kinds.add(meta["kind"])
+    assert len(kinds) == len(du.KINDS)
+
+
+def test_core_degenerate_inputs_follow_the_reference_argument_order():
+    """Whole frames of -inf, sums that overflow, -inf tail padding without seq_lens: log_sum_exp(-FLT_MAX, -inf) depends
+    on the order of its arguments (decoder_utils.h:47-54), i.e. on the permutation std::nth_element left in `prefixes`
+    (ctc_beam_search_decoder.cpp:87-142,150-154).  Round 2 always added the repeat contribution first and differed from
+    the reference on 20-90 % of such inputs; danger mode (beam_core.h enter_danger) replays the order."""
+    _degenerate_sweep(300, 101, reference_every=3)
+
+
+def test_core_degenerate_inputs_pruned_and_ragged():
+    _degenerate_sweep(150, 102, reference_every=5, prune=True)
+
+
+def test_core_degenerate_inputs_streamed():
+    """Danger mode is part of the parked stream state: any chunking of a degenerate utterance equals the one-shot result."""
+    _degenerate_sweep(150, 103, chunked=True)
+
+
+@pytest.mark.parametrize("level", ["1", "2"])
+def test_core_degenerate_inputs_hbm_scratch_layouts(monkeypatch, level):
+    monkeypatch.setenv("CTC_HOST_BIG", level)
+    _degenerate_sweep(60, 104 + int(level))
 
 
 @pytest.mark.parametrize("level", ["1", "2"])

@@ -257,6 +257,52 @@ def test_edge_cases_on_gpu(torch_mod):
         ou.assert_same(_with_nres(got, want), want, name)
 
 
+@pytest.mark.parametrize("threads", [128, 1024])
+def test_degenerate_inputs_follow_the_reference_argument_order(torch_mod, threads):
+    """Whole frames of -inf, sums that overflow, -inf tail padding without seq_lens: the kernel's danger
+    mode replays std::nth_element every frame and adds a prefix's two contributions in the order of the reference's
+    `prefixes` array (decoder_utils.h:47-54, ctc_beam_search_decoder.cpp:87-142,150-154).  Offline, both workspace layouts,
+    and streamed with random chunking; every fourth case also against the live reference when it is built."""
+    import ctcdecode_amd
+    import degenerate_util as du
+
+    rng = np.random.default_rng(2024 + threads)
+    kinds = set()
+    for it in range(60):
+        meta, lp = du.make_case(rng)
+        K, blank, T, V = meta["K"], meta["blank"], meta["T"], meta["V"]
+        kw = dict(beam=K, blank_id=blank)
+        want = ou.decode(lp, which="restated", **kw)
+        if it % 4 == 0 and ou.have_reference():
+            ou.assert_same(want, ou.decode(lp, which="reference", **kw), "oracle vs live reference %s" % meta)
+        if it % 3 != 2:
+            got = _decode(torch_mod, lp, threads=threads, fixed_layout=it % 3 == 0, **kw)
+        else:
+            dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], beam_width=K, blank_id=blank, log_probs_input=True)
+            dec.set_threads(threads)
+            states = [ctcdecode_amd.DecoderState(dec) for _ in range(2)]
+            bounds = [0] + sorted(set(int(v) for v in rng.integers(0, T + 1, size=int(rng.integers(0, 4))))) + [T]
+            x = torch_mod.from_numpy(lp)
+            for i in range(len(bounds) - 1):
+                out, sc, ts, ln = dec.decode(x[:, bounds[i]:bounds[i + 1]], states, [i == len(bounds) - 2] * 2)
+            got = dict(tokens=np.zeros((2, K, T), np.int32), timesteps=np.zeros((2, K, T), np.int32), scores=sc.numpy(), lens=ln.numpy())
+            got["tokens"][:, : out.shape[1], : out.shape[2]] = out.numpy()
+            got["timesteps"][:, : out.shape[1], : out.shape[2]] = ts.numpy()
+        ou.assert_same(_with_nres(got, want), want, "degenerate case %d %s" % (it, meta))
+        kinds.add(meta["kind"])
+    assert len(kinds) == len(du.KINDS)
+
+
+def test_degenerate_frames_inside_the_north_star_shape(torch_mod):
+    """-inf tail padding without seq_lens and a -inf frame in the middle at full size (T=1000, V=29, beam 100)."""
+    lp = ou.synth_logprobs(4, 1000, 29, 77)
+    lp[0, 700:, :] = -np.inf
+    lp[1, 500, :] = -np.inf
+    lp[2, 100:104, :] = -3.0e38
+    want = ou.decode(lp, beam=100, which="reference" if ou.have_reference() else "restated")
+    ou.assert_same(_with_nres(_decode(torch_mod, lp, beam=100), want), want)
+
+
 def test_host_pointer_entry_point(torch_mod):
     """ctcd_beam_decode_host: the entry point a maintainer of the reference would bind in place of paddle_beam_decode
      -- CPU buffers in, CPU buffers out, through the raw C ABI."""

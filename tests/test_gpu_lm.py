@@ -51,6 +51,24 @@ def test_lm_reference_fixtures(torch_mod, name, threads):
     ou.assert_same(_with_nres(got, want), want, name)
 
 
+def test_lm_degenerate_inputs(torch_mod):
+    """Whole frames of -inf / overflowing sums with the scorer: contributions in the order of the frame's
+    std::sort (ctc_beam_search_decoder.cpp:75-76)."""
+    import degenerate_util as du
+
+    rng = np.random.default_rng(99)
+    models = [("abcd_words.arpa", ["_", "a", "b", "c", "d", "'", " "]), ("chars.arpa", ["_", "a", "b", "c", "d", "'", "é", " "]), ("test.arpa", LABELS29)]
+    for it in range(45):
+        arpa, labels = models[it % 3]
+        meta, lp = du.make_case(rng, V=len(labels), labels_space=labels.index(" "))
+        lm = dict(labels=labels, lm_path=os.path.join(DATA, arpa), alpha=float(rng.choice([0.0, 0.3, 1.0, 2.5])), beta=float(rng.choice([-1.0, 0.0, 0.5, 1.5])))
+        kw = dict(beam=meta["K"], cutoff_top_n=int(rng.choice([40, 40, 5])), blank_id=0)
+        sc = ou.Scorer(lm["alpha"], lm["beta"], lm["lm_path"], labels, "restated")
+        want = ou.decode(lp, scorer=sc, **kw)
+        got, _ = _decode(torch_mod, lp, lm, threads=[0, 256, 512][it % 3], **kw)
+        ou.assert_same(_with_nres(got, want), want, "LM degenerate case %d %s %s" % (it, arpa, meta))
+
+
 def test_reference_lm_golden_strings(torch_mod):
     """tests/test_decode.py:55-64,93-115,141-159 of the reference: "a a" with test.arpa -- offline, online, online in two calls."""
     import ctcdecode_amd

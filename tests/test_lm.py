@@ -180,6 +180,30 @@ def test_product_core_with_lm_random_sweep():
                        "case %d %s K=%d T=%d alpha=%g beta=%g q=%s" % (it, arpa, K, T, alpha, beta, quant))
 
 
+def test_product_core_with_lm_degenerate_inputs():
+    """Whole frames of -inf / overflowing sums with a scorer: the order of a prefix's two contributions then follows the
+    frame's std::sort (ctc_beam_search_decoder.cpp:75-76) on top of std::nth_element's permutation.  The restated oracle
+    is checked against the live reference on every third case."""
+    import degenerate_util as du
+
+    rng = np.random.default_rng(12)
+    models = [("abcd_words.arpa", ["_", "a", "b", "c", "d", "'", " "]), ("chars.arpa", ["_", "a", "b", "c", "d", "'", "é", " "]),
+              ("test.arpa", LABELS29)]
+    for it in range(150):
+        arpa, labels = models[it % 3]
+        meta, lp = du.make_case(rng, V=len(labels), labels_space=labels.index(" "))
+        alpha, beta = float(rng.choice([0.0, 0.3, 1.0, 2.5])), float(rng.choice([-1.0, 0.0, 0.5, 1.5]))
+        kw = dict(beam=meta["K"], cutoff_top_n=int(rng.choice([40, 40, 5])), blank_id=0)
+        path = os.path.join(DATA, arpa)
+        sc = ou.Scorer(alpha, beta, path, labels, "restated")
+        want = ou.decode(lp, scorer=sc, **kw)
+        what = "case %d %s %s alpha=%g beta=%g" % (it, arpa, meta, alpha, beta)
+        ou.assert_same(ou.decode_core_host_lm(lp, alpha, beta, path, labels, **kw), want, what)
+        if it % 3 == 0 and ou.have_reference():
+            ref = ou.Scorer(alpha, beta, path, labels, "reference")
+            ou.assert_same(ou.decode(lp, scorer=ref, which="reference", **kw), want, what + " (oracle vs live reference)")
+
+
 @pytest.mark.parametrize("name", gu.lm_names())
 def test_restatement_and_product_core_match_committed_lm_fixtures(name):
     args, lm, want = gu.load_lm(name)
