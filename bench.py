@@ -11,6 +11,11 @@ batch i+1 (ctcdecode_amd.distributed.ResultGatherer), all gathers complete befor
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: this process launches the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+    python bench.py --config {1,2,4} ...     BASELINE.json's other multi-GPU configurations (default 1 = the headline):
+        2 = configs[2]: B=2048 utterances, beam 500, T=2000, no LM -- STRONG scaling: the 2048 utterances are cut into
+            contiguous blocks of ceil(2048 / N) (ctcdecode_amd.distributed.shard_bounds), one block per rank;
+        4 = configs[4]: B=1024, beam 100, T=1500, with the LM scorer on tests/data/test.arpa (alpha 0.5, beta 1.0), strong scaling.
+
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field).
 """
 import argparse
@@ -46,10 +51,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
-    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--config", type=int, choices=[1, 2, 4], default=1, help="BASELINE.json configs[i]: 1 = headline (weak scaling, 256 utterances per GPU); 2, 4 = strong scaling of the named total batch")
+    ap.add_argument("--batch", type=int, default=0, help="config 1: utterances per GPU (default 256); configs 2 / 4: TOTAL utterances (default 2048 / 1024)")
+    ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--vocab", type=int, default=29)
-    ap.add_argument("--beam", type=int, default=100)
+    ap.add_argument("--beam", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = library default)")
     ap.add_argument("--gather", choices=["overlap", "sync", "none"], default="overlap",
                     help="N>1: gather the results to rank 0 inside the timed region; 'overlap' lets batch i's gather "
@@ -67,23 +73,27 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(lp_np, beam, target_s):
+def cpu_baseline(lp_np, beam, target_s, lm=None):
     """The reference CPU path (oracle/_ref = its own sources; falls back to this repo's restatement = "port") timed on
-    this box's host cores with num_processes = os.cpu_count(), on a bounded sample of the same workload."""
+    this box's host cores with num_processes = os.cpu_count(), on a bounded sample of the same workload.
+    lm = (labels, arpa path, alpha, beta): with the reference's scorer (configs[4])."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_util as ou
 
     cores = os.cpu_count() or 1
     which, kind = ("reference", "reference") if ou.have_reference() else ("restated", "port")
+    kw = dict(beam=beam, cutoff_top_n=lp_np.shape[2], which=which, threads=cores)
+    if lm:
+        kw["scorer"] = ou.Scorer(lm[2], lm[3], lm[1], lm[0], which)
     n0 = min(lp_np.shape[0], max(cores, 4))
     t0 = time.perf_counter()
-    ou.decode(lp_np[:n0], beam=beam, cutoff_top_n=lp_np.shape[2], which=which, threads=cores)
+    ou.decode(lp_np[:n0], **kw)
     dt = time.perf_counter() - t0
     n, best = n0, n0 / dt
     n1 = min(lp_np.shape[0], int(best * target_s) // cores * cores)
     if n1 > n0 and dt < target_s * 0.6:
         t0 = time.perf_counter()
-        ou.decode(lp_np[:n1], beam=beam, cutoff_top_n=lp_np.shape[2], which=which, threads=cores)
+        ou.decode(lp_np[:n1], **kw)
         dt = time.perf_counter() - t0
         n, best = n1, n1 / dt
     return {"value": round(best, 3), "unit": "utterances/s", "cores": cores, "kind": kind,
@@ -232,13 +242,37 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    B, T, V, K = a.batch, a.frames, a.vocab, a.beam
+    # BASELINE.json configs[a.config]: (total or per-GPU batch, frames, beam, scaling, LM)
+    cfg = {1: dict(batch=256, frames=1000, beam=100, scaling="weak", lm=None),
+           2: dict(batch=2048, frames=2000, beam=500, scaling="strong", lm=None),
+           4: dict(batch=1024, frames=1500, beam=100, scaling="strong", lm=(os.path.join(ROOT, "tests", "data", "test.arpa"), 0.5, 1.0))}[a.config]
+    T, V, K = a.frames or cfg["frames"], a.vocab, a.beam or cfg["beam"]
+    strong = cfg["scaling"] == "strong"
+    B_total = (a.batch or cfg["batch"]) * (1 if strong else world)
+    if strong:  # contiguous blocks of ceil(B / world) utterances, as decode_sharded cuts them
+        from ctcdecode_amd.distributed import shard_bounds
+
+        lo, hi = shard_bounds(B_total, world, rank)
+        B = hi - lo
+    else:
+        B = a.batch or cfg["batch"]
+    labels = [str(i) for i in range(V)]
+    dec_kw = {}
+    if cfg["lm"]:  # blank, apostrophe, space, a..z: the words of tests/data/test.arpa can be spelled
+        assert V == 29
+        labels = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
+        dec_kw = dict(model_path=cfg["lm"][0], alpha=cfg["lm"][1], beta=cfg["lm"][2])
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    lp_cpu = torch.randn((B, T, V), generator=g, dtype=torch.float32).log_softmax(-1)
+    lp_cpu = torch.randn((max(B, 1), T, V), generator=g, dtype=torch.float32).log_softmax(-1)[:B]
     lp = lp_cpu.to(dev)
-    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=V, beam_width=K, blank_id=0, log_probs_input=True, device=dev)
-    if a.threads:
-        dec.set_threads(a.threads)
+
+    def make_decoder():
+        d = ctcdecode_amd.CTCBeamDecoder(labels, cutoff_top_n=V, beam_width=K, blank_id=0, log_probs_input=True, device=dev, **dec_kw)
+        if a.threads:
+            d.set_threads(a.threads)
+        return d
+
+    dec = make_decoder()
     dec.set_timing(True)
 
     gatherer = None
@@ -252,14 +286,12 @@ def main():
     if use_dist and a.gather != "none":
         from ctcdecode_amd.distributed import make_gatherer
 
-        gatherer = make_gatherer(a.gather_format, B, K, T, V, dev, dst=0, depth=2, decoder=dec,
+        per = (B_total + world - 1) // world if strong else B  # the padded shard size of the "full" format
+        gatherer = make_gatherer(a.gather_format, per, K, T, V, dev, dst=0, depth=2, decoder=dec,
                                  stream=torch.cuda.Stream(device=dev) if lookahead else None)
     decs = [dec]
     if lookahead:
-        dec2 = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=V, beam_width=K, blank_id=0, log_probs_input=True, device=dev)
-        if a.threads:
-            dec2.set_threads(a.threads)
-        decs.append(dec2)
+        decs.append(make_decoder())
     pending = []  # [(decoder, ticket)] of the batch whose kernel is queued but whose results the host has not handled yet
     nlaunch = [0]
 
@@ -310,18 +342,24 @@ def main():
     # kernel duration of the last timed launch (HIP events on the launch stream); averaged over a few extra launches
     # OUTSIDE the timed region so the event reads do not perturb it
     durs = []
-    for _ in range(max(3, min(a.steps, 10))):
+    for _ in range(max(3, min(a.steps, 10)) if a.config == 1 else 2):
         res = dec.decode_device(lp, None, check=False)
         torch.cuda.synchronize()
         durs.append(dec.last_kernel_ms())
     ctcdecode_amd._native.check(ctcdecode_amd._native.lib.ctcd_check_status(dec._handle, B))
     kern_ms = float(np.mean(durs))
+    kern_all = [kern_ms]
+    if use_dist:  # every rank's kernel duration (rank order)
+        kt = torch.tensor([kern_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        parts = [torch.zeros_like(kt) for _ in range(world)]
+        dist.all_gather(parts, kt)
+        kern_all = [float(p.item()) for p in parts]
 
     out_len = res[3]
     # ALGORITHMIC bytes per utterance: read T*V*4 of input + write the valid token/timestep prefixes
     # (8 bytes per emitted label per beam) + scores and lengths (8 bytes per beam) + 4 (seq_len)
     alg_bytes = B * (T * V * 4 + 8 * K + 4) + 8 * int(out_len.sum().item())
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     traffic, traffic_src = None, None
     if os.path.exists(a.traffic_json):
         try:
@@ -333,25 +371,31 @@ def main():
     if rank == 0:
         floor = sum(FRAME_FLOOR.values())
         frame_clocks = kern_ms * 1e-3 / T * SHADER_GHZ * 1e9
+        workload = {1: "BASELINE.json configs[1]: CTC prefix beam search, no LM, log-softmax of N(0,1) logits",
+                    2: "BASELINE.json configs[2]: B=2048 batch-sharded, beam 500, T=2000, no LM, compact RCCL gather",
+                    4: "BASELINE.json configs[4]: B=1024 batch-sharded, beam 100, T=1500, LM scorer on tests/data/test.arpa (alpha 0.5, beta 1.0)"}[a.config]
         line = {
-            "metric": "utterances/sec at B=256 T=1000 V=29 beam=100",
-            "value": round(world * B * a.steps / elapsed, 3),
+            "metric": "utterances/sec at B=256 T=1000 V=29 beam=100" if a.config == 1 else
+                      "utterances/sec at B=%d T=%d V=%d beam=%d%s (BASELINE.json configs[%d])" % (B_total, T, V, K, " with the LM scorer" if cfg["lm"] else "", a.config),
+            "value": round(B_total * a.steps / elapsed, 3),
             "unit": "utterances/s",
-            "n_gpus": min(world, ndev), "steps": a.steps, "warmup": a.warmup,
+            # ranks that took part in the run (torch.distributed's world size once the process group is up)
+            "n_gpus": dist.get_world_size() if use_dist else 1, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: CTC prefix beam search, no LM, log-softmax of N(0,1) logits",
+            "config": {"workload": workload,
                        "utterances_per_gpu": B, "frames": T, "vocab": V, "beam_width": K, "cutoff_top_n": V,
-                       "global_batch": world * B, "ranks": world,
+                       "global_batch": B_total, "ranks": world, "devices_visible": ndev,
                        "parallelism": "batch-sharded x%d, gather=%s/%s, backend=%s" % (world, a.gather, a.gather_format, backend) if use_dist else "single GPU",
                        "threads_per_workgroup": a.threads or "default"},
             "kernel_ms": round(kern_ms, 4),
+            "kernel_ms_per_rank": [round(v, 4) for v in kern_all],
             "us_per_frame": round(kern_ms * 1e3 / T, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 6), "traffic": traffic,
+                         "frac": round(achieved / 8000.0, 6), "traffic": traffic if a.config == 1 else None,
                          "traffic_source": ("constant from profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command), not measured in this run" % traffic_src) if traffic else None,
-                         "traffic_ratio": round(traffic / alg_bytes, 2) if traffic else None,
+                         "traffic_ratio": round(traffic / alg_bytes, 2) if traffic and a.config == 1 else None,
                          "memset_bytes_outside_kernel": 2 * B * K * T * 4 + 2 * B * K * 4,
                          "kernel": "ctc_beam_decode_kernel", "algorithmic_bytes_per_launch": alg_bytes},
             # the recurrence is latency-bound, not HBM-bound: distance from the critical-path floor of one frame
@@ -360,7 +404,7 @@ def main():
         }
         if shared:
             line["config"]["oversubscribed"] = "%d ranks on %d device(s): a dry run of the N-rank path, not a scaling number" % (world, ndev)
-        if world == 1 and not a.no_extras:
+        if world == 1 and not a.no_extras and a.config == 1:
             e2e = time_e2e(torch, dec, lp_cpu)
             line["e2e"] = {"what": "drop-in decode(): CPU float32 tensor in, four CPU tensors out (SURVEY 8(d) primary definition)",
                            "ms_per_batch": round(e2e * 1e3, 3), "value": round(B / e2e, 1), "unit": "utterances/s"}
@@ -374,8 +418,8 @@ def main():
                 line["other_configs"] = other_configs(torch, ctcdecode_amd, dev)
             except Exception as e:
                 line["other_configs"] = {"error": str(e)[:300]}
-        if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(lp_cpu.numpy(), K, a.cpu_seconds)
+        if not a.no_cpu_baseline:  # (rank 0's host cores, on rank 0's own shard; outside the timed region)
+            line["cpu_baseline"] = cpu_baseline(lp_cpu.numpy(), K, a.cpu_seconds, lm=(labels,) + cfg["lm"] if cfg["lm"] else None)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier(device_ids=[dev.index]) if backend == "nccl" else dist.barrier()

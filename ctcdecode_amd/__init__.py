@@ -84,7 +84,7 @@ class CTCBeamDecoder(object):
         h = ctypes.c_void_p()
         _native.check(_native.lib.ctcd_create(ctypes.byref(h), self._device.index))
         self._handle = h
-        if model_path is not None:  # ctcdecode/__init__.py:47-50
+        if model_path:  # ctcdecode/__init__.py:47-50 (`if model_path:`: None and "" both mean no scorer)
             self._scorer = _Scorer(alpha, beta, model_path, self._labels, self._device.index)
 
     def set_threads(self, n):
@@ -224,7 +224,9 @@ class CTCBeamDecoder(object):
                 cnt.data_ptr(), cap, scores.data_ptr(), out_len.data_ptr(), None, stream))
             _native.check(_native.lib.ctcd_check_status(self._handle, B))
             n = int(cnt.item())
-        return hdr, ent, self._c_labels[:n], scores, out_len
+        # (an owned copy: the per-decoder buffer is overwritten by this decoder's next call, possibly while an asynchronous
+        #  gather of this batch still reads the labels)
+        return hdr, ent, self._c_labels[:n].clone(), scores, out_len
 
     def decode_compact_async(self, probs, seq_lens=None):
         """``decode_compact`` without waiting: the kernel, then the copies of the status words and of the label count into
@@ -273,7 +275,9 @@ class CTCBeamDecoder(object):
             b = int((st != 0).nonzero()[0])
             raise _native.NativeError("ctcdecode_amd: decoder status %d for item %d" % (int(st[b]), b))
         n = int(ticket["cnt_host"][0])
-        return ticket["hdr"], ticket["ent"], ticket["labels"][:n], ticket["scores"], ticket["lens"]
+        with torch.cuda.device(self._device):
+            labels = ticket["labels"][:n].clone()  # owned: the decoder's label buffer belongs to its next call
+        return ticket["hdr"], ticket["ent"], labels, ticket["scores"], ticket["lens"]
 
     def expand_compact(self, hdr, ent, labels, T):
         """(c_hdr, c_ent, c_labels) of any number of items -> (output [B,K,T], timesteps [B,K,T]) in HBM."""
@@ -337,6 +341,10 @@ class OnlineCTCBeamDecoder(object):
         self._handle = h
         if model_path:  # ctcdecode/__init__.py:183-187
             self._scorer = _Scorer(alpha, beta, model_path, self._labels, self._device.index)
+
+    def set_threads(self, n):
+        """Test hook (as CTCBeamDecoder.set_threads): threads per workgroup, 0 = the library's choice."""
+        _native.check(_native.lib.ctcd_set_threads(self._handle, int(n)))
 
     def decode(self, probs, states, is_eos_s, seq_lens=None):
         """Same contract as ctcdecode/__init__.py:189-238: returns CPU tensors (beam_results[B, R, L], beam_scores[B, K],

@@ -15,7 +15,9 @@ LIB_DIR = os.path.join(HERE, "_lib")
 # CTCDECODE_AMD_LIB: load another build of the library (kernel experiments: tools/build_variants.sh)
 LIB_PATH = os.environ.get("CTCDECODE_AMD_LIB") or os.path.join(LIB_DIR, "libctcdecode_amd.so")
 SOURCES = ["ctcdecode_amd.hip"]
-HEADERS = ["beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h", "compact_results.h", os.path.join("..", "..", "include", "ctcdecode_amd.h")]
+KERNEL_SOURCE = "decode_kernels.hip"  # compiled once per group of kernel instantiations (decode_kernel.h CTC_KERNEL_LIST), in parallel
+KERNEL_GROUPS = 12
+HEADERS = ["decode_kernels.hip", "decode_kernel.h", "beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h", "compact_results.h", os.path.join("..", "..", "include", "ctcdecode_amd.h")]
 ROCM = os.environ.get("ROCM_HOME", "/opt/rocm")
 
 
@@ -43,22 +45,34 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=False, defines=(), out=None):
+def build(force=False, verbose=False, defines=(), out=None, jobs=None):
     """defines/out: build a variant of the library (kernel experiments) next to the product one."""
+    from concurrent.futures import ThreadPoolExecutor
+
     lib_path = out or LIB_PATH
     if not out and not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    for src in SOURCES:
-        obj = os.path.splitext(lib_path)[0] + "." + os.path.splitext(src)[0] + ".o" if out else os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-               "-Wno-unused-result"] + ["-D" + d for d in defines] + os.environ.get("CTCD_EXTRA_HIPCC_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
+    stem = os.path.splitext(lib_path)[0] if out else os.path.join(LIB_DIR, "obj")
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+            "-Wno-unused-result"] + ["-D" + d for d in defines] + os.environ.get("CTCD_EXTRA_HIPCC_FLAGS", "").split()
+    if verbose:
+        base.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    quick = any(d.split("=")[0] == "CTC_QUICK_BUILD" for d in defines)
+    units = [(os.path.join(CSRC, src), stem + "." + os.path.splitext(src)[0] + ".o", []) for src in SOURCES]
+    units += [(os.path.join(CSRC, KERNEL_SOURCE), "%s.kernels%02d.o" % (stem, g), ["-DCTC_KERNEL_GROUP=%d" % g])
+              for g in range(2 if quick else KERNEL_GROUPS)]
+
+    def compile_one(u):
+        src, obj, extra = u
+        cmd = base + extra + ["-c", src, "-o", obj]
         if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, units))
     tl = _torch_lib_dir()
     libdirs = ([tl] if tl else []) + [os.path.join(ROCM, "lib")]
     link = ["g++", "-shared", "-o", lib_path] + objs

@@ -126,6 +126,7 @@ enum {
   P_NPIN = 0, P_LCOUNT, P_NMAXKEY, P_NMINKEY, P_NCAND, P_SIZE = 8,
   VAR_LASTN = VAR_PAR0 + 2 * P_SIZE,  // #candidates / #slots of the frame decoded last in this launch (-1: none yet):
   VAR_LASTS,                          // what enter_danger needs to replay that frame's std::nth_element after the fact
+  VAR_LASTNENT, VAR_LASTBRANK,        // ... and (LAZY layouts) to rebuild its info words: #beam entries, rank of the blank
   VAR_COUNT = VAR_LASTN + 4
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
@@ -312,7 +313,12 @@ constexpr int kSmallK = 128, kSmallV = 32;
 #endif
 
 // LM: decode with the external scorer (ctc_beam_search_decoder.cpp:74-82,93-95,120-137,173-206; tables: lm_tables.h).
-template <class X, bool IDENT, bool SMALLV = false, bool LM = false>
+// LAZY (the wide-beam layouts, whose per-slot info words live in HBM scratch): the info word of a slot -- which label,
+// which kind of candidate, which beam entry -- is a pure function of the slot layout, so it is not stored while the
+// candidates are scored.  The <= K survivors find theirs with a binary search over the entries' slot offsets
+// (info_of_slot); the rare paths that look at every slot (ties at the K boundary, exact replay) first rebuild all of them
+// (fill_info).  Round 2 wrote S info words per frame to HBM: 30 GB per configs[2] launch, 18x the algorithmic bytes.
+template <class X, bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false>
 struct Decoder {
   X &x;
   Work &w;
@@ -488,6 +494,10 @@ struct Decoder {
     if (N < 0) return;  // nothing decoded in this launch yet: init() / load_state() left the order of the incoming beam
     x.sync();
     if (N > K) {
+      if (LAZY) {  // the frame's info words were never stored: its layout (ostart / cstart), keys and candidate labels are still in place
+        const int np = x.uni(w.vars[VAR_LASTNENT]), brp = x.uni(w.vars[VAR_LASTBRANK]);
+        fill_info(w.nxt, np, S / np - 2, brp);
+      }
       nth_element_order(S, N, K);
       int *ord = w.surv + 2 * K;
       for (int q = tid; q < K; q += nt) {  // rank by slot = index in the current beam
@@ -618,6 +628,47 @@ struct Decoder {
     if (c < 0) return -1;
     if (IDENT) return c < in.Vc ? c : -1;
     return w.rank_of[c];
+  }
+
+  // ---- LAZY info words ----------------------------------------------------------------------------------------------
+  CTC_HD int cand_char(int rn, int brank) const {  // label of the rn-th non-blank candidate
+    const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
+    return IDENT ? r : w.cch[r];
+  }
+  // w.sinfo[] of every slot of the frame whose layout is in ostart / cstart and whose keys are in skey (a hole has key 0),
+  // for the n entries of beam pb.  Ends with a full fence (the words live in HBM scratch).
+  CTC_HD void fill_info(const Beam &pb, int n, int Vnb, int brank) {
+    const int tid = x.tid(), nt = x.nt();
+    for (int j = tid; j < n; j += nt) {
+      const int s0 = w.ostart[j];
+      w.sinfo[s0] = w.skey[s0] != 0u ? mk_info(pb.viach[j], T_REVIVED, j) : kHoleInfo;
+      w.sinfo[s0 + 1] = mk_info(pb.ch[j], T_SELF, j);
+    }
+    for (int idx = tid; idx < n * Vnb; idx += nt) {
+      const int i = idx / Vnb, rn = idx - i * Vnb;
+      const int sl = w.cstart[i] + rn;
+      w.sinfo[sl] = w.skey[sl] != 0u ? mk_info(cand_char(rn, brank), T_CHILD, i) : kHoleInfo;
+    }
+    x.sync_full();
+  }
+  // The info word of slot sl (not a hole), from the layout alone: open(j) = [revived | self]; between open(j) and
+  // open(j + 1) lie the groups of brand-new children of the entries whose subtree ends at j + 1 -- j itself, then its
+  // nearest in-beam ancestor, and so on up (close(i) = 2 e_i + Vnb (e_i - 1 - a_i), beam_core.h header).
+  CTC_HD uint32_t info_of_slot(const Beam &pb, int sl, int n, int Vnb, uint64_t vmagic, int brank) const {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {  // largest j with ostart[j] <= sl
+      const int mid = (lo + hi + 1) >> 1;
+      if (w.ostart[mid] <= sl) lo = mid; else hi = mid - 1;
+    }
+    const int j = lo, off = sl - w.ostart[j];
+    if (off == 0) return mk_info(pb.viach[j], T_REVIVED, j);
+    if (off == 1) return mk_info(pb.ch[j], T_SELF, j);
+    const uint32_t q = (uint32_t)(off - 2);
+    const int g = (int)(((uint64_t)q * vmagic) >> 32);  // q / Vnb (exact for q < 2^16)
+    const int rn = (int)q - g * Vnb;
+    int i = j;
+    for (int h = 0; h < g; ++h) i = w.anc[i];
+    return mk_info(cand_char(rn, brank), T_CHILD, i);
   }
 
   // log_p of extending beam entry P with character c (ctc_beam_search_decoder.cpp:110-118)
@@ -1021,8 +1072,9 @@ struct Decoder {
         }
         ++ncand;
         const uint32_t k1 = ord_f32(ns);
-        w.skey[s0] = k0; w.sinfo[s0] = i0;
-        w.skey[s0 + 1] = k1; w.sinfo[s0 + 1] = mk_info(c, T_SELF, j);
+        w.skey[s0] = k0;
+        w.skey[s0 + 1] = k1;
+        if (!LAZY) { w.sinfo[s0] = i0; w.sinfo[s0 + 1] = mk_info(c, T_SELF, j); }
         if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
       }
       if (LM) x.wave_add(&pv[P_NCAND], ncand);
@@ -1058,7 +1110,7 @@ struct Decoder {
             const uint32_t k = ord_f32(logp) & live;
             const int s = cs + rn;
             w.skey[s] = k;
-            w.sinfo[s] = ((childinfo | (uint32_t)i) & live) | (kHoleInfo & ~live);
+            if (!LAZY) w.sinfo[s] = ((childinfo | (uint32_t)i) & live) | (kHoleInfo & ~live);
             hist_add(wd, k);
           }
         }
@@ -1084,7 +1136,7 @@ struct Decoder {
           }
           const uint32_t k = exists ? 0u : ord_f32(logp);
           w.skey[s] = k;
-          w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
+          if (!LAZY) w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
           if (small_vocab) hist_add(wd, k);
         }
       }
@@ -1097,7 +1149,8 @@ struct Decoder {
         if (r >= 0) {
           const int s = w.cstart[w.anc[j]] + r - ((brank >= 0 && r > brank) ? 1 : 0);
           if (LM && w.skey[s] != 0u) x.atomic_add(&pv[P_NCAND], -1);
-          w.skey[s] = 0; w.sinfo[s] = kHoleInfo;
+          w.skey[s] = 0;
+          if (!LAZY) w.sinfo[s] = kHoleInfo;
         }
       }
       x.sync();
@@ -1110,6 +1163,7 @@ struct Decoder {
     const int N = LM ? x.uni(pv[P_NCAND]) : n * (1 + Vnb) - x.uni(npin_total);
     uint32_t tau = 0, tauc = 0;
     bool exact = false, have_bitmap = false;
+    bool info_ready = !LAZY;  // (LAZY: w.sinfo[] is rebuilt by whichever rare path needs all of it first)
     if (CTC_USUAL(N > K)) {  // ctc_beam_search_decoder.cpp:150
       have_bitmap = select_kth(S, K, pv, wd);
       int tv[4];
@@ -1118,6 +1172,7 @@ struct Decoder {
       const int E = tv[2], m = K - tv[1];
       if (CTC_RARE(E > m)) {
         have_bitmap = false;
+        if (LAZY) { fill_info(b, n, Vnb, brank); info_ready = true; }
         if (resolve_by_character(S, tau, m, E, pv)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);
         else exact = true;  // the boundary splits a group of equivalent prefixes
       }
@@ -1133,6 +1188,7 @@ struct Decoder {
     // threshold; when the outcome depends on it, an exact replay of std::nth_element followed by a ranking by slot.
     const int n_new = N < K ? N : K;
     if (CTC_RARE(exact)) {
+      if (LAZY && !info_ready) { fill_info(b, n, Vnb, brank); info_ready = true; }
       nth_element_order(S, N, K);
       for (int q = tid; q < K; q += nt) {  // rank by slot
         const int mine = ord[q];
@@ -1151,7 +1207,7 @@ struct Decoder {
       const bool all = N <= K;
       x.compact_slots(S, surv, [=](int s) -> bool {
         const uint32_t k = skey[s];
-        return all ? (k != 0u) : (k > tau || (k == tau && (sinfo[s] >> 16) >= tauc));
+        return all ? (k != 0u) : (k > tau || (k == tau && (tauc == 0u || (sinfo[s] >> 16) >= tauc)));
       });
       x.mark(3);
     }
@@ -1165,6 +1221,13 @@ struct Decoder {
     // append), its probabilities -- go to three different sets of waves when the workgroup has them.
     uint32_t kloc = 0, kmin = 0xFFFFFFFFu;
     bool r_prob_any = true;
+    const bool lazy_info = LAZY && !info_ready;
+    uint32_t *sinf = reinterpret_cast<uint32_t *>(rk);  // LAZY: the survivors' info words (rk is idle unless the frame was exact)
+    if (lazy_info) {
+      const uint64_t vmagic = Vnb > 0 ? 0xFFFFFFFFull / (uint32_t)Vnb + 1ull : 0ull;
+      for (int k = tid; k < n_new; k += nt) sinf[k] = info_of_slot(b, surv[k], n, Vnb, vmagic, brank);
+      x.sync();
+    }
     {
       const int ne = (n_new + 63) & ~63;
       const bool roles = nt >= 3 * ne;
@@ -1189,12 +1252,13 @@ struct Decoder {
           if (t0 == 0) {
             reset_pvars(pvars(in.t + 1));
             w.vars[VAR_LASTN] = N; w.vars[VAR_LASTS] = S;  // (enter_danger)
+            if (LAZY) { w.vars[VAR_LASTNENT] = n; w.vars[VAR_LASTBRANK] = brank; }
           }
         }
       }
       for (int k = roles ? tid - role * ne : tid; k < n_new && role < nroles; k += roles ? ne : nt) {
         const int s = surv[k];
-        const uint32_t inf = w.sinfo[s];
+        const uint32_t inf = lazy_info ? sinf[k] : w.sinfo[s];
         const uint32_t type = info_type(inf);
         const int j = info_entry(inf);
         if (r_lcp) {
@@ -1202,7 +1266,7 @@ struct Decoder {
           // off (a brand-new child never lies on an existing path), capped by the depth of a revived interior node.
           int l = -1;
           if (k > 0) {
-            const uint32_t pinf = w.sinfo[surv[k - 1]];
+            const uint32_t pinf = lazy_info ? sinf[k - 1] : w.sinfo[surv[k - 1]];
             const int pj = info_entry(pinf);
             l = lca_depth(pj, j);
             if (type == T_REVIVED) { const int dx = b.dep[w.anc[j]] + 1; l = dx < l ? dx : l; }
@@ -1533,13 +1597,13 @@ struct PrunedRows {
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
 // LM tier: `lm` = the scorer's tables, `raw` = the caller's own [len, V] rows (log-probabilities or probabilities,
 // `raw_log` says which): ctc_beam_search_decoder.cpp:78 takes the blank's log-probability from them directly.
-template <bool IDENT, bool SMALLV = false, bool LM = false, class X>
+template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr, const ctclm::LmView *lm = nullptr, const float *raw = nullptr,
                             int raw_log = 1) {
   if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
-  Decoder<X, IDENT, SMALLV, LM> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
+  Decoder<X, IDENT, SMALLV, LM, LAZY> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   if (t0 > 0) dec.load_state(*ss); else dec.init();
@@ -1587,6 +1651,16 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       }
     } else {
       in.identity = 0;
+      if (LAZY) {  // danger must be noticed while the previous frame's candidate labels (w.cch) are still in place: fill_info
+        if (prefetch) {
+          if (tid < x.uni(pre_cnt)) dec.note_lp(pre_lp);
+        } else {
+          const int cn = x.uni(pr->cnt[t]);
+          for (int r = tid; r < cn; r += nt) dec.note_lp(pr->lp[(size_t)t * width + r]);
+        }
+        x.sync();
+        dec.poll_danger();
+      }
       if (prefetch) {
         in.Vc = x.uni(pre_cnt);
         if (tid < in.Vc) { w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid; dec.note_lp(pre_lp); }

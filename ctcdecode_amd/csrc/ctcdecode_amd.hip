@@ -23,7 +23,7 @@
 
 #include "../../include/ctcdecode_amd.h"
 #define CTC_EXACT_MATH_HOST_TABLES
-#include "beam_core.h"
+#include "decode_kernel.h"
 #include "lm_build.h"
 #include "compact_results.h"
 
@@ -31,543 +31,12 @@ namespace {
 
 using namespace ctcbeam;
 
-// ------------------------------------------------------------------------------------------------ device policy
-// Cross-lane data movement uses DPP (row shifts + row broadcasts, a few cycles each) instead of ds_bpermute-based
-// shuffles (~100 cycles each on the critical path): every block primitive below is a wave-level scan.
-#define CTC_DPP(old, v, ctrl, rowmask) __builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rowmask), 0xf, false)
+// (execution policy + kernel template: decode_kernel.h; its instantiations are compiled in decode_kernels.hip)
+using namespace ctcdk;
+#define CTC_X_EXTERN(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, G_) extern template __global__ void ctcdk::ctc_beam_decode_kernel<PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_>(ctcdk::KernelArgs);
+} namespace ctcdk { CTC_KERNEL_LIST(CTC_X_EXTERN) } namespace {
+#undef CTC_X_EXTERN
 
-// Inclusive scan over the 64 lanes of a wave; op(left, mine); `ident` is op's left identity.
-template <class Op>
-__device__ __forceinline__ int wave_scan(int v, const int ident, Op op) {
-  v = op(CTC_DPP(ident, v, 0x111, 0xf), v);  // row_shr:1
-  v = op(CTC_DPP(ident, v, 0x112, 0xf), v);  // row_shr:2
-  v = op(CTC_DPP(ident, v, 0x114, 0xf), v);  // row_shr:4
-  v = op(CTC_DPP(ident, v, 0x118, 0xf), v);  // row_shr:8
-  v = op(CTC_DPP(ident, v, 0x142, 0xa), v);  // row_bcast:15 -> rows 1, 3
-  v = op(CTC_DPP(ident, v, 0x143, 0xc), v);  // row_bcast:31 -> rows 2, 3
-  return v;
-}
-__device__ __forceinline__ int wave_sum(int v) {
-  return __builtin_amdgcn_readlane(wave_scan(v, 0, [](int a, int b) { return a + b; }), 63);
-}
-__device__ __forceinline__ int wave_min(int v) {
-  return __builtin_amdgcn_readlane(wave_scan(v, ctcbeam::kIntMax, [](int a, int b) { return a < b ? a : b; }), 63);
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_readlane(
-      wave_scan((int)v, 0, [](int a, int b) { return (uint32_t)a > (uint32_t)b ? a : b; }), 63);
-}
-
-// FAR: part of the workspace lives in HBM (BIG layout): every barrier must then also drain global memory traffic.
-// PROF: 0 = product build; 1 = per-phase timers (mark) and the beam dump; 2 = barrier timeline only (no timers: the
-// timers' mutable state would put this object into scratch memory and distort the timeline).
-// NT: the workgroup size when it is known at compile time (0 = read blockDim): wave counts, the role split of a frame
-// and the slot-to-wave assignment then fold to constants.
-template <int PROF, bool FAR, int NT = 0>
-struct DevX {
-  int *red;  // 2 x 16 ints of LDS
-  int parity;
-  long long *prof;   // PROF: per-phase cycle accumulators (LDS), written by thread 0
-  long long last;
-  __device__ __forceinline__ void mark(int id) {
-    if (PROF == 1 && threadIdx.x == 0) {
-      const long long now = (long long)wall_clock64();
-      prof[id] += now - last;
-      last = now;
-    }
-  }
-  // debugging aid (profiling build only): the beam after every frame -> dbg[t][0] = n, then (node, dep, lcp, score bits) per entry
-  int *dbg; int dbg_stride;
-  __device__ __forceinline__ void dump(int t, int n, const int *node, const int *dep, const int *lcp, const float *score) {
-    if (PROF == 1 && dbg) {
-      int *o = dbg + (size_t)t * dbg_stride;
-      if (threadIdx.x == 0) o[0] = n;
-      for (int i = threadIdx.x; i < n; i += nt()) {
-        o[1 + 4 * i] = node[i]; o[2 + 4 * i] = dep[i]; o[3 + 4 * i] = lcp[i]; o[4 + 4 * i] = __float_as_int(score[i]);
-      }
-    }
-  }
-  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
-  __device__ __forceinline__ int nt() const { return NT ? NT : (int)blockDim.x; }
-  __device__ __forceinline__ constexpr bool far() const { return FAR; }  // part of the workspace lives in HBM
-  // LDS-only barrier: waits for this wave's LDS traffic, not for outstanding global loads/stores (the row prefetch
-  // and the pool appends stay in flight across phases).  sync_full() is the fence that also drains global memory.
-  __device__ __forceinline__ void sync() {
-    if (PROF == 2 && tl) tl_rec();
-    if (FAR) __syncthreads();
-    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (PROF == 2 && tl) tl_rec();
-  }
-  __device__ __forceinline__ void sync_full() {
-    if (PROF == 2 && tl) tl_rec();
-    __syncthreads();
-    if (PROF == 2 && tl) tl_rec();
-  }
-  // Barrier timeline (profiling build, tools/barrier_timeline.py): during a few chosen frames of batch item 0 every
-  // wave stores the shader clock when it arrives at, and when it leaves, each barrier.
-  // (stamps go to LDS -- a global store per stamp would make the compiler's memory waits part of the measurement --
-  // and are copied out when the kernel ends)
-  // The only mutable state, the per-wave record counters, lives in LDS (tlcnt): mutable members would push this whole
-  // object into scratch memory.  A counter at or beyond tl_cap means "not recording".
-  long long *tl; int *tlcnt; int tl_cap, tl_f0, tl_nf;
-  __device__ __forceinline__ void tl_rec() {
-    if ((threadIdx.x & 63) == 0) {
-      const int i = atomicAdd(&tlcnt[threadIdx.x >> 6], 1);
-      if (i < tl_cap) tl[(threadIdx.x >> 6) * tl_cap + i] = (long long)clock64();
-    }
-  }
-  __device__ __forceinline__ void tick() { if (PROF == 2 && tl) tl_rec(); }  // extra stamp between barriers
-  __device__ __forceinline__ void trace_frame(int t) {
-    if (PROF == 2 && tl && (threadIdx.x & 63) == 0) {
-      if (t == tl_f0) tlcnt[threadIdx.x >> 6] = 0;
-      if (t == tl_f0 + tl_nf) tlcnt[threadIdx.x >> 6] = tl_cap;
-    }
-  }
-  // a value every thread of the workgroup holds identically -> scalar register (branches/loops on it become scalar)
-  __device__ __forceinline__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
-  // four consecutive, 16-byte aligned LDS words every thread reads identically: one ds_read_b128
-  __device__ __forceinline__ void uni4(const int *p, int *out) const {
-    const int4 v = *reinterpret_cast<const int4 *>(p);
-    out[0] = __builtin_amdgcn_readfirstlane(v.x); out[1] = __builtin_amdgcn_readfirstlane(v.y);
-    out[2] = __builtin_amdgcn_readfirstlane(v.z); out[3] = __builtin_amdgcn_readfirstlane(v.w);
-  }
-  __device__ __forceinline__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-  // issue priority of this wave among the waves of its SIMD (0 = default .. 3).  (Raising it for the wave that works
-  // alone in a phase, or for the child-scoring waves of phase B, was measured: neutral to 0.6 % slower -- not used.)
-  template <int P>
-  __device__ __forceinline__ void prio() const { __builtin_amdgcn_s_setprio(P); }
-  // a pointer the compiler must treat as new: what it points to is (re)loaded after this point, not kept live before it
-  template <class P>
-  __device__ __forceinline__ const P *fresh(const P *p) const {
-    asm volatile("" : "+s"(p));
-    return p;
-  }
-  // the value lane `idx` holds (idx uniform)
-  __device__ __forceinline__ int pick(int v, int idx) const { return __builtin_amdgcn_readlane(v, idx); }
-  __device__ __forceinline__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
-  __device__ __forceinline__ void atomic_max(int *p, int v) { atomicMax(p, v); }
-  // a "group" = one wave: work items that the 64 lanes search / paint together
-  __device__ __forceinline__ int group() const { return __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); }
-  __device__ __forceinline__ int ngroups() const { return (nt() + 63) >> 6; }
-  __device__ __forceinline__ int lane() const { return (int)threadIdx.x & 63; }
-  __device__ __forceinline__ int lanes() const { return 64; }
-  __device__ __forceinline__ unsigned long long ballot(bool p) const { return __ballot(p); }
-  // first q in [from, n) with arr[q] < bound (n if none); arguments uniform across the wave
-  __device__ __forceinline__ int first_below(const int *arr, int from, int n, int bound) const {
-    for (int base = from; base < n; base += 64) {
-      const int q = base + ((int)threadIdx.x & 63);
-      const unsigned long long m = __ballot(q < n && arr[q] < bound);
-      if (m) return base + __ffsll((long long)m) - 1;
-    }
-    return n;
-  }
-  __device__ __forceinline__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
-  // one LDS atomic per wave
-  __device__ __forceinline__ void wave_add(int *p, int v) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
-  }
-
-  __device__ __forceinline__ void wave_max_to(int *p, uint32_t v) {
-    v = wave_max_u32(v);
-    if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
-  }
-  __device__ __forceinline__ unsigned global_add(unsigned *p, unsigned v) { return atomicAdd(p, v); }
-  __device__ __forceinline__ void wave_min_to(int *p, uint32_t v) {
-    v = ~wave_max_u32(~v);
-    if ((threadIdx.x & 63) == 0) atomicMin((unsigned *)p, v);
-  }
-
-  // bit s of bitmap = pred(s), for every slot s in [0, S): each wave owns a contiguous range of slots (the same mapping
-  // as compact_slots), so one ballot is one 64-bit word of the bitmap.  pred may have side effects (list appends).
-  template <class Pred>
-  __device__ __forceinline__ void mark_slots(int S, uint32_t *bitmap, Pred pred) {
-    const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
-    const int first = wave * rounds * 64;
-    if (rounds <= 4) {  // common case: straight-line, the four predicates (and their LDS reads) issued together
-      const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
-      const bool f0 = s0 < S && pred(s0);
-      const bool f1 = rounds > 1 && s1 < S && pred(s1);
-      const bool f2 = rounds > 2 && s2 < S && pred(s2);
-      const bool f3 = rounds > 3 && s3 < S && pred(s3);
-      const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
-      if (lane < rounds) {
-        const unsigned long long m = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : m3;
-        bitmap[2 * (wave * rounds + lane)] = (uint32_t)m;
-        bitmap[2 * (wave * rounds + lane) + 1] = (uint32_t)(m >> 32);
-      }
-      return;
-    }
-    for (int it = 0; it < rounds; ++it) {
-      const int s = first + it * 64 + lane;
-      const unsigned long long m = __ballot(s < S && pred(s));
-      if (lane == 0) {
-        bitmap[2 * (wave * rounds + it)] = (uint32_t)m;
-        bitmap[2 * (wave * rounds + it) + 1] = (uint32_t)(m >> 32);
-      }
-    }
-  }
-  // One pass over the slot keys for the select: the keys inside the bucket [b32, b32 + bspan] are appended to list[]
-  // (key offset + 1) / lslot[] (slot), and -- when `direct` -- bit s of the bitmap says "key above the bucket".
-  // A wave reserves the list space of ALL its slots with ONE returning LDS atomic: a returning atomic costs a full LDS
-  // round trip, and one per bucket member (in divergent code, once per round) was most of this pass.
-  __device__ __forceinline__ void list_bucket(int S, const uint32_t *skey, uint32_t b32, uint32_t bspan, bool direct, uint32_t *bitmap,
-                                              uint32_t *list, int *lslot, int *lcount) {
-    const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
-    const int first = wave * rounds * 64;
-#define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
-    if (rounds <= 4) {
-      const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
-      const uint32_t k0 = s0 < S ? skey[s0] : 0u, k1 = (rounds > 1 && s1 < S) ? skey[s1] : 0u;
-      const uint32_t k2 = (rounds > 2 && s2 < S) ? skey[s2] : 0u, k3 = (rounds > 3 && s3 < S) ? skey[s3] : 0u;
-      const uint32_t d0 = k0 - b32, d1 = k1 - b32, d2 = k2 - b32, d3 = k3 - b32;
-      const bool g0 = k0 >= b32, g1 = k1 >= b32, g2 = k2 >= b32, g3 = k3 >= b32;  // (b32 >= 1: holes, key 0, never pass)
-      const bool i0 = g0 && d0 <= bspan, i1 = g1 && d1 <= bspan, i2 = g2 && d2 <= bspan, i3 = g3 && d3 <= bspan;
-      const unsigned long long m0 = __ballot(i0), m1 = __ballot(i1), m2 = __ballot(i2), m3 = __ballot(i3);
-      const unsigned long long a0 = __ballot(direct && g0 && !i0), a1 = __ballot(direct && g1 && !i1), a2 = __ballot(direct && g2 && !i2),
-                               a3 = __ballot(direct && g3 && !i3);
-      const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
-      const int tot = c0 + c1 + c2 + c3;
-      if (tot) {  // (uniform)
-        int base = 0;
-        if (lane == 0) base = atomicAdd(lcount, tot);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (i0) { const int p = base + CTC_BELOW(m0); list[p] = d0 + 1u; lslot[p] = s0; }
-        if (i1) { const int p = base + c0 + CTC_BELOW(m1); list[p] = d1 + 1u; lslot[p] = s1; }
-        if (i2) { const int p = base + c0 + c1 + CTC_BELOW(m2); list[p] = d2 + 1u; lslot[p] = s2; }
-        if (i3) { const int p = base + c0 + c1 + c2 + CTC_BELOW(m3); list[p] = d3 + 1u; lslot[p] = s3; }
-      }
-      if (lane < rounds) {
-        const unsigned long long m = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a3;
-        bitmap[2 * (wave * rounds + lane)] = (uint32_t)m;
-        bitmap[2 * (wave * rounds + lane) + 1] = (uint32_t)(m >> 32);
-      }
-      return;
-    }
-    for (int it = 0; it < rounds; ++it) {
-      const int s = first + it * 64 + lane;
-      const uint32_t k = s < S ? skey[s] : 0u, dk = k - b32;
-      const bool g = k >= b32, in = g && dk <= bspan;
-      const unsigned long long m = __ballot(in), am = __ballot(direct && g && !in);
-      if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(lcount, __popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (in) { const int p = base + CTC_BELOW(m); list[p] = dk + 1u; lslot[p] = s; }
-      }
-      if (lane == 0) {
-        bitmap[2 * (wave * rounds + it)] = (uint32_t)am;
-        bitmap[2 * (wave * rounds + it) + 1] = (uint32_t)(am >> 32);
-      }
-    }
-#undef CTC_BELOW
-  }
-  // out[r] = s for the r-th set bit s of the bitmap (ascending); one wave, the others wait at the closing barrier.
-  // CLUSTERED: the set bits come in long runs (the LM tier: a dictionary-constrained beam keeps the children of few
-  // parents) -- one lane per BYTE of the bitmap on as many waves as that takes, instead of one lane per 64-bit word on
-  // one wave whose lanes would loop over dozens of bits while their neighbours idle.  (Measured: −1 % per LM frame; no
-  // change for the plain kernel, which keeps the single-wave form.)
-  template <bool CLUSTERED = false>
-  __device__ __forceinline__ void expand_bitmap(const uint32_t *bitmap, int nwords64, int *out) {
-    if (CLUSTERED && nwords64 <= 64 && nwords64 * 8 <= nt()) {
-      const int lane = (int)threadIdx.x & 63;
-      const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-      if (wave * 64 < nwords64 * 8) {
-        // every participating wave scans the words' populations for itself; a lane's first rank = (bits in lower words)
-        // + (bits in the lower bytes of its word)
-        const int g = wave * 64 + lane, wi = g >> 3, by = g & 7;
-        const unsigned long long *b64 = reinterpret_cast<const unsigned long long *>(bitmap);
-        const unsigned long long mineword = lane < nwords64 ? b64[lane] : 0ull;
-        const unsigned long long w = wi < nwords64 ? b64[wi] : 0ull;
-        const int cnt = __popcll(mineword);
-        const int incl = wave_scan(cnt, 0, [](int a, int b) { return a + b; });
-        const int pfx = __shfl(incl - cnt, wi & 63, 64);
-        unsigned bits = (unsigned)(w >> (8 * by)) & 0xFFu;
-        int base = pfx + __popcll(w & ((1ull << (8 * by)) - 1ull));
-        const int s0 = wi * 64 + 8 * by;
-        while (bits) {
-          out[base++] = s0 + __builtin_ctz(bits);
-          bits &= bits - 1u;
-        }
-      }
-      sync();
-      return;
-    }
-    if (threadIdx.x < 64) {
-      const int lane = (int)threadIdx.x;
-      int running = 0;
-      for (int w0 = 0; w0 < nwords64; w0 += 64) {
-        const int wi = w0 + lane;
-        unsigned long long word = 0ull;
-        if (wi < nwords64) word = (unsigned long long)bitmap[2 * wi] | ((unsigned long long)bitmap[2 * wi + 1] << 32);
-        const int cnt = __popcll(word);
-        const int incl = wave_scan(cnt, 0, [](int a, int b) { return a + b; });
-        int base = running + incl - cnt;
-        while (word) {
-          out[base++] = wi * 64 + __builtin_ctzll(word);
-          word &= word - 1ull;
-        }
-        running += __builtin_amdgcn_readlane(incl, 63);
-      }
-    }
-    sync();
-  }
-
-  // Ordered compaction: out[r] = s for every slot s in [0, S) with pred(s), r = number of such slots below s.
-  // Each wave owns a contiguous range of slots (consecutive lanes = consecutive slots), so the rank of a slot is
-  // (survivors in lower waves) + (survivors in this wave's earlier rounds) + (set ballot bits below the lane):
-  // no atomics, no sorting.  Starts and ends with a barrier-consistent state (caller synced before; syncs after).
-  template <class Pred>
-  __device__ __forceinline__ void compact_slots(int S, int *out, Pred pred) {
-    compact_slots_to(S, pred, [=](int r, int s) { out[r] = s; });
-  }
-  // ... the general form: emit(r, s) is called once for every slot s that passes, r = its rank among them
-  template <class Pred, class Emit>
-  __device__ __forceinline__ void compact_slots_to(int S, Pred pred, Emit emit) {
-    const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
-    const int first = wave * rounds * 64;
-    int *row = red + parity * 16;
-    parity ^= 1;
-    if (rounds <= 4) {  // common case: straight-line code, the four slots' predicates evaluated together
-      const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
-      const bool f0 = s0 < S && pred(s0);
-      const bool f1 = rounds > 1 && s1 < S && pred(s1);
-      const bool f2 = rounds > 2 && s2 < S && pred(s2);
-      const bool f3 = rounds > 3 && s3 < S && pred(s3);
-      const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
-      const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
-      if (lane == 0) row[wave] = c0 + c1 + c2 + c3;
-      sync();
-      int tot = lane < nw ? row[lane] : 0;
-      tot += CTC_DPP(0, tot, 0x111, 0xf); tot += CTC_DPP(0, tot, 0x112, 0xf);
-      tot += CTC_DPP(0, tot, 0x114, 0xf); tot += CTC_DPP(0, tot, 0x118, 0xf);
-      const int base = wave > 0 ? __builtin_amdgcn_readlane(tot, wave - 1) : 0;
-#define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
-      if (f0) emit(base + CTC_BELOW(m0), s0);
-      if (f1) emit(base + c0 + CTC_BELOW(m1), s1);
-      if (f2) emit(base + c0 + c1 + CTC_BELOW(m2), s2);
-      if (f3) emit(base + c0 + c1 + c2 + CTC_BELOW(m3), s3);
-      sync();
-      return;
-    }
-    unsigned long long flags = 0ull;
-    int cnt = 0;
-    for (int it = 0; it < rounds; ++it) {
-      const int s = first + it * 64 + lane;
-      const bool f = s < S && pred(s);
-      cnt += __popcll(__ballot(f));
-      if (f && it < 64) flags |= 1ull << it;
-    }
-    if (lane == 0) row[wave] = cnt;
-    sync();
-    // exclusive prefix over the <= 16 wave totals: one LDS read per lane + a row-level DPP scan, then one readlane
-    int tot = lane < nw ? row[lane] : 0;
-    tot += CTC_DPP(0, tot, 0x111, 0xf); tot += CTC_DPP(0, tot, 0x112, 0xf);
-    tot += CTC_DPP(0, tot, 0x114, 0xf); tot += CTC_DPP(0, tot, 0x118, 0xf);
-    int base = wave > 0 ? __builtin_amdgcn_readlane(tot, wave - 1) : 0;
-    for (int it = 0; it < rounds; ++it) {
-      const int s = first + it * 64 + lane;
-      const bool f = it < 64 ? ((flags >> it) & 1ull) != 0ull : (s < S && pred(s));
-      const unsigned long long m = __ballot(f);
-      if (f) emit(base + CTC_BELOW(m), s);
-      base += __popcll(m);
-    }
-#undef CTC_BELOW
-    sync();
-  }
-
-  // Histogram complete (caller synced): bins[0, 1024).  Wave 0 finds the bucket holding the need-th largest key: every
-  // lane adds up 16 consecutive buckets, a suffix scan over those 64 sums picks the group, a 16-lane suffix scan inside
-  // it picks the bucket.  Everyone gets out[0..3] = {bucket or -1, #keys above it, #keys
-  // total, #keys in it} after the closing barrier.
-  __device__ __forceinline__ void find_bucket(const int *bins, int need, int *out) {
-    if (threadIdx.x < 64) {
-      const int lane = (int)threadIdx.x;
-      const int c = 63 - lane;  // lane 0 owns the TOP coarse bucket: a prefix scan over lanes is a suffix sum over buckets
-      const int4 *f4 = reinterpret_cast<const int4 *>(bins + 16 * c);  // its 16 fine buckets: four 128-bit reads, one round trip
-      const int4 q0 = f4[0], q1 = f4[1], q2 = f4[2], q3 = f4[3];
-      const int cv = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) + ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));
-      const int incl = wave_scan(cv, 0, [](int a, int b) { return a + b; });
-      const int total = __builtin_amdgcn_readlane(incl, 63);
-      const unsigned long long m = __ballot(incl >= need);
-      if (m == 0ull) {
-        if (lane == 0) { out[0] = -1; out[1] = 0; out[2] = total; out[3] = 0; }
-      } else {
-        const int l1 = __ffsll((long long)m) - 1;            // lane of the coarse bucket holding the key
-        const int cstar = 63 - l1;
-        const int above_c = __builtin_amdgcn_readlane(incl, l1) - __builtin_amdgcn_readlane(cv, l1);
-        const int fv = lane < 16 ? bins[cstar * 16 + (15 - lane)] : 0;  // its 16 fine buckets, top one in lane 0
-        const int fincl = wave_scan(fv, 0, [](int a, int b) { return a + b; }) + above_c;
-        const unsigned long long mf = __ballot(lane < 16 && fincl >= need);
-        const int l2 = __ffsll((long long)mf) - 1;
-        if (lane == l2) { out[0] = cstar * 16 + (15 - lane); out[1] = fincl - fv; out[2] = total; out[3] = fv; }
-      }
-    }
-    sync();
-  }
-
-  // Exclusive prefix (in thread order) and total of one 32-bit value per thread; contains one barrier.  (Used with two
-  // 16-bit counters packed into the word.)
-  __device__ __forceinline__ void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) {
-    const int t = (int)threadIdx.x, wave = t >> 6, nw = (nt() + 63) >> 6;
-    const uint32_t incl = (uint32_t)wave_scan((int)mine, 0, [](int a, int b) { return a + b; });
-    int *row = red + parity * 16;
-    parity ^= 1;
-    if ((t & 63) == 63) row[wave] = (int)incl;
-    sync();
-    uint32_t tot = (t & 63) < nw ? (uint32_t)row[t & 63] : 0u;
-    tot += (uint32_t)CTC_DPP(0, tot, 0x111, 0xf); tot += (uint32_t)CTC_DPP(0, tot, 0x112, 0xf);
-    tot += (uint32_t)CTC_DPP(0, tot, 0x114, 0xf); tot += (uint32_t)CTC_DPP(0, tot, 0x118, 0xf);
-    const uint32_t below = wave > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)tot, wave - 1) : 0u;
-    *base_out = below + incl - mine;
-    *total_out = (uint32_t)__builtin_amdgcn_readlane((int)tot, nw - 1);
-  }
-
-  // In-place exclusive prefix sum of a[0, n) in LDS; returns the total.  Each thread owns a contiguous chunk.
-  __device__ __forceinline__ uint32_t scan_excl(uint32_t *a, int n) {
-    const int nthreads = nt(), t = (int)threadIdx.x;
-    const int chunk = ctcbeam::ceil_div_p2(n, nthreads) | 1;  // odd stride: no LDS bank conflicts across lanes
-    const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
-    uint32_t sum = 0;
-    for (int i = lo; i < hi; ++i) sum += a[i];
-    const uint32_t incl = (uint32_t)wave_scan((int)sum, 0, [](int x, int y) { return x + y; });
-    const int wave = t >> 6, nw = (nthreads + 63) >> 6;
-    int *row = red + parity * 16;
-    parity ^= 1;
-    if ((t & 63) == 63) row[wave] = (int)incl;
-    sync();
-    uint32_t base = 0, total = 0;
-    for (int i = 0; i < nw; ++i) {
-      const uint32_t v = (uint32_t)row[i];
-      if (i < wave) base += v;
-      total += v;
-    }
-    uint32_t run = base + incl - sum;
-    for (int i = lo; i < hi; ++i) {
-      const uint32_t v = a[i];
-      a[i] = run;
-      run += v;
-    }
-    sync();
-    return total;
-  }
-};
-
-constexpr int kTimelineCap = 128;  // barrier timeline entries per wave (16 KB of LDS in the profiling build)
-
-struct KernelArgs {
-  const float *probs;       // [B, T, V] log-probabilities
-  const int32_t *seq_lens;  // [B] or null
-  int B, T, V, K, blank;
-  Dims dims;
-  PoolNode *pool;           // [B, pool_stride]
-  int *pool_up;             // [B, pool_stride] express pointers (beam_core.h kExpress)
-  long long pool_stride;
-  const uint64_t *tables;   // 64 words (exact_math.h)
-  OutRefs outs;             // result tensors; read through the kernel-argument segment at the end of an utterance
-  int32_t *status;          // [B]
-  long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
-  int *dbg;                 // profiling build: beam of item 0 after every frame, [T][1 + 4K] (or null)
-  long long *tl;            // profiling build: barrier timeline of item 0, [waves][tl_cap] (or null)
-  int tl_cap, tl_f0, tl_nf;
-  char *far;                // BIG layout: per-utterance HBM scratch, far_stride bytes each
-  long long far_stride;
-  // streaming (ctcd_stream_decode): per item, the HBM block that holds its parked beam + node pool
-  char **st_base;           // [B] or null
-  const int *st_poolcap;    // [B] nodes the pool of each stream can hold
-  const unsigned char *st_eos;  // [B] 1: this call ends the stream (run decode())
-  long long st_pool_off;    // byte offset of the node pool inside a stream block
-  // LM tier (ctcd_beam_decode_lm): the scorer's tables, and the caller's own rows (the blank's log-probability is taken
-  // from them, ctc_beam_search_decoder.cpp:78)
-  ctclm::LmView lm;
-  const float *raw;         // [B, T, V] as given by the caller
-  int raw_log;              // 1: they are log-probabilities
-  const int *pr_cnt;        // pruned mode: [B, T] candidates per frame (null in identity mode)
-  const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
-  const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
-  int pr_stride;
-};
-
-// LAYOUT: 0 = the workspace is laid out for the call's own beam width / vocabulary (array bases are run-time values);
-// 1 = fixed layout for beam <= kFixedK, vocabulary <= kFixedV: every LDS array sits at a compile-time address, which
-// frees the scalar registers the bases would occupy and folds them into the instructions' offset fields.
-constexpr int kFixedK = ctcbeam::kSmallK, kFixedV = ctcbeam::kSmallV;
-__host__ __device__ constexpr Dims fixed_layout_dims(bool lm = false) { return Dims{kFixedK, kFixedV, kFixedV, 1, lm ? 1 : 0}; }
-__host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
-
-// PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
-template <int PROF, int BIG, int LAYOUT, bool PRUNED, int NT = 0, bool LM = false>
-__global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ uint64_t tbl[64];
-  __shared__ int red[32];
-  const int b = (int)blockIdx.x;
-  if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
-  Work w;
-  if (LAYOUT == 1) carve<0>(w, smem, nullptr, fixed_layout_dims(LM), nullptr);
-  else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
-  __shared__ long long prof[16];
-  constexpr int kTlCap = LM ? kTimelineCap / 2 : kTimelineCap;  // (the LM tier's workspace leaves 8 KB for the stamps)
-  __shared__ long long tlbuf[PROF == 2 ? 16 * kTlCap : 1];
-  __shared__ int tlcnt[16];
-  if (PROF == 2 && threadIdx.x < 16) tlcnt[threadIdx.x] = kTlCap;
-  if (PROF == 2 && a.tl && b == 0)
-    for (int i = threadIdx.x; i < 16 * kTlCap; i += blockDim.x) tlbuf[i] = 0;
-  if (PROF == 1 && threadIdx.x < 16) prof[threadIdx.x] = 0;
-  DevX<PROF, BIG != 0, NT> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
-                    (PROF == 2 && b == 0 && a.tl) ? tlbuf : nullptr, tlcnt, kTlCap, a.tl_f0, a.tl_nf};
-  int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
-  len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
-  __syncthreads();
-  if (PROF == 1) x.last = (long long)wall_clock64();
-  PrunedRows prow;
-  if (PRUNED) {
-    prow.cnt = a.pr_cnt + (size_t)b * a.T;
-    prow.ch = a.pr_ch + (size_t)b * a.T * a.pr_stride;
-    prow.lp = a.pr_lp + (size_t)b * a.T * a.pr_stride;
-    prow.stride = a.pr_stride;
-  }
-  PoolNode *pool = a.pool + (size_t)b * a.pool_stride;
-  int *pool_up = a.pool_up + (size_t)b * a.pool_stride;
-  int pool_cap = (int)a.pool_stride;
-  StreamState ss;
-  if (a.st_base) {
-    char *base = a.st_base[b];
-    ss.hdr = (int *)base;
-    ss.arrays = ss.hdr + SH_WORDS;
-    ss.finish = a.st_eos[b];
-    pool = (PoolNode *)(base + a.st_pool_off);
-    pool_cap = a.st_poolcap[b];
-    pool_up = (int *)(pool + pool_cap);
-  }
-  // the result pointers stay in the kernel-argument segment until the utterance ends (finish() reads them from there)
-#if defined(__HIP_DEVICE_COMPILE__)
-  const OutRefs *outs = (const OutRefs *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernelArgs, outs));
-#else
-  const OutRefs *outs = &a.outs;
-#endif
-  const ctclm::LmView *lmv = nullptr;
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (LM) lmv = (const ctclm::LmView *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernelArgs, lm));
-#else
-  if (LM) lmv = &a.lm;
-#endif
-  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
-                                  PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
-                                  a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + (size_t)b * a.T * a.V : nullptr, a.raw_log);
-  if (threadIdx.x == 0) a.status[b] = st;
-  if (PROF == 2 && a.tl && b == 0) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 16 * kTlCap; i += blockDim.x) a.tl[i] = tlbuf[i];  // (LM build: [16][kTimelineCap / 2])
-  }
-  if (PROF == 1 && threadIdx.x < 16) a.prof[(size_t)b * 16 + threadIdx.x] = prof[threadIdx.x];
-}
 
 // prob -> log-prob exactly as decoder_utils.cpp:42 : float(log(double(p) + FLT_MIN)).  The device log() is within
 // 1 ulp of the correctly rounded double; the element is flagged (and later recomputed with the host C library the
@@ -2071,6 +1540,8 @@ int ctcd_expand_compact(ctcd_decoder *d, const int32_t *c_hdr, const int32_t *c_
   CTC_ON_DEVICE(d->device);
   if (beam > kExpandMaxK) return fail(CTCD_EUNSUPPORTED, "device expansion of compact results: beam_width > 4096");
   const size_t esm = ((size_t)5 * beam + (beam + 31) / 32 + 4) * 4;
+  if (esm + 1024 > (size_t)d->max_lds) return fail(CTCD_EUNSUPPORTED, "device expansion of compact results: the entry tables of this beam width exceed one workgroup's LDS");
+  HIP_TRY(hipFuncSetAttribute((const void *)expand_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)esm));  // (beam > ~3270 needs more than the default 64 KB)
   hipLaunchKernelGGL(expand_compact_kernel, dim3(B), dim3(beam >= 16 ? 1024 : 256), esm, (hipStream_t)stream_, c_hdr, c_ent, c_labels, beam, T,
                      out_tok, out_ts);
   HIP_TRY(hipGetLastError());

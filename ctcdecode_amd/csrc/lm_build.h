@@ -149,7 +149,7 @@ struct HostScorer {
     st_bo.assign(1 + W, 0.0f);
     st_fail.assign(1 + W, 0u);
     for (uint32_t w = 0; w < W; ++w) {
-      uni_state[w] = 1 + w;
+      uni_state[w] = order == 1 ? 0u : 1 + w;  // (a unigram model keeps no context: kenlm's state has length 0, no back-off is ever added)
       st_bo[1 + w] = ub[w];
       state_of[{w}] = 1 + w;
     }

@@ -106,17 +106,21 @@ class CompactGatherer(object):
     the labels it does not share with its neighbour in the trie -- an order of magnitude fewer bytes than the padded
     [B, K, T] pair -- and ``dst`` rebuilds the padded tensors of the whole batch in its HBM with one expansion kernel.
 
-    Per batch: one all_reduce of a single word (the longest label buffer, so that every rank pads to the same length),
-    then five gathers to ``dst`` (point to point underneath: every peer has its own xGMI link to the root).  ``submit``
-    launches them asynchronously; ``wait`` drains and, on ``dst``, leaves the expanded tensors of the last batch in
-    ``self.last`` = (output, scores, timesteps, out_lens)."""
+    Per batch: the ranks tell each other how many labels they hold -- one all_gather of a single host word over a gloo
+    control group, so that every rank pads its label buffer to the same length and ``dst`` knows where each rank's labels
+    end WITHOUT reading anything back from the device (no ``.item()`` / stream synchronisation in the gather path) --
+    then five gathers to ``dst`` over the data group (RCCL; point to point underneath: every peer has its own xGMI link to
+    the root).  ``submit`` launches them asynchronously; ``wait`` drains and, on ``dst``, leaves the expanded tensors of
+    the last batch in ``self.last`` = (output, scores, timesteps, out_lens)."""
 
-    def __init__(self, decoder, T, dst=0, group=None, depth=2, stream=None):
+    def __init__(self, decoder, T, dst=0, group=None, depth=2, stream=None, ctl_group=None):
         self.dec, self.T, self.dst, self.group = decoder, T, dst, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.depth = max(1, depth)
         self._host_only = dist.get_backend(group) == "gloo"
+        # control plane: host integers travel over gloo (collective construction: every rank builds its gatherer)
+        self.ctl = group if self._host_only else (ctl_group if ctl_group is not None else dist.new_group(backend="gloo"))
         self._inflight = []
         self.last = None
         # Optional side stream (device backends): the collectives, and on ``dst`` the expansion kernel, are issued there
@@ -150,10 +154,13 @@ class CompactGatherer(object):
         while len(self._inflight) >= self.depth:
             self._finish_one(self._inflight.pop(0))
         dev = hdr.device
-        # the label buffers differ in length: agree on the longest (one all_reduce of a single word), pad, gather
-        nmax = torch.tensor([labels.numel()], dtype=torch.int64, device="cpu" if self._host_only else dev)
-        dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
-        nmax = max(int(nmax.item()), 1)
+        # the label buffers differ in length: every rank learns every count (host words over the control group), pads to
+        # the longest, gathers
+        mine = torch.tensor([labels.numel()], dtype=torch.int64)
+        counts = [torch.zeros((1,), dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(counts, mine, group=self.ctl)
+        ns = [int(c[0]) for c in counts]
+        nmax = max(max(ns), 1)
         lab = labels
         if lab.numel() < nmax:
             lab = torch.cat([lab, torch.zeros((nmax - lab.numel(),), dtype=lab.dtype, device=lab.device)])
@@ -163,14 +170,14 @@ class CompactGatherer(object):
             recv = [[torch.empty_like(t) for _ in range(self.world)] for t in send]
         for i, t in enumerate(send):
             works.append(dist.gather(t, recv[i] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True))
-        self._inflight.append((works, recv if self.rank == self.dst else send, dev))  # (sources stay alive until the gather is done)
+        self._inflight.append((works, recv if self.rank == self.dst else send, dev, ns))  # (sources stay alive until the gather is done)
 
     def _finish(self, item):
         with self._on_stream():
             self._finish_one(item)
 
     def _finish_one(self, item):
-        works, recv, dev = item
+        works, recv, dev, ns = item
         for wk in works:
             wk.wait()
         if self.rank != self.dst:
@@ -179,7 +186,7 @@ class CompactGatherer(object):
         base = 0
         for r in range(self.world):
             h, e, lab = recv[0][r].to(dev), recv[1][r].to(dev).clone(), recv[2][r].to(dev)
-            n = int(h[:, 1].sum().item())
+            n = ns[r]  # (= the sum of the rank's per-item label counts h[:, 1]; known on the host since submit)
             e[:, :, 3] += base  # label indices (relative to the rank's own buffer) rebased onto the concatenated one
             hdrs.append(h); ents.append(e); labs.append(lab[:n])
             base += n
@@ -195,12 +202,12 @@ class CompactGatherer(object):
             torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
 
 
-def make_gatherer(fmt, B, K, T, V, device, dst=0, group=None, depth=2, decoder=None, stream=None):
+def make_gatherer(fmt, B, K, T, V, device, dst=0, group=None, depth=2, decoder=None, stream=None, ctl_group=None):
     """The gatherer bench.py / a serving loop uses: ``fmt`` = "full" (the four padded tensors travel) or "compact"
     (the trie-compact form travels; needs the ``decoder`` to expand it on ``dst``)."""
     if fmt == "full":
         shapes = [((B, K, T), torch.int32), ((B, K), torch.float32), ((B, K, T), torch.int32), ((B, K), torch.int32)]
         return ResultGatherer(shapes, device, dst=dst, group=group, depth=depth)
     if fmt == "compact":
-        return CompactGatherer(decoder, T, dst=dst, group=group, depth=depth, stream=stream)
+        return CompactGatherer(decoder, T, dst=dst, group=group, depth=depth, stream=stream, ctl_group=ctl_group)
     raise ValueError("unknown gather format %r" % (fmt,))

@@ -309,6 +309,11 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
         else st = decode_utterance<true, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+      } else if (big) {  // the wide-beam layouts do not store the per-slot info words (LAZY)
+        if (pruned) st = decode_utterance<false, false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
+        else st = decode_utterance<true, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
       } else if (beam <= 128 && V <= 32) {  // the shapes the device runs with its fixed layout
         if (pruned) st = decode_utterance<false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b);
@@ -341,7 +346,11 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
   d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0; d.lm = 0;
   Work w;
   size_t far_bytes = 0;
-  std::vector<char> mem(carve<0>(w, nullptr, nullptr, d, &far_bytes) + 64);
+  const bool big = getenv("CTC_HOST_BIG") != nullptr;  // the HBM-scratch layouts (CTC_HOST_BIG=1 or 2), as in decode_impl
+  const int flevel = big && getenv("CTC_HOST_BIG")[0] == '2' ? 2 : 1;
+  std::vector<char> mem((!big ? carve<0>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
+                                                                                 : carve<1>(w, nullptr, nullptr, d, &far_bytes)) + 64);
+  std::vector<char> far(far_bytes + 64);
   for (int b = 0; b < B; ++b) {
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
     std::vector<int> pool_up(pool.size());
@@ -350,11 +359,18 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       const int lo = bounds[c], hi = bounds[c + 1];
       // a fresh workspace every chunk, as a new kernel launch would have
       std::fill(mem.begin(), mem.end(), (char)0x5a);
-      carve<0>(w, mem.data(), nullptr, d, nullptr);
+      std::fill(far.begin(), far.end(), (char)0x5a);
+      if (!big) carve<0>(w, mem.data(), nullptr, d, nullptr);
+      else if (flevel == 2) carve<2>(w, mem.data(), far.data(), d, nullptr);
+      else carve<1>(w, mem.data(), far.data(), d, nullptr);
       HostX x;
+      x.far_ = big;
       StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u};
-      int st = decode_utterance<true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
+      int st;
+      if (big) st = decode_utterance<true, false, false, true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo,
+                                pool.data(), pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss);
+      else st = decode_utterance<true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
                                 pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss);
       if (st != ST_OK) return -st;
     }

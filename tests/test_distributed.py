@@ -261,6 +261,58 @@ def test_bench_launches_its_own_ranks():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config,batch,extra", [(2, 12, ["--beam", "500", "--frames", "120"]), (4, 10, ["--frames", "150"])])
+def test_bench_strong_scaling_configs_two_rank_dry_run(config, batch, extra):
+    """BASELINE.json's 8-GPU configurations as bench modes (configs[2]: beam 500; configs[4]: with the LM scorer), strong
+    scaling: the named TOTAL batch is cut into contiguous blocks (shard_bounds).  Dry run with two ranks on this box's one
+    device (gloo), shrunk in batch / frames; cpu_baseline is part of every line."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", str(config), "--steps", "2", "--warmup", "1",
+                        "--batch", str(batch), "--cpu-seconds", "2"] + extra, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["global_batch"] == batch and d["config"]["utterances_per_gpu"] == batch // 2
+    assert d["value"] > 0 and len(d["kernel_ms_per_rank"]) == 2 and d["cpu_baseline"]["value"] > 0
+    assert ("configs[%d]" % config) in d["metric"]
+
+
+@pytest.mark.gpu
+def test_compact_gather_one_decoder_depth_two_device_backend():
+    """decode_compact returns an owned label tensor, so ONE decoder feeding a depth-2 gatherer on a device backend
+    (one-rank RCCL group) cannot have batch i's labels overwritten by batch i+1's decode while they are being gathered."""
+    import subprocess
+
+    code = (
+        "import os,sys,numpy as np,torch,torch.distributed as dist\n"
+        "sys.path.insert(0,%r); sys.path.insert(0,os.path.join(%r,'tests'))\n"
+        "import oracle_util as ou, ctcdecode_amd\n"
+        "from ctcdecode_amd import distributed as dd\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "B,T,V,K=6,150,29,32\n"
+        "dev=torch.device('cuda:0')\n"
+        "dec=ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], beam_width=K, log_probs_input=True, device=dev)\n"
+        "g=dd.make_gatherer('compact',B,K,T,V,dev,dst=0,depth=2,decoder=dec,stream=torch.cuda.Stream(device=dev))\n"
+        "lps=[ou.synth_logprobs(B,T,V,9100+i) for i in range(4)]\n"
+        "outs=[]\n"
+        "for i,lp in enumerate(lps):\n"
+        "    g.submit(dec.decode_compact(torch.from_numpy(lp)))\n"
+        "g.wait(); torch.cuda.synchronize()\n"
+        "out,sc,ts,ln=(t.cpu().numpy() for t in g.last)\n"
+        "want=ou.decode(lps[-1],beam=K)\n"
+        "ou.assert_same(dict(tokens=out,scores=sc,timesteps=ts,lens=ln,nres=want['nres']),want,'last batch')\n"
+        "dist.destroy_process_group(); print('OK')\n") % (ROOT, ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_bench_gather_behind_next_decode_rccl_one_rank():
     """The N > 1 loop of bench.py on a one-rank RCCL group (the GPU box has one device; RCCL refuses two ranks on it): async
     compact decode tickets, status words fetched without draining the stream, collectives + expansion on a side stream."""

@@ -115,11 +115,11 @@ def test_lm_streaming_equals_one_shot(torch_mod, c):
 
 
 def test_lm_config5_shape_sample(torch_mod):
-    """BASELINE.json configs[4]: V=29, beam 100, T=1500, test.arpa with alpha 0.5 / beta 1.0 -- 16 utterances of that shape against
-    the oracle (restated; oracle/_ref where built), and reset_params taking effect."""
+    """BASELINE.json configs[4]: V=29, beam 100, T=1500, test.arpa with alpha 0.5 / beta 1.0 -- the 128 utterances of one GPU's share (16 on
+    small hosts) against the oracle (restated; oracle/_ref where built), and reset_params taking effect."""
     import ctcdecode_amd
 
-    B, T, V, K = 16, 1500, 29, 100
+    B, T, V, K = min(128, max(16, os.cpu_count() or 1)), 1500, 29, 100  # the whole per-GPU share (128) where the host has the cores
     lp = ou.synth_logprobs(B, T, V, 555)
     lp[:, :, LABELS29.index(" ")] += np.float32(1.0)
     lp[:, :, LABELS29.index("a")] += np.float32(1.0)

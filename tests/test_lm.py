@@ -204,6 +204,28 @@ def test_product_core_with_lm_degenerate_inputs():
             ou.assert_same(ou.decode(lp, scorer=ref, which="reference", **kw), want, what + " (oracle vs live reference)")
 
 
+def test_unigram_model_keeps_no_context():
+    """An order-1 ARPA model that lists back-off weights: kenlm's state for it has length 0, so no back-off is
+    ever added -- the product's tables, the restated oracle and the reference's scorer.cpp over the kenlm stand-in agree,
+    on single queries and on a decode."""
+    path = os.path.join(DATA, "unigram_bo.arpa")
+    labels = ["_", "a", "b", " "]
+    checkers = [ou.Scorer(0.8, 0.4, path, labels, w) for w in (("restated", "reference") if ou.have_reference() else ("restated",))]
+    for words in (["ab"], ["ab", "ba"], ["a", "b", "abba"], ["zz", "ab"], ["ab", "</s>"]):
+        got, meta = ou.core_host_lm_cond(path, labels, words)
+        assert meta[1] == 1
+        for sc in checkers:
+            assert got == sc.cond_logprob(words), (words, sc.which)
+    assert got == -0.9 / np.log10(np.e) or abs(got - (-0.9 / 0.4342944819)) < 1e-5  # "</s>" alone: no back-off of "ab" added
+    lp = ou.synth_logprobs(2, 80, 4, 41)
+    lp[:, :, 3] += np.float32(1.0)
+    kw = dict(beam=20, blank_id=0)
+    want = ou.decode(lp, scorer=checkers[0], **kw)
+    ou.assert_same(ou.decode_core_host_lm(lp, 0.8, 0.4, path, labels, **kw), want, "unigram model, product core")
+    if len(checkers) > 1:
+        ou.assert_same(ou.decode(lp, scorer=checkers[1], which="reference", **kw), want, "unigram model, live reference")
+
+
 @pytest.mark.parametrize("name", gu.lm_names())
 def test_restatement_and_product_core_match_committed_lm_fixtures(name):
     args, lm, want = gu.load_lm(name)
