@@ -90,6 +90,11 @@ class CTCBeamDecoder(object):
     def set_threads(self, n):
         _native.check(_native.lib.ctcd_set_threads(self._handle, int(n)))
 
+    def set_cu_sharing(self, mode=1):
+        """1: always launch the two-workgroups-per-CU build of the kernel (beam <= 128, <= 32 labels) -- for a serving loop
+        that keeps several launches in flight; 0: never; -1 (default): when a batch has more utterances than the GPU has CUs."""
+        _native.check(_native.lib.ctcd_set_cu_sharing(self._handle, int(mode)))
+
     def set_fixed_layout(self, on=True):
         """Test hook: False forces the run-time workspace layout also for small shapes (identical results)."""
         _native.check(_native.lib.ctcd_debug_set_fixed_layout(self._handle, 1 if on else 0))

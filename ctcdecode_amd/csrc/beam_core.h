@@ -161,6 +161,7 @@ struct Work {
   int *lslot;      // kListCap: their slots
   uint32_t *bitmap;  // one bit per slot: survives (select fast path)
   int *fin, *sstack;
+  int stage_skey;  // 1: the exact replay may stage its ranges in the LDS block of the slot keys (they live in LDS: not BIG == 2)
   int *apos;       // K: position of every beam entry in the reference's `prefixes` array (maintained in danger mode only)
   int *vars;
 };
@@ -173,14 +174,19 @@ CTC_HD P *carve_ptr(char *&p, size_t count) {
 }
 
 // Lay the workspace out in `base` (LDS on the GPU).  Returns bytes used; call with base == nullptr to size it.
-// BIG != 0: the arrays that only the rare paths touch per slot (info words, and the scratch of the exact replay) live in
-// `far` (HBM, per utterance) instead, so that wide beams still fit the 160 KiB of LDS; *far_bytes gets their size.
+// FARREP: the scratch of the exact std::nth_element replay (candidate list ek, stop positions lr: 12 bytes per slot,
+// touched in ~1 % of the frames) lives in `far` (HBM scratch, per utterance; L2-resident in practice) instead of LDS,
+// where it is half of the fixed-layout workgroup's 132 KB and keeps a second workgroup off the CU.  The replay's first
+// round then runs in `far`; the range that remains is staged in LDS (Decoder::replay_nth_element).  Costs ~5 % of a lone
+// launch (measured), buys 1.4-1.5x when two workgroups share a CU: the library picks per call (ctcdecode_amd.hip).
+// BIG != 0 (implies FARREP): the per-slot info words live in `far` as well (and are only written on the rare paths:
+// LAZY), so that wide beams still fit the 160 KiB of LDS; *far_bytes gets the size of everything in `far`.
 // BIG == 1: the rare-path per-slot arrays in HBM; BIG == 2: also the slot keys and the rarely read per-entry arrays
 // (dead-interior bookkeeping, existing-child ranks): the widest beams, slowly.
-template <int BIG>
+template <int BIG, bool FARREP = false>
 CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_bytes) {
   char *p = base;
-  char *q = BIG ? far : nullptr;
+  char *q = far;
   constexpr bool deep = BIG >= 2;  // (a compile-time choice: every array keeps a static address space, LDS or global)
   const size_t K = (size_t)d.K, S = (size_t)d.S_max();
   const size_t Kr = ((K * 4 + 15) / 16) * 16;
@@ -227,9 +233,11 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.vars = carve_ptr<int>(p, VAR_COUNT);
   char *&r = BIG ? q : p;
   w.sinfo = carve_ptr<uint32_t>(r, S);
-  w.pos = carve_ptr<uint32_t>(r, S + 2);
-  w.ek = carve_ptr<uint64_t>(r, S); w.lr = carve_ptr<uint16_t>(r, 2 * S + 2);
-  if (far_bytes) *far_bytes = BIG ? (size_t)(q - far) : 0;
+  w.pos = carve_ptr<uint32_t>(r, K + 2);  // (finish(): label offsets of the compact results)
+  char *&rr = (BIG || FARREP) ? q : p;
+  w.ek = carve_ptr<uint64_t>(rr, S); w.lr = carve_ptr<uint16_t>(rr, 2 * S + 2);
+  w.stage_skey = deep ? 0 : 1;
+  if (far_bytes) *far_bytes = (size_t)(q - far);
   return (size_t)(p - base);
 }
 
@@ -298,6 +306,18 @@ struct OutRefs {
 };
 enum : int { ST_COMPACT_OVERFLOW = 3 };
 
+// An execution policy seen through "every barrier is a full fence": for the stretches of the exact replay that work on
+// arrays in HBM scratch while the kernel's ordinary barriers only wait for LDS traffic.
+template <class X>
+struct FullSyncView {
+  X &x;
+  CTC_HD int tid() const { return x.tid(); }
+  CTC_HD int nt() const { return x.nt(); }
+  CTC_HD void sync() { x.sync_full(); }
+  CTC_HD int uni(int v) const { return x.uni(v); }
+  CTC_HD void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) { x.block_scan_u32(mine, base_out, total_out); }
+};
+
 // IDENT: the utterance is decoded without vocabulary pruning (candidate r of every frame is label r).  A compile-time
 // switch: the two modes keep different things in flight across a frame (next row vs. next candidate list), and mixing
 // them in one instantiation makes the compiler wait for the prefetch where the other mode's registers are written.
@@ -318,14 +338,15 @@ constexpr int kSmallK = 128, kSmallV = 32;
 // candidates are scored.  The <= K survivors find theirs with a binary search over the entries' slot offsets
 // (info_of_slot); the rare paths that look at every slot (ties at the K boundary, exact replay) first rebuild all of them
 // (fill_info).  Round 2 wrote S info words per frame to HBM: 30 GB per configs[2] launch, 18x the algorithmic bytes.
-template <class X, bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false>
+// FARREP: the exact replay's scratch lives in HBM (carve).
+template <class X, bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY>
 struct Decoder {
   X &x;
   Work &w;
   const Dims d;
   const int blank;
   PoolNode *pool;
-  int *pool_up;  // up(X) per pool node
+  int *pool_up;  // up(X), stored for the nodes whose depth is a multiple of kExpress only
   const int pool_cap;
   const uint64_t *tbl;  // exact_math tables
   const ctclm::LmView *lm;  // LM tier only
@@ -470,7 +491,8 @@ struct Decoder {
   }
   // The order std::nth_element leaves N candidates (w.skey / w.sinfo over S slots) in: fin[p] / apos[] of the K survivors.
   // rk[p] = DFS rank (= index in the next beam) of the survivor at array position p is left in w.surv + K as well.
-  CTC_HD void nth_element_order(int S, int N, int K) {
+  // Returns true when the replay used the block of the slot keys as its staging area (w.skey[] is then garbage).
+  CTC_HD bool nth_element_order(int S, int N, int K) {
     const int tid = x.tid(), nt = x.nt();
     int *rk = w.surv + K, *ord = w.surv + 2 * K;
     {  // the candidates in DFS (= slot) order: (48-bit key, slot) of every slot that is not a hole
@@ -480,9 +502,12 @@ struct Decoder {
       x.compact_slots_to(S, [=](int s) -> bool { return info_type(sinfo[s]) != T_HOLE; },
                          [=](int r, int s) { ek[r] = (key48(skey[s], sinfo[s]) << 16) | (uint64_t)s; });
     }
-    replay_nth_element(N, K);
+    FullSyncView<X> fx{x};
+    if (FARREP) fx.sync();  // the list is in HBM scratch
+    const bool keys_gone = replay_nth_element(fx, N, K);
     for (int k = tid; k < K; k += nt) { rk[k] = 0; ord[k] = (int)(w.ek[k] & 0xFFFFu); }  // ord: nth_element order
     x.sync();
+    return keys_gone;
   }
   // Called when VAR_DANGER has just been seen set: the frame decoded last (if any in this launch) was pruned without
   // recording its permutation; its slots are still in place, so the replay is done now.
@@ -491,7 +516,8 @@ struct Decoder {
     st_danger = 1;
     select_beams();  // (the replay may stage its ranges in the block of the beam that is not current)
     const int N = x.uni(w.vars[VAR_LASTN]), S = x.uni(w.vars[VAR_LASTS]);
-    if (N < 0) return;  // nothing decoded in this launch yet: init() / load_state() left the order of the incoming beam
+    if (N < 0) return;  // -1: nothing decoded in this launch yet: init() / load_state() left the order of the incoming beam;
+                        // -2: the last frame replayed std::nth_element itself and recorded the order
     x.sync();
     if (N > K) {
       if (LAZY) {  // the frame's info words were never stored: its layout (ostart / cstart), keys and candidate labels are still in place
@@ -515,11 +541,15 @@ struct Decoder {
   CTC_HD void poll_danger() {
     if (CTC_RARE(x.uni(w.vars[VAR_DANGER]) != 0 && !st_danger)) enter_danger();
   }
+  // K packed (key, entry) words for the std::sort replays: in LDS (the block of the slot keys is idle between frames and
+  // after the last one) wherever the slot keys are
+  CTC_HD uint64_t *sort_scratch() const { return FARREP && w.stage_skey ? reinterpret_cast<uint64_t *>(w.skey) : w.ek; }
+
   // With a scorer the frame starts by sorting `prefixes` (ctc_beam_search_decoder.cpp:75-76): the contributions of this
   // frame then come in THAT order.  apos[] := position after the sort (fin[] keeps the order std::nth_element left).
   CTC_HD void lm_sorted_order(const Beam &b, int n) {
     const int tid = x.tid(), nt = x.nt();
-    uint64_t *pk = w.ek;
+    uint64_t *pk = sort_scratch();
     for (int p = tid; p < n; p += nt) {
       const int a = w.fin[p];
       pk[p] = (key48(ord_f32(b.score[a]), mk_info(b.ch[a], 0, 0)) << 16) | (uint64_t)a;
@@ -858,46 +888,67 @@ struct Decoder {
   // One partition step of std::nth_element on v[first, last) (median of three to the front, unguarded Hoare partition of
   // the rest: stl_emul.h split_with_median_pivot) by the whole workgroup.  Lp, Rp: scratch for last - first + 1 positions
   // each.  Returns the cut.
-  CTC_HD int hoare_round(uint64_t *v, int first, int last, uint16_t *Lp, uint16_t *Rp) {
-    return stlemu::hoare_round_parallel(x, v, first, last, [](uint64_t e) { return e >> 16; }, Lp, Rp, &w.vars[VAR_CUT]);
+  template <class XX>
+  CTC_HD int hoare_round(XX &xx, uint64_t *v, int first, int last, uint16_t *Lp, uint16_t *Rp) {
+    return stlemu::hoare_round_parallel(xx, v, first, last, [](uint64_t e) { return e >> 16; }, Lp, Rp, &w.vars[VAR_CUT]);
   }
 
   // std::nth_element(begin, begin+K, end, prefix_compare) on the DFS-ordered candidate list (w.ek[0, N)).
-  CTC_HD void replay_nth_element(int N, int K) {
+  // The list lives in HBM scratch: `fx` = the execution policy with every barrier a full fence (it also waits for global
+  // memory), used for the rounds that run there.  Once the range is short enough it moves into LDS -- the elements into
+  // the block of the slot keys (dead from here on: the emission takes the survivors' keys from the list itself), the stop
+  // positions into the block of the NEXT beam (nothing lives there until the emission); widest-beam layout, whose slot
+  // keys are not in LDS: both into the next beam's block -- positions rebased to the range's start, and moves back when
+  // the selection is done.  Returns true when the slot keys were overwritten.
+  template <class XX>
+  CTC_HD bool replay_nth_element(XX &fx, int N, int K) {
     const int tid = x.tid(), nt = x.nt();
     uint64_t *v = w.ek;
     auto before = [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); };
     int first = 0, last = N, depth = 2 * stlemu::floor_lg(N);
-    // Wide-beam layouts keep the candidate list in HBM: every barrier of a round then also waits for global memory.  Once
-    // the range is short enough it moves into the LDS block of the NEXT beam (nothing lives there until the emission),
-    // positions rebased to the range's start, and moves back when the selection is done.
-    const int stage_cap = x.far() ? (int)((w.beam_blk - 16) / 12) : 0;  // 8 B per element + two 16-bit position lists
+    if (!FARREP) {  // everything in LDS
+      while (last - first > kSerialCut && depth > 0) {
+        --depth;
+        const int cut = hoare_round(x, v, first, last, w.lr, w.lr + N + 1);
+        if (cut <= K) first = cut; else last = cut;
+      }
+      if (tid == 0) stlemu::introselect(v, first, K, last, depth, before);
+      x.sync();
+      return false;
+    }
+    uint64_t *sv = reinterpret_cast<uint64_t *>(w.nxt.node);
+    int stage_cap = (int)((w.beam_blk - 16) / 12);  // 8 B per element + two 16-bit position lists
+    if (w.stage_skey) {
+      sv = reinterpret_cast<uint64_t *>(w.skey);
+      const int cap_e = d.S_max() / 2, cap_p = (int)(w.beam_blk / 4) - 2;
+      stage_cap = cap_e < cap_p ? cap_e : cap_p;
+    }
     while (last - first > kSerialCut && depth > 0 && last - first > stage_cap) {
       --depth;
-      const int cut = hoare_round(v, first, last, w.lr, w.lr + N + 1);
+      const int cut = hoare_round(fx, v, first, last, w.lr, w.lr + N + 1);
       if (cut <= K) first = cut; else last = cut;
     }
-    if (x.far() && last - first > kSerialCut && depth > 0) {
+    if (last - first > kSerialCut && depth > 0) {
       const int m0 = last - first, base = first;
-      uint64_t *sv = reinterpret_cast<uint64_t *>(w.nxt.node);
-      uint16_t *sLp = reinterpret_cast<uint16_t *>(sv + m0), *sRp = sLp + m0 + 1;
+      uint16_t *sLp = w.stage_skey ? reinterpret_cast<uint16_t *>(w.nxt.node) : reinterpret_cast<uint16_t *>(sv + m0), *sRp = sLp + m0 + 1;
       for (int i = tid; i < m0; i += nt) sv[i] = v[base + i];
       x.sync();
       int f2 = 0, l2 = m0;
       const int K2 = K - base;
       while (l2 - f2 > kSerialCut && depth > 0) {
         --depth;
-        const int cut = hoare_round(sv, f2, l2, sLp, sRp);
+        const int cut = hoare_round(x, sv, f2, l2, sLp, sRp);
         if (cut <= K2) f2 = cut; else l2 = cut;
       }
       if (tid == 0) stlemu::introselect(sv, f2, K2, l2, depth, before);
       x.sync();
       for (int i = tid; i < m0; i += nt) v[base + i] = sv[i];
-      x.sync();
-      return;
+      fx.sync();
+      return w.stage_skey != 0;
     }
     if (tid == 0) stlemu::introselect(v, first, K, last, depth, before);
-    x.sync();
+    fx.sync();
+    return false;
   }
 
   // One time step.  w.clp/w.cch (and rank_of in pruned mode) hold this step's candidates; `last` selects the
@@ -1164,6 +1215,7 @@ struct Decoder {
     uint32_t tau = 0, tauc = 0;
     bool exact = false, have_bitmap = false;
     bool info_ready = !LAZY;  // (LAZY: w.sinfo[] is rebuilt by whichever rare path needs all of it first)
+    bool keys_in_ord = false;  // the exact replay overwrote w.skey[]: the survivors' keys are in ord[] (by beam position)
     if (CTC_USUAL(N > K)) {  // ctc_beam_search_decoder.cpp:150
       have_bitmap = select_kth(S, K, pv, wd);
       int tv[4];
@@ -1189,7 +1241,7 @@ struct Decoder {
     const int n_new = N < K ? N : K;
     if (CTC_RARE(exact)) {
       if (LAZY && !info_ready) { fill_info(b, n, Vnb, brank); info_ready = true; }
-      nth_element_order(S, N, K);
+      keys_in_ord = nth_element_order(S, N, K);
       for (int q = tid; q < K; q += nt) {  // rank by slot
         const int mine = ord[q];
         int r = 0;
@@ -1198,6 +1250,10 @@ struct Decoder {
         surv[r] = mine;
       }
       x.sync();
+      if (keys_in_ord) {
+        for (int q = tid; q < K; q += nt) ord[rk[q]] = (int)(uint32_t)(w.ek[q] >> 32);
+        x.sync();
+      }
       x.mark(6);
     } else if (have_bitmap) {
       x.template expand_bitmap<LM>(w.bitmap, (S + 63) / 64, surv);
@@ -1251,7 +1307,7 @@ struct Decoder {
           for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }
           if (t0 == 0) {
             reset_pvars(pvars(in.t + 1));
-            w.vars[VAR_LASTN] = N; w.vars[VAR_LASTS] = S;  // (enter_danger)
+            w.vars[VAR_LASTN] = exact ? -2 : N; w.vars[VAR_LASTS] = S;  // (enter_danger)
             if (LAZY) { w.vars[VAR_LASTNENT] = n; w.vars[VAR_LASTBRANK] = brank; }
           }
         }
@@ -1289,10 +1345,15 @@ struct Decoder {
           if (child) {                                                                // path_trie.cpp:97-105
             PoolNode pn; pn.parent = node_j; pn.ch = c; pn.tstep = in.t; pn.lpc = w.clp[rank_of_char(in, c)];
             pool[id] = pn;
-            pool_up[id] = upv;
+            // (up(X) is read back only from express nodes -- the back-trace hops from one multiple of kExpress levels to
+            //  the next -- so only those store it: 1 node in kExpress)
+            if (((dep_j + 1) & (kExpress - 1)) == 0) pool_up[id] = upv;
           } else if (CTC_RARE(!self)) {                                                         // path_trie.cpp:50-56 : revived
             const int P = w.anc[j];
-            o_node = via_j; o_par = b.node[P]; o_dep = b.dep[P] + 1; o_up = pool_up[via_j];
+            o_node = via_j; o_par = b.node[P]; o_dep = b.dep[P] + 1;
+            int xu = via_j;  // up(revived node): its ancestor at depth ((d - 1) / kExpress) * kExpress, found by walking (rare)
+            for (int h = o_dep - ((o_dep - 1) / kExpress) * kExpress; h > 0; --h) xu = pool[xu].parent;
+            o_up = xu;
           }
           nb.node[k] = o_node; nb.par[k] = o_par; nb.ch[k] = o_ch; nb.dep[k] = o_dep;
           nb.via[k] = via_j; nb.viaanc[k] = o_viaanc; nb.viach[k] = viach_j; nb.up[k] = o_up;  // via/viach: only read when viaanc matches
@@ -1320,7 +1381,7 @@ struct Decoder {
         }
         if (r_lm) lm_emit(b, (self || child) ? j : w.anc[j], self ? -1 : c, nb, k);
         if (r_prob) {
-          const uint32_t ks = w.skey[s];
+          const uint32_t ks = keys_in_ord ? (uint32_t)ord[k] : w.skey[s];
           kloc = ks > kloc ? ks : kloc;
           kmin = ks < kmin ? ks : kmin;
         }
@@ -1330,7 +1391,7 @@ struct Decoder {
       x.wave_max_to(&pv[P_NMAXKEY], kloc);
       if (LM) x.wave_min_to(&pv[P_NMINKEY], kmin);
     }
-    if (CTC_RARE(last || st_danger)) {  // the order std::nth_element left the survivors in (identity when it was not called)
+    if (CTC_RARE(last || st_danger || exact)) {  // the order std::nth_element left the survivors in (identity when it was not called)
       for (int q = tid; q < n_new; q += nt) {
         const int r = exact ? rk[q] : q;
         w.fin[q] = r;
@@ -1418,7 +1479,7 @@ struct Decoder {
     {
       const float *sc = b.score;
       const int *ch = b.ch;
-      uint64_t *pk = w.ek;
+      uint64_t *pk = sort_scratch();
       if (LM) {
         for (int a = tid; a < n; a += nt) {
           // the word the prefix ends in, when it does not end in a space (:173-185; word models only)
@@ -1597,13 +1658,13 @@ struct PrunedRows {
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
 // LM tier: `lm` = the scorer's tables, `raw` = the caller's own [len, V] rows (log-probabilities or probabilities,
 // `raw_log` says which): ctc_beam_search_decoder.cpp:78 takes the blank's log-probability from them directly.
-template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, class X>
+template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr, const ctclm::LmView *lm = nullptr, const float *raw = nullptr,
                             int raw_log = 1) {
   if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
-  Decoder<X, IDENT, SMALLV, LM, LAZY> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
+  Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   if (t0 > 0) dec.load_state(*ss); else dec.init();

@@ -33,7 +33,7 @@ using namespace ctcbeam;
 
 // (execution policy + kernel template: decode_kernel.h; its instantiations are compiled in decode_kernels.hip)
 using namespace ctcdk;
-#define CTC_X_EXTERN(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, G_) extern template __global__ void ctcdk::ctc_beam_decode_kernel<PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_>(ctcdk::KernelArgs);
+#define CTC_X_EXTERN(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, OCC2_, G_) extern template __global__ void ctcdk::ctc_beam_decode_kernel<PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, OCC2_>(ctcdk::KernelArgs);
 } namespace ctcdk { CTC_KERNEL_LIST(CTC_X_EXTERN) } namespace {
 #undef CTC_X_EXTERN
 
@@ -829,6 +829,9 @@ struct ctcd_decoder {
   HostPool *workers = nullptr;
   int threads = 0;  // 0 = choose per call from the number of candidate slots
   int max_lds = 0;
+  int cu_count = 0;
+  long long lds_floor = -1;  // CTCD_LDS_FLOOR (experiments): dynamic LDS bytes every decode launch asks for at least
+  int cu_sharing = -1;       // ctcd_set_cu_sharing: 1 = always launch the two-workgroups-per-CU build, 0 = never, -1 = when B > #CUs
   Buf pool, status, tables, logp, lsm, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
   Buf prune_in, prune_out, st_lens;  // own staging: the host-pointer entry points keep their tensors in stage_in/out
   long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
@@ -976,6 +979,9 @@ int ctcd_create(ctcd_decoder **out, int device_id) {
   int v = 0;
   HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id));
   d->max_lds = v;
+  HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id));
+  d->cu_count = v;
+  if (const char *e = getenv("CTCD_LDS_FLOOR")) d->lds_floor = atoll(e);
   *out = d;
   return CTCD_OK;
 }
@@ -991,6 +997,12 @@ void ctcd_destroy(ctcd_decoder *d) {
   if (d->h_stage) (void)hipHostFree(d->h_stage);
   delete d->workers;
   delete d;
+}
+
+int ctcd_set_cu_sharing(ctcd_decoder *d, int mode) {
+  if (!d || mode < -1 || mode > 1) return fail(CTCD_EINVAL, "cu sharing mode must be -1 (automatic), 0 or 1");
+  d->cu_sharing = mode;
+  return CTCD_OK;
 }
 
 int ctcd_set_threads(ctcd_decoder *d, int t) {
@@ -1030,7 +1042,9 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   // (the LM tier has the fixed-layout kernel at 1024 threads only)
   const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout && (!scorer || threads == 1024);
   const Dims ldims = fixed ? fixed_layout_dims(scorer != nullptr) : dims;
-  size_t lds = carve<0>(wtmp, nullptr, nullptr, ldims, nullptr);
+  // two workgroups per CU (OCC2 build of the fixed-layout kernel): batches that outnumber the CUs, or on request
+  const bool occ2 = fixed && threads == 1024 && !d->profile && (d->cu_sharing == 1 || (d->cu_sharing < 0 && B > d->cu_count));
+  size_t lds = occ2 ? carve<0, true>(wtmp, nullptr, nullptr, ldims, &far_bytes) : carve<0>(wtmp, nullptr, nullptr, ldims, &far_bytes);
   bool big = false;
   int far_level = 1;
   if (lds + 2048 > (size_t)d->max_lds) {  // wide beam: rare-path arrays go to HBM scratch
@@ -1040,13 +1054,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       far_level = 2;
       lds = carve<2>(wtmp, nullptr, nullptr, dims, &far_bytes);
     }
-    far_bytes = (far_bytes + 255) / 256 * 256;
   }
+  far_bytes = (far_bytes + 255) / 256 * 256;
   if (lds + 2048 > (size_t)d->max_lds)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) needs " + std::to_string(lds) + " B of LDS, more than one workgroup has");
   if (big && scorer) return fail(CTCD_EUNSUPPORTED, "the LM tier does not fit this beam width / vocabulary in LDS yet");
   if (scorer && d->profile && !d->tl_armed) return fail(CTCD_EUNSUPPORTED, "the phase-timer kernel builds do not include the LM tier (the barrier timeline does)");
-  if (big && (rc = d->far.ensure((size_t)B * far_bytes))) return rc;
+  if ((rc = d->far.ensure((size_t)B * far_bytes))) return rc;
 
   // outputs: everything outside the valid region is defined as 0
   const size_t kt = co ? 0 : (size_t)B * beam * out_T;
@@ -1306,6 +1320,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (big || !fixed || pruned_mode || scorer || threads != 1024 || (d->profile && !d->tl_armed))
     return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD: only the fixed-layout, no-prune, no-LM, 1024-thread kernel was compiled");
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
+  if (occ2) fn = (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
 #else
 #define CTC_PICK(PROF_)                                                                                                  \
   (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, false>)    \
@@ -1318,6 +1333,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   }
   if (!d->profile && fixed && !big && threads == 1024)  // the usual case: workgroup size folded into the code
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
+  if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, false, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
   if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes only
     if (big || !fixed || pruned_mode) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels, no pruning");
     if (threads != 1024) return fail(CTCD_EUNSUPPORTED, "barrier timeline: 1024 threads per workgroup (the product configuration)");
@@ -1328,12 +1344,15 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 0, 0, false, 0, true>;
     if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
       fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
+    if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true, true>;
     if (d->profile && d->tl_armed) {  // (shape conditions checked above)
       if (!fixed) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels");
       fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true>;
     }
   }
 #endif
+  // (CTCD_LDS_FLOOR: experiments with the occupancy the LDS request allows)
+  if (d->lds_floor >= 0) lds = std::max(lds, std::min((size_t)d->lds_floor, (size_t)d->max_lds - 2048));
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (d->timing) HIP_TRY(hipEventRecord(d->ev0, stream));
   void *kargs[] = {&a};

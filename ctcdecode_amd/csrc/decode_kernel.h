@@ -373,23 +373,12 @@ struct DevX {
     if (threadIdx.x < 64) {
       const int lane = (int)threadIdx.x;
       const int c = 63 - lane;  // lane 0 owns the TOP coarse bucket: a prefix scan over lanes is a suffix sum over buckets
-#if defined(CTC_EXP_FB_B128)
-      const int4 *f4 = reinterpret_cast<const int4 *>(bins + 16 * c);  // its 16 fine buckets: four 128-bit reads, one round trip
+      // its 16 fine buckets: four 128-bit reads, one round trip.  (Measured in round 3: reading them one dword per step in a
+      // lane-rotated, bank-conflict-free order is 1 % SLOWER -- 16 dependent address computations cost more than the
+      // conflicts of the four wide reads.)
+      const int4 *f4 = reinterpret_cast<const int4 *>(bins + 16 * c);
       const int4 q0 = f4[0], q1 = f4[1], q2 = f4[2], q3 = f4[3];
       const int cv = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) + ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));
-#else
-      // its 16 fine buckets, one dword per step in a lane-rotated order: a lane's buckets start 64 bytes after its
-      // neighbour's, so reading them front to back (or 128 bits at a time) lands all 64 lanes on two groups of four banks
-      // -- a 32-way bank conflict; rotated by lane / 2, the 64 lanes of a step cover all 32 banks twice.
-      const int *fb = bins + 16 * c;
-      const int rot = lane >> 1;
-      int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll
-      for (int j = 0; j < 16; j += 4) {
-        p0 += fb[(j + rot) & 15]; p1 += fb[(j + 1 + rot) & 15]; p2 += fb[(j + 2 + rot) & 15]; p3 += fb[(j + 3 + rot) & 15];
-      }
-      const int cv = (p0 + p1) + (p2 + p3);
-#endif
       const int incl = wave_scan(cv, 0, [](int a, int b) { return a + b; });
       const int total = __builtin_amdgcn_readlane(incl, 63);
       const unsigned long long m = __ballot(incl >= need);
@@ -473,7 +462,7 @@ struct KernelArgs {
   int *dbg;                 // profiling build: beam of item 0 after every frame, [T][1 + 4K] (or null)
   long long *tl;            // profiling build: barrier timeline of item 0, [waves][tl_cap] (or null)
   int tl_cap, tl_f0, tl_nf;
-  char *far;                // BIG layout: per-utterance HBM scratch, far_stride bytes each
+  char *far;                // per-utterance HBM scratch (exact-replay arrays; wide-beam layouts: more), far_stride bytes each
   long long far_stride;
   // streaming (ctcd_stream_decode): per item, the HBM block that holds its parked beam + node pool
   char **st_base;           // [B] or null
@@ -499,16 +488,21 @@ __host__ __device__ constexpr Dims fixed_layout_dims(bool lm = false) { return D
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
 
 // PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
-template <int PROF, int BIG, int LAYOUT, bool PRUNED, int NT = 0, bool LM = false>
-__global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
+// OCC2 (fixed layout only): the build for two workgroups per CU -- at most 64 VGPRs (8 waves per SIMD) and the exact
+// replay's scratch in HBM (67 KB of LDS instead of 132 KB).  A lone workgroup runs ~7 % slower than in the default build
+// (fewer registers, replay rounds in HBM), two per CU together 1.4-1.5x faster: the library launches this build for
+// batches that outnumber the CUs and when the caller keeps several launches in flight (ctcd_set_cu_sharing).
+template <int PROF, int BIG, int LAYOUT, bool PRUNED, int NT = 0, bool LM = false, bool OCC2 = false>
+__global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
   __shared__ int red[32];
   const int b = (int)blockIdx.x;
   if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
   Work w;
-  if (LAYOUT == 1) carve<0>(w, smem, nullptr, fixed_layout_dims(LM), nullptr);
-  else carve<BIG>(w, smem, BIG ? a.far + (size_t)b * a.far_stride : nullptr, a.dims, nullptr);
+  // (every layout keeps the exact replay's scratch in per-utterance HBM scratch; the wide-beam layouts more: beam_core.h carve)
+  if (LAYOUT == 1) carve<0, OCC2>(w, smem, a.far + (size_t)b * a.far_stride, fixed_layout_dims(LM), nullptr);
+  else carve<BIG>(w, smem, a.far + (size_t)b * a.far_stride, a.dims, nullptr);
   __shared__ long long prof[16];
   constexpr int kTlCap = LM ? kTimelineCap / 2 : kTimelineCap;  // (the LM tier's workspace leaves 8 KB for the stamps)
   __shared__ long long tlbuf[PROF == 2 ? 16 * kTlCap : 1];
@@ -555,7 +549,7 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
 #else
   if (LM) lmv = &a.lm;
 #endif
-  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM, BIG != 0>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
+  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM, BIG != 0, BIG != 0 || OCC2>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + (size_t)b * a.T * a.V : nullptr, a.raw_log);
   if (threadIdx.x == 0) a.status[b] = st;
@@ -566,21 +560,22 @@ __global__ void __launch_bounds__(1024) ctc_beam_decode_kernel(KernelArgs a) {
   if (PROF == 1 && threadIdx.x < 16) a.prof[(size_t)b * 16 + threadIdx.x] = prof[threadIdx.x];
 }
 
-// Every instantiation the library launches: X(PROF, BIG, LAYOUT, PRUNED, NT, LM, translation-unit group).
+// Every instantiation the library launches: X(PROF, BIG, LAYOUT, PRUNED, NT, LM, OCC2, translation-unit group).
 // decode_kernels.hip instantiates the ones of its group (-DCTC_KERNEL_GROUP=g); ctcdecode_amd.hip declares them all extern.
 #define CTC_KERNEL_GROUPS 12
-#if defined(CTC_QUICK_BUILD)  // experiment builds: the north-star class kernel and its barrier-timeline twin only
+#if defined(CTC_QUICK_BUILD)  // experiment builds: the north-star class kernels and the barrier-timeline twin only
 #define CTC_KERNEL_LIST(X) \
-  X(0, 0, 1, false, 1024, false, 0) X(2, 0, 1, false, 1024, false, 1)
+  X(0, 0, 1, false, 1024, false, false, 0) X(2, 0, 1, false, 1024, false, false, 1) X(0, 0, 1, false, 1024, false, true, 1)
 #else
-#define CTC_KERNEL_LIST(X)                                                                                              \
-  X(0, 0, 1, false, 1024, false, 0) X(0, 0, 1, true, 1024, false, 1) X(2, 0, 1, false, 1024, false, 2)                      \
-  X(0, 1, 0, false, 0, false, 3) X(0, 1, 0, true, 0, false, 4) X(0, 2, 0, false, 0, false, 5) X(0, 2, 0, true, 0, false, 5)   \
-  X(0, 0, 0, false, 0, false, 6) X(0, 0, 0, true, 0, false, 6) X(0, 0, 1, false, 0, false, 7) X(0, 0, 1, true, 0, false, 7)   \
-  X(1, 1, 0, false, 0, false, 8) X(1, 1, 0, true, 0, false, 8) X(1, 0, 1, false, 0, false, 9) X(1, 0, 1, true, 0, false, 9)   \
-  X(1, 0, 0, false, 0, false, 10) X(1, 0, 0, true, 0, false, 10)                                                          \
-  X(0, 0, 0, false, 0, true, 11) X(0, 0, 0, true, 0, true, 11) X(0, 0, 1, false, 1024, true, 2) X(0, 0, 1, true, 1024, true, 3) \
-  X(2, 0, 1, false, 1024, true, 4)
+#define CTC_KERNEL_LIST(X)                                                                                                          \
+  X(0, 0, 1, false, 1024, false, false, 0) X(0, 0, 1, true, 1024, false, false, 1) X(2, 0, 1, false, 1024, false, false, 2)               \
+  X(0, 1, 0, false, 0, false, false, 3) X(0, 1, 0, true, 0, false, false, 4) X(0, 2, 0, false, 0, false, false, 5) X(0, 2, 0, true, 0, false, false, 5) \
+  X(0, 0, 0, false, 0, false, false, 6) X(0, 0, 0, true, 0, false, false, 6) X(0, 0, 1, false, 0, false, false, 7) X(0, 0, 1, true, 0, false, false, 7) \
+  X(1, 1, 0, false, 0, false, false, 8) X(1, 1, 0, true, 0, false, false, 8) X(1, 0, 1, false, 0, false, false, 9) X(1, 0, 1, true, 0, false, false, 9) \
+  X(1, 0, 0, false, 0, false, false, 10) X(1, 0, 0, true, 0, false, false, 10)                                                       \
+  X(0, 0, 0, false, 0, true, false, 11) X(0, 0, 0, true, 0, true, false, 11) X(0, 0, 1, false, 1024, true, false, 2)                     \
+  X(0, 0, 1, true, 1024, true, false, 3) X(2, 0, 1, false, 1024, true, false, 4)                                                       \
+  X(0, 0, 1, false, 1024, false, true, 0) X(0, 0, 1, true, 1024, false, true, 1) X(0, 0, 1, false, 1024, true, true, 10) X(0, 0, 1, true, 1024, true, true, 11)
 #endif
 
 }  // namespace ctcdk

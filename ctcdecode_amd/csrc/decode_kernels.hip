@@ -10,8 +10,8 @@ namespace ctcdk {
 
 template <int G> struct InGroup { static constexpr bool value = G == (CTC_KERNEL_GROUP); };
 
-#define CTC_X_INST(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, G_) CTC_INST_##G_(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_)
-#define CTC_DO_INST(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_) template __global__ void ctc_beam_decode_kernel<PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_>(KernelArgs);
+#define CTC_X_INST(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, OCC2_, G_) CTC_INST_##G_(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, OCC2_)
+#define CTC_DO_INST(PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, OCC2_) template __global__ void ctc_beam_decode_kernel<PROF_, BIG_, LAYOUT_, PRUNED_, NT_, LM_, OCC2_>(KernelArgs);
 #if CTC_KERNEL_GROUP == 0
 #define CTC_INST_0(...) CTC_DO_INST(__VA_ARGS__)
 #else

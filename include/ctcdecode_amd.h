@@ -186,7 +186,12 @@ int ctcd_debug_beam_dump(ctcd_decoder *dec, int on, int *out, int T, int beam);
 
 /* Tuning / introspection. */
 int ctcd_set_threads(ctcd_decoder *dec, int threads_per_workgroup); /* 0 = automatic (default); else a power of two in [64, 1024] */
-int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob); /* LDS one utterance needs */
+/* Two workgroups per CU.  The fixed-layout class (beam <= 128, <= 32 labels) has a second build of its kernel that fits
+ * two utterances on a compute unit (<= 64 VGPRs; the exact replay's scratch in HBM: 67 KB of LDS instead of 132 KB): a lone
+ * workgroup runs ~7 % slower in it, two on a CU together 1.4-1.5x faster.  mode = -1 (default): used when a batch has
+ * more utterances than the device has CUs; 1: always (a serving loop that keeps several launches in flight); 0: never. */
+int ctcd_set_cu_sharing(ctcd_decoder *dec, int mode);
+int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob); /* LDS one utterance needs (default build) */
 const char *ctcd_last_error(void);
 const char *ctcd_version(void);
 

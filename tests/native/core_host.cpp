@@ -231,6 +231,7 @@ extern "C" int ctccore_decode_compact_f32(const float *probs, const int32_t *seq
   Work w;
   size_t far_bytes = 0;
   std::vector<char> mem(carve<0>(w, nullptr, nullptr, d, &far_bytes) + 64);
+  std::vector<char> far(far_bytes + 64);  // (the exact replay's scratch: HBM on the device)
   std::vector<int32_t> hdr((size_t)B * 4, 0), ent((size_t)B * beam * 4, 0);
   std::vector<uint32_t> rag((size_t)B * beam * T + 1);
   unsigned count = 0;
@@ -239,7 +240,7 @@ extern "C" int ctccore_decode_compact_f32(const float *probs, const int32_t *seq
     std::vector<int> pool_up(pool.size());
     int len = seq_lens ? seq_lens[b] : T;
     len = std::max(0, std::min(len, T));
-    carve<0>(w, mem.data(), nullptr, d, nullptr);
+    carve<0>(w, mem.data(), far.data(), d, nullptr);
     HostX x;
     const OutRefs outs{nullptr, nullptr, out_scores, out_lens, n_results, beam, T, hdr.data(), ent.data(), rag.data(), &count, (unsigned)(rag.size() - 1)};
     int st = decode_utterance<true>(x, w, d, blank_id, probs + (size_t)b * T * V, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(),
@@ -279,8 +280,9 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
     Work w;
     size_t far_bytes = 0;
     const bool big = getenv("CTC_HOST_BIG") != nullptr;  // exercise the HBM-scratch layouts too (CTC_HOST_BIG=1 or 2)
+    const bool farrep = !big && getenv("CTC_HOST_FARREP") != nullptr;  // ... and the layout whose replay scratch alone is "far"
     const int flevel = big && getenv("CTC_HOST_BIG")[0] == '2' ? 2 : 1;
-    std::vector<char> mem((!big ? carve<0>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
+    std::vector<char> mem((farrep ? carve<0, true>(w, nullptr, nullptr, d, &far_bytes) : !big ? carve<0>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
                                                                                    : carve<1>(w, nullptr, nullptr, d, &far_bytes)) + 64);
     std::vector<char> far(far_bytes + 64);
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
@@ -292,7 +294,8 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
       if (b >= B) return;
       int len = seq_lens ? seq_lens[b] : T;
       len = std::max(0, std::min(len, T));
-      if (!big) carve<0>(w, mem.data(), nullptr, d, nullptr);
+      if (farrep) carve<0, true>(w, mem.data(), far.data(), d, nullptr);
+      else if (!big) carve<0>(w, mem.data(), far.data(), d, nullptr);
       else if (flevel == 2) carve<2>(w, mem.data(), far.data(), d, nullptr);
       else carve<1>(w, mem.data(), far.data(), d, nullptr);
       HostX x;
@@ -313,6 +316,11 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
         if (pruned) st = decode_utterance<false, false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b);
         else st = decode_utterance<true, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
+      } else if (farrep) {
+        if (pruned) st = decode_utterance<false, false, false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
+        else st = decode_utterance<true, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b);
       } else if (beam <= 128 && V <= 32) {  // the shapes the device runs with its fixed layout
         if (pruned) st = decode_utterance<false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
@@ -360,7 +368,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       // a fresh workspace every chunk, as a new kernel launch would have
       std::fill(mem.begin(), mem.end(), (char)0x5a);
       std::fill(far.begin(), far.end(), (char)0x5a);
-      if (!big) carve<0>(w, mem.data(), nullptr, d, nullptr);
+      if (!big) carve<0>(w, mem.data(), far.data(), d, nullptr);
       else if (flevel == 2) carve<2>(w, mem.data(), far.data(), d, nullptr);
       else carve<1>(w, mem.data(), far.data(), d, nullptr);
       HostX x;

@@ -306,6 +306,94 @@ def test_degenerate_frames_inside_the_north_star_shape(torch_mod):
     ou.assert_same(_with_nres(_decode(torch_mod, lp, beam=100), want), want)
 
 
+def test_two_workgroups_per_cu_build(torch_mod):
+    """The second build of the fixed-layout kernel (<= 64 VGPRs, exact-replay scratch in HBM with LDS staging: 67 KB of LDS,
+    two utterances per CU): forced with set_cu_sharing(1), and picked automatically for a batch that outnumbers the CUs.
+    Same results as the default build: random cases, tie-heavy cases (many exact replays), degenerate inputs, pruning."""
+    import ctcdecode_amd
+    import degenerate_util as du
+
+    def run(lp, sl=None, mode=1, **kw):
+        V = lp.shape[2]
+        d = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=kw.get("cutoff_top_n", 40), beam_width=kw["beam"],
+                                         blank_id=kw.get("blank_id", 0), log_probs_input=True, device="cuda:0")
+        d.set_cu_sharing(mode)
+        out, sc, ts, ln = d.decode(torch_mod.from_numpy(lp), torch_mod.from_numpy(sl) if sl is not None else None)
+        return dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+
+    for c in CASES:
+        if c["K"] > 128 or c["V"] > 32:
+            continue
+        blank = c.get("blank_id", 0)
+        lp = ou.synth_logprobs(c["B"], c["T"], c["V"], c["seed"], quant=c.get("quant"), blank_bias=c.get("blank_bias", 0.0), blank_id=blank)
+        sl = np.array([c["T"], 0, 1, c["T"] // 2, c["T"] + 9][: c["B"]], np.int32) if c.get("ragged") else None
+        want = ou.decode(lp, sl, beam=c["K"], blank_id=blank)
+        ou.assert_same(_with_nres(run(lp, sl, beam=c["K"], blank_id=blank), want), want, "OCC2 %s" % c)
+    lp = ou.synth_logprobs(2, 400, 29, 321, quant=0.5)  # coarse values: ties at the K boundary in most frames -> exact replays
+    want = ou.decode(lp, beam=100)
+    ou.assert_same(_with_nres(run(lp, beam=100), want), want, "OCC2 tie-heavy")
+    lp = ou.synth_logprobs(2, 200, 29, 322)
+    want = ou.decode(lp, beam=64, cutoff_top_n=12)
+    ou.assert_same(_with_nres(run(lp, beam=64, cutoff_top_n=12), want), want, "OCC2 pruned")
+    rng = np.random.default_rng(77)
+    for it in range(24):
+        meta, lp = du.make_case(rng)
+        kw = dict(beam=meta["K"], blank_id=meta["blank"])
+        want = ou.decode(lp, **kw)
+        ou.assert_same(_with_nres(run(lp, **kw), want), want, "OCC2 degenerate %s" % meta)
+    # more utterances than CUs: the library switches to this build by itself
+    ncu = torch_mod.cuda.get_device_properties(0).multi_processor_count
+    lp = ou.synth_logprobs(ncu + 44, 40, 29, 323, quant=1.0)
+    want = ou.decode(lp, beam=100)
+    ou.assert_same(_with_nres(run(lp, mode=-1, beam=100), want), want, "B > #CUs")
+    ou.assert_same(_with_nres(run(lp, mode=0, beam=100), want), want, "B > #CUs, default build")
+
+
+def test_capability_boundaries(torch_mod):
+    """Every CTCD_EUNSUPPORTED edge of the no-LM path: on the supported side of a limit the call decodes
+    and matches the oracle; one step beyond, it raises NotImplementedError -- cleanly: the same decoder object then decodes
+    an ordinary batch correctly.  The limits: K * (candidates + 2) <= 65535 slots, beam_width <= 16383, labels <= 65534
+    (<= 32767 when pruning), one workgroup's LDS (beam ~1100 at V=29), compact results T <= 65536."""
+    import ctcdecode_amd
+
+    def dec_for(V, K, top_n=40, cutoff_prob=1.0):
+        return ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=top_n, cutoff_prob=cutoff_prob, beam_width=K,
+                                            log_probs_input=True, device="cuda:0")
+
+    def check(V, K, top_n, T=12, B=2, seed=5):
+        lp = ou.synth_logprobs(B, T, V, seed)
+        d = dec_for(V, K, top_n)
+        out, sc, ts, ln = d.decode(torch_mod.from_numpy(lp))
+        want = ou.decode(lp, beam=K, cutoff_top_n=top_n)
+        got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+        ou.assert_same(_with_nres(got, want), want, "V=%d K=%d top_n=%d" % (V, K, top_n))
+
+    def refused(V, K, top_n, T=12):
+        d = dec_for(V, K, top_n)
+        lp = ou.synth_logprobs(2, T, V, 6)
+        with pytest.raises(NotImplementedError):
+            d.decode(torch_mod.from_numpy(lp))
+        # the refusal left the decoder usable: a second, supported call on the same library state decodes correctly
+        check(29, 10, 40)
+
+    # candidate slots: K * (min(V, top_n) + 2) <= 65535
+    check(1000, 65, 1000)              # 65 * 1002 = 65130 slots, no pruning (cutoff_top_n >= V)
+    refused(1000, 66, 1000)            # 66 * 1002 = 66132
+    check(300, 200, 300, T=8)          # 200 * 302 = 60400
+    refused(300, 220, 300)             # 66440
+    check(2000, 100, 600, T=8)         # pruned: 100 * 602 = 60200
+    refused(2000, 110, 600)            # 66220
+    # the beam's own arrays: beam 1000 fits one workgroup's LDS (test_beam_width_1000), 1400 does not
+    refused(29, 1400, 40)
+    refused(29, 20000, 40)             # beyond the 14-bit entry index as well
+    # labels
+    refused(40000, 4, 40)              # pruning with more than 32767 labels
+    lp = ou.synth_logprobs(1, 3, 65535, 7)
+    with pytest.raises(NotImplementedError):
+        dec_for(65535, 1, 65535).decode(torch_mod.from_numpy(lp))
+    # wide beams decode without a scorer but not (yet) with one: see tests/test_gpu_lm.py::test_lm_capability_boundaries
+
+
 def test_host_pointer_entry_point(torch_mod):
     """ctcd_beam_decode_host: the entry point a maintainer of the reference would bind in place of paddle_beam_decode
      -- CPU buffers in, CPU buffers out, through the raw C ABI."""
