@@ -206,6 +206,22 @@ def other_configs(torch, ctcdecode_amd, dev):
                 model_path=arpa, alpha=0.5, beta=1.0)
         except Exception as e:  # the LM tier must not take the bench line down
             out["configs[4] with the LM scorer"] = {"error": str(e)[:200]}
+    # the same shape with a language model of realistic size (generated: 50 000 words, 3-gram, ~20 MB of ARPA text; the
+    # tables are tens of MB, so the kernel's look-ups miss L2 -- test.arpa's 37 unigrams never do)
+    if getattr(ctcdecode_amd, "HAVE_LM", False):
+        try:
+            import importlib.util
+            import tempfile
+
+            spec = importlib.util.spec_from_file_location("make_big_lm", os.path.join(ROOT, "tools", "make_big_lm.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            big = os.path.join(tempfile.gettempdir(), "ctcd_big_words_50k.arpa")
+            if not os.path.exists(big):
+                mod.make(big)
+            run("configs[4] per-GPU shape with a generated 50k-word 3-gram LM (alpha 0.5, beta 1.0)", 128, 1500, 29, 100, model_path=big, alpha=0.5, beta=1.0, reps=1)
+        except Exception as e:
+            out["configs[4] with the generated 50k-word LM"] = {"error": str(e)[:200]}
     return out
 
 

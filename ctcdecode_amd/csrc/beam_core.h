@@ -144,6 +144,8 @@ struct Work {
   // around the frame loop (26 pointers that would otherwise stay live in scalar registers).
   Beam cur, nxt, beam0;
   size_t beam_blk;  // bytes from an array of copy 0 to the same array of copy 1
+  size_t beam_blk_far;  // ... for the beam arrays that live in HBM scratch (wide-beam layouts)
+  size_t blk_via, blk_lm;  // which of the two applies to via / viaanc / viach and to the LM arrays
   int *e, *anc, *ostart, *cstart, *pinr, *revr;  // per beam entry, this step
   int *ancbuf, *acntbuf;  // 2K each: nearest in-beam ancestor / number of in-beam ancestors, painted; by step parity
   uint32_t *hit;   // 2 words per entry: ranks (non-blank numbering) of the children that already exist
@@ -191,27 +193,31 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   const size_t K = (size_t)d.K, S = (size_t)d.S_max();
   const size_t Kr = ((K * 4 + 15) / 16) * 16;
   Beam *bs[2] = {&w.cur, &w.nxt};
-  // the distance between the two copies of a beam array is the same for every array (Decoder::beam_at)
-  w.beam_blk = (size_t)(kBeamArrays - (deep ? 3 : 0) + (d.lm ? kBeamArraysLm : 0)) * Kr;
+  // the distance between the two copies of a beam array is the same for every array of one memory (Decoder::beam_at).
+  // Wide-beam layouts keep the scorer's per-entry state (LM tier) in HBM scratch: a capability, not a fast path.
+  constexpr bool lm_far = BIG != 0;
+  const size_t n_lm = d.lm ? (size_t)kBeamArraysLm : 0;
+  w.beam_blk = (size_t)(kBeamArrays - (deep ? 3 : 0) + (lm_far ? 0 : n_lm)) * Kr;
+  w.beam_blk_far = ((deep ? 3 : 0) + (lm_far ? n_lm : 0)) * Kr;
+  w.blk_via = deep ? w.beam_blk_far : w.beam_blk;
+  w.blk_lm = lm_far ? w.beam_blk_far : w.beam_blk;
   for (int i = 0; i < 2; ++i) {
     Beam &b = *bs[i];
+    char *f = q + (size_t)i * w.beam_blk_far;
     b.node = carve_ptr<int>(p, K); b.par = carve_ptr<int>(p, K); b.ch = carve_ptr<int>(p, K);
     b.dep = carve_ptr<int>(p, K); b.lcp = carve_ptr<int>(p, K);
-    if (deep) {
-      char *f = q + (size_t)i * w.beam_blk;
-      b.via = carve_ptr<int>(f, K); b.viaanc = carve_ptr<int>(f, K); b.viach = carve_ptr<int>(f, K);
-    } else {
-      b.via = carve_ptr<int>(p, K); b.viaanc = carve_ptr<int>(p, K); b.viach = carve_ptr<int>(p, K);
-    }
+    char *&pv3 = deep ? f : p;
+    b.via = carve_ptr<int>(pv3, K); b.viaanc = carve_ptr<int>(pv3, K); b.viach = carve_ptr<int>(pv3, K);
     b.up = carve_ptr<int>(p, K);
     b.bprev = carve_ptr<float>(p, K); b.nbprev = carve_ptr<float>(p, K); b.score = carve_ptr<float>(p, K);
     b.lpc = carve_ptr<float>(p, K);
     const size_t Kl = d.lm ? K : 0;
-    b.lmst = carve_ptr<int>(p, Kl); b.lmcl = carve_ptr<int>(p, Kl); b.acc_lo = carve_ptr<int>(p, Kl); b.acc_hi = carve_ptr<int>(p, Kl);
-    b.dn = carve_ptr<int>(p, Kl); b.dmlo = carve_ptr<int>(p, Kl); b.dmhi = carve_ptr<int>(p, Kl); b.dfc = carve_ptr<int>(p, Kl);
-    b.spc_lo = carve_ptr<int>(p, Kl); b.spc_hi = carve_ptr<int>(p, Kl); b.spst = carve_ptr<int>(p, Kl); b.spcl = carve_ptr<int>(p, Kl);
+    char *&pl = lm_far ? f : p;
+    b.lmst = carve_ptr<int>(pl, Kl); b.lmcl = carve_ptr<int>(pl, Kl); b.acc_lo = carve_ptr<int>(pl, Kl); b.acc_hi = carve_ptr<int>(pl, Kl);
+    b.dn = carve_ptr<int>(pl, Kl); b.dmlo = carve_ptr<int>(pl, Kl); b.dmhi = carve_ptr<int>(pl, Kl); b.dfc = carve_ptr<int>(pl, Kl);
+    b.spc_lo = carve_ptr<int>(pl, Kl); b.spc_hi = carve_ptr<int>(pl, Kl); b.spst = carve_ptr<int>(pl, Kl); b.spcl = carve_ptr<int>(pl, Kl);
   }
-  if (deep) q += w.beam_blk + 3 * Kr;
+  q += 2 * w.beam_blk_far;
   w.beam0 = w.cur;
   w.e = carve_ptr<int>(p, K); w.ancbuf = carve_ptr<int>(p, 2 * K); w.acntbuf = carve_ptr<int>(p, 2 * K); w.anc = w.ancbuf;
   w.ostart = carve_ptr<int>(p, K);
@@ -227,13 +233,14 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.surv = carve_ptr<int>(p, 3 * K + 4);
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
   w.lslot = carve_ptr<int>(p, kListCap + 4); w.bitmap = carve_ptr<uint32_t>(p, 2 * ((S + 63) / 64 + 17));
-  w.fin = carve_ptr<int>(p, K);
+  w.fin = carve_ptr<int>(BIG ? q : p, K);  // (last / exact / danger frames and finish() only: HBM scratch in the wide-beam layouts)
   w.apos = carve_ptr<int>(BIG ? q : p, K);  // (read in danger mode only: HBM scratch in the wide-beam layouts)
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
-  char *&r = BIG ? q : p;
-  w.sinfo = carve_ptr<uint32_t>(r, S);
-  w.pos = carve_ptr<uint32_t>(r, K + 2);  // (finish(): label offsets of the compact results)
+  // info words: one per slot -- except in the wide-beam layouts, which never store them (LAZY): there the array holds the
+  // K survivors' words between the select and the emission
+  w.sinfo = carve_ptr<uint32_t>(p, BIG ? K : S);
+  w.pos = carve_ptr<uint32_t>(BIG ? q : p, K + 2);  // (finish(): label offsets of the compact results)
   char *&rr = (BIG || FARREP) ? q : p;
   w.ek = carve_ptr<uint64_t>(rr, S); w.lr = carve_ptr<uint16_t>(rr, 2 * S + 2);
   w.stage_skey = deep ? 0 : 1;
@@ -306,6 +313,14 @@ struct OutRefs {
 };
 enum : int { ST_COMPACT_OVERFLOW = 3 };
 
+// What it takes to name a slot of a frame: the beam the frame started from, its #entries, #non-blank candidates (and the
+// multiplier that divides by it), the blank's rank; the layout itself is in w.ostart / w.cstart / w.anc.
+struct SlotCtx {
+  const Beam *pb;
+  int n, Vnb, brank;
+  uint64_t vmagic;  // 2^32 / Vnb rounded up: (q * vmagic) >> 32 == q / Vnb for q < 2^16
+};
+
 // An execution policy seen through "every barrier is a full fence": for the stretches of the exact replay that work on
 // arrays in HBM scratch while the kernel's ordinary barriers only wait for LDS traffic.
 template <class X>
@@ -368,16 +383,16 @@ struct Decoder {
   CTC_HD static P *shifted(P *q, size_t bytes) { return reinterpret_cast<P *>(reinterpret_cast<char *>(q) + bytes); }
   CTC_HD Beam beam_at(int par) const {
     const Beam &o = w.beam0;
-    const size_t off = par ? w.beam_blk : 0;
+    const size_t off = par ? w.beam_blk : 0, offv = par ? w.blk_via : 0, offl = par ? w.blk_lm : 0;
     Beam r;
     r.node = shifted(o.node, off); r.par = shifted(o.par, off); r.ch = shifted(o.ch, off); r.dep = shifted(o.dep, off);
-    r.lcp = shifted(o.lcp, off); r.via = shifted(o.via, off); r.viaanc = shifted(o.viaanc, off); r.viach = shifted(o.viach, off);
+    r.lcp = shifted(o.lcp, off); r.via = shifted(o.via, offv); r.viaanc = shifted(o.viaanc, offv); r.viach = shifted(o.viach, offv);
     r.up = shifted(o.up, off); r.bprev = shifted(o.bprev, off); r.nbprev = shifted(o.nbprev, off);
     r.score = shifted(o.score, off); r.lpc = shifted(o.lpc, off);
     if (LM) {
-      r.lmst = shifted(o.lmst, off); r.lmcl = shifted(o.lmcl, off); r.acc_lo = shifted(o.acc_lo, off); r.acc_hi = shifted(o.acc_hi, off);
-      r.dn = shifted(o.dn, off); r.dmlo = shifted(o.dmlo, off); r.dmhi = shifted(o.dmhi, off); r.dfc = shifted(o.dfc, off);
-      r.spc_lo = shifted(o.spc_lo, off); r.spc_hi = shifted(o.spc_hi, off); r.spst = shifted(o.spst, off); r.spcl = shifted(o.spcl, off);
+      r.lmst = shifted(o.lmst, offl); r.lmcl = shifted(o.lmcl, offl); r.acc_lo = shifted(o.acc_lo, offl); r.acc_hi = shifted(o.acc_hi, offl);
+      r.dn = shifted(o.dn, offl); r.dmlo = shifted(o.dmlo, offl); r.dmhi = shifted(o.dmhi, offl); r.dfc = shifted(o.dfc, offl);
+      r.spc_lo = shifted(o.spc_lo, offl); r.spc_hi = shifted(o.spc_hi, offl); r.spst = shifted(o.spst, offl); r.spcl = shifted(o.spcl, offl);
     }
     return r;
   }
@@ -492,10 +507,12 @@ struct Decoder {
   // The order std::nth_element leaves N candidates (w.skey / w.sinfo over S slots) in: fin[p] / apos[] of the K survivors.
   // rk[p] = DFS rank (= index in the next beam) of the survivor at array position p is left in w.surv + K as well.
   // Returns true when the replay used the block of the slot keys as its staging area (w.skey[] is then garbage).
-  CTC_HD bool nth_element_order(int S, int N, int K) {
+  CTC_HD bool nth_element_order(int S, int N, int K, const SlotCtx *lz = nullptr) {
     const int tid = x.tid(), nt = x.nt();
     int *rk = w.surv + K, *ord = w.surv + 2 * K;
-    {  // the candidates in DFS (= slot) order: (48-bit key, slot) of every slot that is not a hole
+    if (LAZY) {
+      build_ek_lazy(*lz, S);
+    } else {  // the candidates in DFS (= slot) order: (48-bit key, slot) of every slot that is not a hole
       const uint32_t *sinfo = w.sinfo;
       const uint32_t *skey = w.skey;
       uint64_t *ek = w.ek;
@@ -520,11 +537,14 @@ struct Decoder {
                         // -2: the last frame replayed std::nth_element itself and recorded the order
     x.sync();
     if (N > K) {
-      if (LAZY) {  // the frame's info words were never stored: its layout (ostart / cstart), keys and candidate labels are still in place
+      if (LAZY) {  // no info words exist: the frame's layout (ostart / cstart / anc), keys and candidate labels are still in place
         const int np = x.uni(w.vars[VAR_LASTNENT]), brp = x.uni(w.vars[VAR_LASTBRANK]);
-        fill_info(w.nxt, np, S / np - 2, brp);
+        const SlotCtx lz = slot_ctx(w.nxt, np, S / np - 2, brp);
+        nth_element_order(S, N, K, &lz);
+        for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;  // (build_ek_lazy's scratch; the next frame's histogram)
+      } else {
+        nth_element_order(S, N, K);
       }
-      nth_element_order(S, N, K);
       int *ord = w.surv + 2 * K;
       for (int q = tid; q < K; q += nt) {  // rank by slot = index in the current beam
         const int mine = ord[q];
@@ -665,40 +685,63 @@ struct Decoder {
     const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
     return IDENT ? r : w.cch[r];
   }
-  // w.sinfo[] of every slot of the frame whose layout is in ostart / cstart and whose keys are in skey (a hole has key 0),
-  // for the n entries of beam pb.  Ends with a full fence (the words live in HBM scratch).
-  CTC_HD void fill_info(const Beam &pb, int n, int Vnb, int brank) {
-    const int tid = x.tid(), nt = x.nt();
-    for (int j = tid; j < n; j += nt) {
-      const int s0 = w.ostart[j];
-      w.sinfo[s0] = w.skey[s0] != 0u ? mk_info(pb.viach[j], T_REVIVED, j) : kHoleInfo;
-      w.sinfo[s0 + 1] = mk_info(pb.ch[j], T_SELF, j);
-    }
-    for (int idx = tid; idx < n * Vnb; idx += nt) {
-      const int i = idx / Vnb, rn = idx - i * Vnb;
-      const int sl = w.cstart[i] + rn;
-      w.sinfo[sl] = w.skey[sl] != 0u ? mk_info(cand_char(rn, brank), T_CHILD, i) : kHoleInfo;
-    }
-    x.sync_full();
+  CTC_HD SlotCtx slot_ctx(const Beam &pb, int n, int Vnb, int brank) const {
+    SlotCtx c;
+    c.pb = &pb; c.n = n; c.Vnb = Vnb; c.brank = brank;
+    c.vmagic = Vnb > 0 ? 0xFFFFFFFFull / (uint32_t)Vnb + 1ull : 0ull;
+    return c;
   }
   // The info word of slot sl (not a hole), from the layout alone: open(j) = [revived | self]; between open(j) and
   // open(j + 1) lie the groups of brand-new children of the entries whose subtree ends at j + 1 -- j itself, then its
   // nearest in-beam ancestor, and so on up (close(i) = 2 e_i + Vnb (e_i - 1 - a_i), beam_core.h header).
-  CTC_HD uint32_t info_of_slot(const Beam &pb, int sl, int n, int Vnb, uint64_t vmagic, int brank) const {
-    int lo = 0, hi = n - 1;
+  CTC_HD uint32_t info_of_slot(const SlotCtx &c, int sl) const {
+    int lo = 0, hi = c.n - 1;
     while (lo < hi) {  // largest j with ostart[j] <= sl
       const int mid = (lo + hi + 1) >> 1;
       if (w.ostart[mid] <= sl) lo = mid; else hi = mid - 1;
     }
     const int j = lo, off = sl - w.ostart[j];
-    if (off == 0) return mk_info(pb.viach[j], T_REVIVED, j);
-    if (off == 1) return mk_info(pb.ch[j], T_SELF, j);
+    if (off == 0) return mk_info(c.pb->viach[j], T_REVIVED, j);
+    if (off == 1) return mk_info(c.pb->ch[j], T_SELF, j);
     const uint32_t q = (uint32_t)(off - 2);
-    const int g = (int)(((uint64_t)q * vmagic) >> 32);  // q / Vnb (exact for q < 2^16)
-    const int rn = (int)q - g * Vnb;
+    const int g = (int)(((uint64_t)q * c.vmagic) >> 32);
+    const int rn = (int)q - g * c.Vnb;
     int i = j;
     for (int h = 0; h < g; ++h) i = w.anc[i];
-    return mk_info(cand_char(rn, brank), T_CHILD, i);
+    return mk_info(cand_char(rn, c.brank), T_CHILD, i);
+  }
+  // LAZY: the DFS-ordered candidate list of the exact replay, w.ek[r] = (48-bit key, slot) of the r-th slot that is not a
+  // hole (a hole has key 0), straight from the layout: one bit per slot says "candidate", a prefix over the bitmap's words
+  // gives every candidate its rank, and each (entry, label) pair writes its own element -- the info words never exist.
+  // Uses the select's bitmap and histogram as scratch (the caller zeroes the histogram again if a frame follows directly).
+  CTC_HD void build_ek_lazy(const SlotCtx &c, int S) {
+    const int tid = x.tid(), nt = x.nt();
+    const uint32_t *skey = w.skey;
+    uint32_t *bm = w.bitmap, *wpre = reinterpret_cast<uint32_t *>(w.bins);
+    x.mark_slots(S, bm, [=](int sl) -> bool { return skey[sl] != 0u; });
+    x.sync();
+    const int nw = (S + 63) / 64;  // <= 1024 (S < 65536): fits the histogram's 1024 + 64 words
+    for (int i = tid; i <= nw; i += nt) wpre[i] = i < nw ? (uint32_t)(__builtin_popcount(bm[2 * i]) + __builtin_popcount(bm[2 * i + 1])) : 0u;
+    x.sync();
+    x.scan_excl(wpre, nw + 1);
+    auto put = [&](int sl, int ch) {
+      const uint32_t lo = bm[2 * (sl >> 6)], hi = bm[2 * (sl >> 6) + 1];
+      const int bit = sl & 63;
+      const uint32_t mlo = bit >= 32 ? 0xFFFFFFFFu : ((1u << bit) - 1u), mhi = bit > 32 ? ((1u << (bit - 32)) - 1u) : 0u;
+      const int r = (int)wpre[sl >> 6] + __builtin_popcount(lo & mlo) + __builtin_popcount(hi & mhi);
+      w.ek[r] = (key48(skey[sl], mk_info(ch, 0, 0)) << 16) | (uint64_t)sl;
+    };
+    for (int j = tid; j < c.n; j += nt) {
+      const int s0 = w.ostart[j];
+      if (skey[s0] != 0u) put(s0, c.pb->viach[j]);
+      put(s0 + 1, c.pb->ch[j]);
+    }
+    for (int idx = tid; idx < c.n * c.Vnb; idx += nt) {
+      const int i = (int)(((uint64_t)(uint32_t)idx * c.vmagic) >> 32), rn = idx - i * c.Vnb;
+      const int sl = w.cstart[i] + rn;
+      if (skey[sl] != 0u) put(sl, cand_char(rn, c.brank));
+    }
+    x.sync();
   }
 
   // log_p of extending beam entry P with character c (ctc_beam_search_decoder.cpp:110-118)
@@ -841,13 +884,13 @@ struct Decoder {
   // m of the E candidates with score key tau must survive.  Sets VAR_TAUC (smallest surviving inverted-character
   // code) and returns true when that cut is unambiguous; false when it would split a group of equivalent prefixes
   // (or the group is too large to rank here): the caller then replays std::nth_element.
-  CTC_HD bool resolve_by_character(int S, uint32_t tau, int m, int E, int *pv) {
+  CTC_HD bool resolve_by_character(int S, uint32_t tau, int m, int E, int *pv, const SlotCtx *lz = nullptr) {
     const int tid = x.tid(), nt = x.nt();
     if (E > kListCap) return false;
     if (tid == 0) { pv[P_LCOUNT] = 0; w.vars[VAR_CUT] = 0; }
     x.sync();
     for (int s = tid; s < S; s += nt)
-      if (w.skey[s] == tau) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = (w.sinfo[s] >> 16) + 1u;
+      if (w.skey[s] == tau) w.list[x.atomic_add(&pv[P_LCOUNT], 1)] = ((LAZY ? info_of_slot(*lz, s) : w.sinfo[s]) >> 16) + 1u;
     x.sync();
     for (int q = tid; q < E; q += nt) {
       const uint32_t mine = w.list[q];
@@ -1214,7 +1257,8 @@ struct Decoder {
     const int N = LM ? x.uni(pv[P_NCAND]) : n * (1 + Vnb) - x.uni(npin_total);
     uint32_t tau = 0, tauc = 0;
     bool exact = false, have_bitmap = false;
-    bool info_ready = !LAZY;  // (LAZY: w.sinfo[] is rebuilt by whichever rare path needs all of it first)
+    SlotCtx lz;  // LAZY: no info words are stored; whoever needs one derives it from the layout
+    if (LAZY) lz = slot_ctx(b, n, Vnb, brank);
     bool keys_in_ord = false;  // the exact replay overwrote w.skey[]: the survivors' keys are in ord[] (by beam position)
     if (CTC_USUAL(N > K)) {  // ctc_beam_search_decoder.cpp:150
       have_bitmap = select_kth(S, K, pv, wd);
@@ -1224,8 +1268,7 @@ struct Decoder {
       const int E = tv[2], m = K - tv[1];
       if (CTC_RARE(E > m)) {
         have_bitmap = false;
-        if (LAZY) { fill_info(b, n, Vnb, brank); info_ready = true; }
-        if (resolve_by_character(S, tau, m, E, pv)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);
+        if (resolve_by_character(S, tau, m, E, pv, &lz)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);
         else exact = true;  // the boundary splits a group of equivalent prefixes
       }
 #ifdef CTC_EXP_ALWAYS_EXACT  // (measurement builds: the cost of one exact replay = the change of the frame time)
@@ -1240,8 +1283,7 @@ struct Decoder {
     // threshold; when the outcome depends on it, an exact replay of std::nth_element followed by a ranking by slot.
     const int n_new = N < K ? N : K;
     if (CTC_RARE(exact)) {
-      if (LAZY && !info_ready) { fill_info(b, n, Vnb, brank); info_ready = true; }
-      keys_in_ord = nth_element_order(S, N, K);
+      keys_in_ord = nth_element_order(S, N, K, &lz);
       for (int q = tid; q < K; q += nt) {  // rank by slot
         const int mine = ord[q];
         int r = 0;
@@ -1263,7 +1305,7 @@ struct Decoder {
       const bool all = N <= K;
       x.compact_slots(S, surv, [=](int s) -> bool {
         const uint32_t k = skey[s];
-        return all ? (k != 0u) : (k > tau || (k == tau && (tauc == 0u || (sinfo[s] >> 16) >= tauc)));
+        return all ? (k != 0u) : (k > tau || (k == tau && (tauc == 0u || ((LAZY ? info_of_slot(lz, s) : sinfo[s]) >> 16) >= tauc)));
       });
       x.mark(3);
     }
@@ -1277,11 +1319,11 @@ struct Decoder {
     // append), its probabilities -- go to three different sets of waves when the workgroup has them.
     uint32_t kloc = 0, kmin = 0xFFFFFFFFu;
     bool r_prob_any = true;
-    const bool lazy_info = LAZY && !info_ready;
-    uint32_t *sinf = reinterpret_cast<uint32_t *>(rk);  // LAZY: the survivors' info words (rk is idle unless the frame was exact)
+    constexpr bool lazy_info = LAZY;
+    uint32_t *sinf = reinterpret_cast<uint32_t *>(w.list);  // LAZY: the survivors' info words
     if (lazy_info) {
-      const uint64_t vmagic = Vnb > 0 ? 0xFFFFFFFFull / (uint32_t)Vnb + 1ull : 0ull;
-      for (int k = tid; k < n_new; k += nt) sinf[k] = info_of_slot(b, surv[k], n, Vnb, vmagic, brank);
+      sinf = w.sinfo;  // (K words: carve)
+      for (int k = tid; k < n_new; k += nt) sinf[k] = info_of_slot(lz, surv[k]);
       x.sync();
     }
     {

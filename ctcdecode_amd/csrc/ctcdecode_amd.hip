@@ -1058,7 +1058,6 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   far_bytes = (far_bytes + 255) / 256 * 256;
   if (lds + 2048 > (size_t)d->max_lds)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) needs " + std::to_string(lds) + " B of LDS, more than one workgroup has");
-  if (big && scorer) return fail(CTCD_EUNSUPPORTED, "the LM tier does not fit this beam width / vocabulary in LDS yet");
   if (scorer && d->profile && !d->tl_armed) return fail(CTCD_EUNSUPPORTED, "the phase-timer kernel builds do not include the LM tier (the barrier timeline does)");
   if ((rc = d->far.ensure((size_t)B * far_bytes))) return rc;
 
@@ -1345,6 +1344,9 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
       fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
     if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true, true>;
+    // wide beams: the scorer's per-entry state moves to the HBM scratch with the other rare-path arrays (a capability, not a fast path)
+    if (big) fn = far_level == 2 ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false, 0, true>)
+                                 : (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 1, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 1, 0, false, 0, true>);
     if (d->profile && d->tl_armed) {  // (shape conditions checked above)
       if (!fixed) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels");
       fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true>;

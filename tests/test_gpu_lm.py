@@ -21,13 +21,15 @@ def torch_mod():
     return torch
 
 
-def _decode(torch, probs, lm, seq_lens=None, beam=100, cutoff_top_n=40, cutoff_prob=1.0, blank_id=0, log_input=True, threads=None):
+def _decode(torch, probs, lm, seq_lens=None, beam=100, cutoff_top_n=40, cutoff_prob=1.0, blank_id=0, log_input=True, threads=None, cu_sharing=None):
     import ctcdecode_amd
 
     dec = ctcdecode_amd.CTCBeamDecoder(lm["labels"], model_path=lm["lm_path"], alpha=lm["alpha"], beta=lm["beta"], cutoff_top_n=cutoff_top_n,
                                        cutoff_prob=cutoff_prob, beam_width=beam, blank_id=blank_id, log_probs_input=log_input, device="cuda:0")
     if threads:
         dec.set_threads(threads)
+    if cu_sharing is not None:
+        dec.set_cu_sharing(cu_sharing)
     out, sc, ts, ln = dec.decode(torch.from_numpy(np.ascontiguousarray(probs)), torch.from_numpy(seq_lens) if seq_lens is not None else None)
     meta = (int(dec.character_based()), dec.max_order(), dec.dict_size())
     return dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy()), meta
@@ -49,6 +51,48 @@ def test_lm_reference_fixtures(torch_mod, name, threads):
     got, meta = _decode(torch_mod, lm=lm, threads=threads, **args)
     assert meta == lm["meta"]
     ou.assert_same(_with_nres(got, want), want, name)
+
+
+@pytest.mark.parametrize("name", gu.lm_names())
+def test_lm_reference_fixtures_two_workgroups_per_cu_build(torch_mod, name):
+    """The LM instantiation of the two-workgroups-per-CU build (ctcd_set_cu_sharing) against the reference fixtures."""
+    args, lm, want = gu.load_lm(name)
+    got, meta = _decode(torch_mod, lm=lm, cu_sharing=1, **args)
+    assert meta == lm["meta"]
+    ou.assert_same(_with_nres(got, want), want, name)
+
+
+def test_lm_generated_mid_size_model(torch_mod, tmp_path):
+    """A generated 3000-word 3-gram model (tools/make_big_lm.py): deep dictionary paths, real probe sequences in the n-gram table."""
+    from test_lm import make_mid_lm
+
+    path = make_mid_lm(tmp_path)
+    lm = dict(labels=LABELS29, lm_path=path, alpha=0.6, beta=0.8)
+    sc = ou.Scorer(0.6, 0.8, path, LABELS29, "restated")
+    for seed, K, th in ((61, 32, 0), (62, 100, 0), (63, 100, 256)):
+        lp = ou.synth_logprobs(3, 200, 29, seed)
+        lp[:, :, LABELS29.index(" ")] += np.float32(1.5)
+        for ch in "etao":
+            lp[:, :, LABELS29.index(ch)] += np.float32(0.7)
+        want = ou.decode(lp, scorer=sc, beam=K)
+        got, meta = _decode(torch_mod, lp, lm, beam=K, threads=th)
+        assert meta == (0, 3, 3000)
+        ou.assert_same(_with_nres(got, want), want, "mid-size model seed %d" % seed)
+
+
+@pytest.mark.parametrize("arpa,labels,K,T", [("test.arpa", LABELS29, 400, 120), ("abcd_words.arpa", ["_", "a", "b", "c", "d", "'", " "], 600, 100),
+                                            ("chars.arpa", ["_", "a", "b", "c", "d", "'", "é", " "], 500, 80), ("test.arpa", LABELS29, 1000, 40)])
+def test_lm_wide_beam(torch_mod, arpa, labels, K, T):
+    """Scorer + a beam too wide for the LDS-resident layout (round 2 refused these): the scorer's per-entry state moves to the
+    HBM scratch with the other rare-path arrays (workspace levels 1 and 2).  path_trie.cpp:59-96 / scorer.cpp:196-230 know no
+    beam-width limit."""
+    lp = ou.synth_logprobs(2, T, len(labels), 4242 + K, quant=0.5 if K == 600 else None)
+    lp[:, :, labels.index(" ")] += np.float32(1.0)
+    lm = dict(labels=labels, lm_path=os.path.join(DATA, arpa), alpha=0.7, beta=0.9)
+    sc = ou.Scorer(0.7, 0.9, lm["lm_path"], labels, "restated")
+    want = ou.decode(lp, scorer=sc, beam=K)
+    got, _ = _decode(torch_mod, lp, lm, beam=K)
+    ou.assert_same(_with_nres(got, want), want, "wide-beam LM %s K=%d" % (arpa, K))
 
 
 def test_lm_degenerate_inputs(torch_mod):

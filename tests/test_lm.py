@@ -204,6 +204,43 @@ def test_product_core_with_lm_degenerate_inputs():
             ou.assert_same(ou.decode(lp, scorer=ref, which="reference", **kw), want, what + " (oracle vs live reference)")
 
 
+def make_mid_lm(tmp_path_factory_or_dir, words=3000, grams=20000):
+    """A generated 3-gram word model of a few thousand words (tools/make_big_lm.py): far more dictionary nodes and n-gram
+    table slots than the committed models, so that table collisions, long probe sequences and deep dictionary paths occur."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_big_lm", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_big_lm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = os.path.join(str(tmp_path_factory_or_dir), "mid_words_%d.arpa" % words)
+    if not os.path.exists(path):
+        mod.make(path, words, grams, grams, seed=3)
+    return path
+
+
+def test_generated_mid_size_model(tmp_path):
+    path = make_mid_lm(tmp_path)
+    checkers = [ou.Scorer(0.6, 0.8, path, LABELS29, w) for w in (("restated", "reference") if ou.have_reference() else ("restated",))]
+    assert checkers[0].dict_size() == 3000 and checkers[0].max_order() == 3
+    rng = np.random.default_rng(5)
+    vocab = [ln.split("\t")[1] for ln in open(path, encoding="utf-8").read().split("\\2-grams:")[0].splitlines() if ln.count("\t") == 2][3:]
+    for _ in range(200):
+        words = [vocab[int(i)] if rng.random() > 0.1 else "zzzq" for i in rng.integers(0, min(len(vocab), 400), size=int(rng.integers(1, 4)))]
+        got, meta = ou.core_host_lm_cond(path, LABELS29, words)
+        for sc in checkers:
+            assert got == sc.cond_logprob(words), (words, sc.which)
+    for seed, K in ((61, 32), (62, 100)):
+        lp = ou.synth_logprobs(2, 150, 29, seed)
+        lp[:, :, LABELS29.index(" ")] += np.float32(1.5)
+        for ch in "etao":
+            lp[:, :, LABELS29.index(ch)] += np.float32(0.7)
+        want = ou.decode(lp, scorer=checkers[0], beam=K)
+        ou.assert_same(ou.decode_core_host_lm(lp, 0.6, 0.8, path, LABELS29, beam=K), want, "mid-size model, product core")
+        if len(checkers) > 1:
+            ou.assert_same(ou.decode(lp, scorer=checkers[1], which="reference", beam=K), want, "mid-size model, live reference")
+        assert int(want["lens"][:, 0].min()) > 5
+
+
 def test_unigram_model_keeps_no_context():
     """An order-1 ARPA model that lists back-off weights: kenlm's state for it has length 0, so no back-off is
     ever added -- the product's tables, the restated oracle and the reference's scorer.cpp over the kenlm stand-in agree,
