@@ -135,6 +135,20 @@ def time_e2e(torch, dec, lp_cpu, reps=5, warm=2):
     return ts[len(ts) // 2]
 
 
+def time_compact(torch, ctcdecode_amd, dec, lp, steps=10, warm=3):
+    """The same launches handing their results over in COMPACT form (what decode() ships over PCIe and what a rank ships to
+    the gathering rank): no padded [B, K, T] tensors exist on the device, so there is nothing to zero-fill."""
+    B = lp.shape[0]
+    tickets = [dec.decode_compact_async(lp, None) for _ in range(warm)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tickets = [dec.decode_compact_async(lp, None) for _ in range(steps)]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    dec.finish_compact(tickets[-1])
+    return dt
+
+
 def time_pipelined(torch, ctcdecode_amd, dev, lp, labels, V, K, inflight=2, steps=24, warm=6):
     """The same batches with `inflight` launches in flight (one decoder + stream each): the kernel time of a launch is set by
     its slowest utterance (ties at the beam boundary cost an exact std::nth_element replay), so a lone launch leaves CUs
@@ -160,9 +174,10 @@ def time_pipelined(torch, ctcdecode_amd, dev, lp, labels, V, K, inflight=2, step
     return dt
 
 
-def other_configs(torch, ctcdecode_amd, dev):
+def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
     """Kernel time of the other BASELINE.json configurations' per-GPU shapes (not bench lines: one or two launches each)."""
     out = {}
+    traffic_consts = traffic_consts or {}
 
     def run(name, B, T, V, K, top_n=40, cutoff_prob=1.0, reps=2, **kw):
         g = torch.Generator(device="cpu").manual_seed(7)
@@ -177,9 +192,11 @@ def other_configs(torch, ctcdecode_amd, dev):
         for _ in range(reps + 1):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            dec.decode_device(lp, None, check=True)
+            res = dec.decode_device(lp, None, check=True)
             torch.cuda.synchronize()
             ws.append(time.perf_counter() - t0)
+            res_len = res[3].sum().item()
+            del res
             ks.append(dec.last_kernel_ms())
             if top_n < V or cutoff_prob < 1.0:
                 ps.append(dec.last_prune_ms())
@@ -189,8 +206,18 @@ def other_configs(torch, ctcdecode_amd, dev):
         if ps:
             r["prune_kernel_ms"] = round(min(ps[1:]), 3)
             r["prune_GBps"] = round(B * T * V * 4 / (min(ps[1:]) * 1e-3) / 1e9, 1)
+            pt = traffic_consts.get("prune_hbm_bytes_per_launch")
+            r["prune_roofline"] = {"bound": "hbm", "achieved": r["prune_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": round(r["prune_GBps"] / 8000.0, 4),
+                                   "algorithmic_bytes_per_launch": B * T * V * 4, "traffic": pt, "traffic_ratio": round(pt / (B * T * V * 4), 2) if pt else None,
+                                   "traffic_source": "profiles/traffic_latest.json (rocprofv3 --pmc, FETCH_SIZE x2 for 128-bit loads: calibrated)"}
             r["prune_flagged_rows"] = int(ctcdecode_amd._native.lib.ctcd_last_prune_flagged_rows(dec._handle))  # settled by the device's std::sort replay ...
             r["prune_host_rows"] = int(ctcdecode_amd._native.lib.ctcd_last_prune_host_rows(dec._handle))  # ... except these
+        if K == 500 and not ps:  # the wide-beam kernel's own roofline block
+            alg = B * (T * V * 4 + 8 * K + 4) + 8 * int(res_len)
+            wt = traffic_consts.get("wide_beam_hbm_bytes_per_launch")
+            gbps = alg / (min(ks[1:]) * 1e-3) / 1e9
+            r["roofline"] = {"bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5), "algorithmic_bytes_per_launch": alg,
+                             "traffic": wt, "traffic_ratio": round(wt / alg, 2) if wt else None, "traffic_source": "profiles/traffic_latest.json (rocprofv3 --pmc passes of tools/bench_configs.py --only 2)"}
         out[name] = r
         del dec, lp
         torch.cuda.empty_cache()
@@ -379,7 +406,7 @@ def main():
     # (8 bytes per emitted label per beam) + scores and lengths (8 bytes per beam) + 4 (seq_len)
     alg_bytes = B * (T * V * 4 + 8 * K + 4) + 8 * int(out_len.sum().item())
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    traffic, traffic_src = None, None
+    traffic, traffic_src, tj = None, None, {}
     if os.path.exists(a.traffic_json):
         try:
             tj = json.load(open(a.traffic_json))
@@ -428,13 +455,21 @@ def main():
             line["e2e"] = {"what": "drop-in decode(): CPU float32 tensor in, four CPU tensors out (SURVEY 8(d) primary definition)",
                            "ms_per_batch": round(e2e * 1e3, 3), "value": round(B / e2e, 1), "unit": "utterances/s"}
             try:
+                cp = time_compact(torch, ctcdecode_amd, dec, lp)
+                ct = tj.get("compact_hbm_bytes_per_launch")
+                line["compact_results"] = {"what": "the same launches with the results left in HBM in compact form (what decode() and the multi-GPU gather ship): no padded tensors on the device, nothing to zero-fill",
+                                           "ms_per_batch": round(cp * 1e3, 3), "value": round(B / cp, 1), "unit": "utterances/s", "memset_bytes_outside_kernel": 0,
+                                           "traffic": ct, "traffic_ratio": round(ct / alg_bytes, 2) if ct else None}
+            except Exception as e:
+                line["compact_results"] = {"error": str(e)[:200]}
+            try:
                 pl = time_pipelined(torch, ctcdecode_amd, dev, lp, [str(i) for i in range(V)], V, K, inflight=3)
                 line["pipelined"] = {"what": "the same batches with 3 launches in flight on 3 streams, two-workgroups-per-CU build of the kernel (a serving loop; not the headline: see DESIGN.md 6)",
                                      "launches_in_flight": 3, "ms_per_batch": round(pl * 1e3, 3), "value": round(B / pl, 1), "unit": "utterances/s"}
             except Exception as e:
                 line["pipelined"] = {"error": str(e)[:200]}
             try:
-                line["other_configs"] = other_configs(torch, ctcdecode_amd, dev)
+                line["other_configs"] = other_configs(torch, ctcdecode_amd, dev, tj)
             except Exception as e:
                 line["other_configs"] = {"error": str(e)[:300]}
         if not a.no_cpu_baseline:  # (rank 0's host cores, on rank 0's own shard; outside the timed region)

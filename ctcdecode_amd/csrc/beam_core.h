@@ -437,6 +437,7 @@ struct Decoder {
   // may entry P be extended by c at all?  path_trie.cpp:59-70: only along the dictionary (word models)
   CTC_HD bool lm_allows(const Beam &b, int P, int c) const {
     if (lm->char_based) return true;
+    if (CTC_RARE(lm->dict_wide)) return ctclm::dict_find_wide(*lm, (uint32_t)b.dmlo[P], (uint32_t)b.dmhi[P], c) >= 0;
     return c < 32 ? (((uint32_t)b.dmlo[P] >> c) & 1u) != 0u : (((uint32_t)b.dmhi[P] >> (c - 32)) & 1u) != 0u;
   }
   // The LM fields of a prefix: `from` = the entry it copies them from (self) or hangs off (child via label c >= 0).
@@ -464,7 +465,7 @@ struct Decoder {
       } else {
         ctclm::DictNode pin;
         pin.mask_lo = (uint32_t)src.dmlo[from]; pin.mask_hi = (uint32_t)src.dmhi[from]; pin.first_child = (uint32_t)src.dfc[from]; pin.word = 0;
-        node = ctclm::dict_child(pin, c);
+        node = CTC_RARE(lm->dict_wide) ? pin.first_child + (uint32_t)ctclm::dict_find_wide(*lm, pin.mask_lo, pin.mask_hi, c) : ctclm::dict_child(pin, c);
       }
       info = lm->dict[node];
       dst.dn[k] = (int)node; dst.dmlo[k] = (int)info.mask_lo; dst.dmhi[k] = (int)info.mask_hi; dst.dfc[k] = (int)info.first_child;

@@ -1396,7 +1396,7 @@ int ctcd_scorer_create(ctcd_scorer **out, double alpha, double beta, const char 
   auto place = [&off](size_t bytes) { const size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
   const size_t o_up = place(h.uni_prob.size() * 4), o_us = place(h.uni_state.size() * 4), o_bo = place(h.st_bo.size() * 4),
                o_fl = place(h.st_fail.size() * 4), o_ng = place(h.ng.size() * sizeof(ctclm::NgSlot)),
-               o_dc = place(h.dict.size() * sizeof(ctclm::DictNode)), o_lw = place(h.label_word.size() * 4);
+               o_dc = place(h.dict.size() * sizeof(ctclm::DictNode)), o_lw = place(h.label_word.size() * 4), o_dl = place(h.dict_lab.size() * 4);
   hipError_t e = hipMalloc((void **)&s->blob, off ? off : 256);
   if (e != hipSuccess) { delete s; return fail(CTCD_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
   auto up = [&](size_t o, const void *src, size_t bytes) { return bytes ? hipMemcpy(s->blob + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
@@ -1404,7 +1404,8 @@ int ctcd_scorer_create(ctcd_scorer **out, double alpha, double beta, const char 
       (e = up(o_bo, h.st_bo.data(), h.st_bo.size() * 4)) != hipSuccess || (e = up(o_fl, h.st_fail.data(), h.st_fail.size() * 4)) != hipSuccess ||
       (e = up(o_ng, h.ng.data(), h.ng.size() * sizeof(ctclm::NgSlot))) != hipSuccess ||
       (e = up(o_dc, h.dict.data(), h.dict.size() * sizeof(ctclm::DictNode))) != hipSuccess ||
-      (e = up(o_lw, h.label_word.data(), h.label_word.size() * 4)) != hipSuccess) {
+      (e = up(o_lw, h.label_word.data(), h.label_word.size() * 4)) != hipSuccess ||
+      (e = up(o_dl, h.dict_lab.data(), h.dict_lab.size() * 4)) != hipSuccess) {
     (void)hipFree(s->blob);
     delete s;
     return fail(CTCD_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
@@ -1414,6 +1415,7 @@ int ctcd_scorer_create(ctcd_scorer **out, double alpha, double beta, const char 
   s->dview.st_bo = (const float *)(s->blob + o_bo); s->dview.st_fail = (const uint32_t *)(s->blob + o_fl);
   s->dview.ng = (const ctclm::NgSlot *)(s->blob + o_ng); s->dview.dict = (const ctclm::DictNode *)(s->blob + o_dc);
   s->dview.label_word = (const uint32_t *)(s->blob + o_lw);
+  s->dview.dict_lab = (const uint32_t *)(s->blob + o_dl);
   *out = s;
   return CTCD_OK;
 }

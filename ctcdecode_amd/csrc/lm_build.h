@@ -32,6 +32,8 @@ struct HostScorer {
   std::vector<uint32_t> uni_state, st_fail, label_word;
   std::vector<NgSlot> ng;
   std::vector<DictNode> dict;
+  std::vector<uint32_t> dict_lab;  // wide dictionaries (more than 64 labels): arc labels
+  bool dict_wide = false;
   uint32_t s0 = 0, w_bos = 0, w_eos = 0;
   int clean0 = 0;
   std::string error;
@@ -64,6 +66,7 @@ struct HostScorer {
     LmView v;
     v.uni_prob = uni_prob.data(); v.uni_state = uni_state.data(); v.st_bo = st_bo.data(); v.st_fail = st_fail.data();
     v.ng = ng.data(); v.dict = dict.data(); v.label_word = label_word.data();
+    v.dict_lab = dict_lab.data(); v.dict_wide = dict_wide ? 1 : 0;
     v.ng_mask = (uint32_t)ng.size() - 1; v.order = order; v.char_based = char_based ? 1 : 0; v.space_id = space_id;
     v.s0 = s0; v.clean0 = clean0; v.w_bos = w_bos; v.w_eos = w_eos; v.alpha = alpha; v.beta = beta;
     return v;
@@ -218,7 +221,8 @@ struct HostScorer {
     dict_size = 0;
     if (!char_based) {
       if (space_id < 0) return fail("a word language model needs a \" \" label");
-      if (labels.size() > 64) return fail("word language models are supported for at most 64 labels in this build");
+      dict_wide = labels.size() > 64;  // more labels than a node's 64-bit arc mask has bits: sorted arc lists instead
+      dict_lab.clear();
       struct TNode { std::map<int, int> kids; uint32_t word = kNoWord; };
       std::vector<TNode> trie(1);
       for (const std::string &w : vocab) {  // add_word_to_dictionary, decoder_utils.cpp:164-193
@@ -250,13 +254,14 @@ struct HostScorer {
       dict.assign(1, DictNode{0, 0, 0, kNoWord});
       for (size_t qi = 0; qi < order_bfs.size(); ++qi) {
         const int t = order_bfs[qi];
-        DictNode dn{0, 0, (uint32_t)dict.size(), trie[t].word};
+        DictNode dn{dict_wide ? (uint32_t)dict_lab.size() : 0u, 0, (uint32_t)dict.size(), trie[t].word};
         std::vector<int> labs;
         for (const auto &kv : trie[t].kids) labs.push_back(kv.first);
         if (trie[t].word != kNoWord && !trie[t].kids.count(space_id)) labs.push_back(space_id);
         std::sort(labs.begin(), labs.end());
         for (int lab : labs) {
-          if (lab < 32) dn.mask_lo |= 1u << lab; else dn.mask_hi |= 1u << (lab - 32);
+          if (dict_wide) { dict_lab.push_back((uint32_t)lab); ++dn.mask_hi; }
+          else if (lab < 32) dn.mask_lo |= 1u << lab; else dn.mask_hi |= 1u << (lab - 32);
           dict.push_back(DictNode{0, 0, 0, kNoWord});
           auto it = trie[t].kids.find(lab);
           if (it != trie[t].kids.end()) {

@@ -22,7 +22,10 @@
 //     contiguously in label order: child(node, c) = first_child + popcount(mask & below(c)).  One 16-byte record per
 //     node {label mask (64 bit), first child, word id of the word that ends here}.  Behaviour-equivalent to the
 //     determinised + minimised FST of scorer.cpp:196-230 for Find / Final; a completed word restarts
-//     the speller at the root (path_trie.cpp:83-92).
+//     the speller at the root (path_trie.cpp:83-92).  Models over MORE than 64 labels ("wide" dictionaries) keep the
+//     same node numbering but, instead of a bit mask, the sorted labels of a node's arcs in a side array:
+//     {first arc's index in dict_lab, #arcs, first child, word}; an arc is found by binary search (a capability for
+//     large label sets, not a fast path: log2(#arcs) dependent reads per gate test).
 #pragma once
 #include <stdint.h>
 
@@ -42,7 +45,7 @@ constexpr int kMaxOrder = 6;               // KENLM_MAX_ORDER of the reference's
 constexpr double kOovScore = -1000.0;      // scorer.h:16
 
 struct NgSlot { uint32_t state, word, prob_bits, next; };         // 16 bytes
-struct DictNode { uint32_t mask_lo, mask_hi, first_child, word; };  // 16 bytes
+struct DictNode { uint32_t mask_lo, mask_hi, first_child, word; };  // 16 bytes (wide dictionaries: mask_lo = first arc in dict_lab, mask_hi = #arcs)
 
 struct LmView {
   const float *uni_prob;       // [W] log10 p(w), w = word id (0 = <unk>)
@@ -52,6 +55,8 @@ struct LmView {
   const NgSlot *ng;            // [ng_mask + 1]
   const DictNode *dict;        // [D] (word models)
   const uint32_t *label_word;  // [V] character models: word id of each label's string (0 = unknown)
+  const uint32_t *dict_lab;    // wide dictionaries (more than 64 labels): the nodes' arc labels, ascending per node
+  int dict_wide;               // 1: DictNode = {first arc in dict_lab, #arcs, first child, word}
   uint32_t ng_mask;
   int order;                   // N
   int char_based;              // scorer.cpp:65-71
@@ -133,6 +138,17 @@ CTC_HD double lm_cond(const LmView &L, uint32_t *state, int *clean, uint32_t wor
   return (double)p10 / (double)0.4342944819f;  // decoder_utils.h:14 NUM_FLT_LOGE is a float constant
 }
 
+// position of `label` among the arcs of a wide-dictionary node (lo = first arc, cnt = #arcs), -1 if it has no such arc
+CTC_HD int dict_find_wide(const LmView &L, uint32_t lo, uint32_t cnt, int label) {
+  uint32_t a = 0, b = cnt;
+  while (a < b) {
+    const uint32_t m = (a + b) >> 1;
+    const uint32_t v = L.dict_lab[lo + m];
+    if (v == (uint32_t)label) return (int)m;
+    if (v < (uint32_t)label) a = m + 1; else b = m;
+  }
+  return -1;
+}
 CTC_HD bool dict_has(const DictNode &n, int label) {
   return label < 32 ? (n.mask_lo >> label) & 1u : (n.mask_hi >> (label - 32)) & 1u;
 }

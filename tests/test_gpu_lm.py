@@ -95,6 +95,21 @@ def test_lm_wide_beam(torch_mod, arpa, labels, K, T):
     ou.assert_same(_with_nres(got, want), want, "wide-beam LM %s K=%d" % (arpa, K))
 
 
+def test_lm_word_model_over_more_than_64_labels(torch_mod, tmp_path):
+    from test_lm import make_wide_label_lm, wide_label_cases, wide_label_inputs
+
+    path, labels = make_wide_label_lm(tmp_path)
+    lm = dict(labels=labels, lm_path=path, alpha=0.7, beta=0.5)
+    sc = ou.Scorer(0.7, 0.5, path, labels, "restated")
+    for it, K, T, top_n in wide_label_cases():
+        lp = wide_label_inputs(it, T, len(labels))
+        kw = dict(beam=K, cutoff_top_n=top_n, blank_id=0)
+        want = ou.decode(lp, scorer=sc, **kw)
+        got, meta = _decode(torch_mod, lp, lm, **kw)
+        assert meta == (0, 2, 400)
+        ou.assert_same(_with_nres(got, want), want, "99 labels, case %d" % it)
+
+
 def test_lm_degenerate_inputs(torch_mod):
     """Whole frames of -inf / overflowing sums with the scorer: contributions in the order of the frame's
     std::sort (ctc_beam_search_decoder.cpp:75-76)."""

@@ -241,6 +241,62 @@ def test_generated_mid_size_model(tmp_path):
         assert int(want["lens"][:, 0].min()) > 5
 
 
+def make_wide_label_lm(directory):
+    """A word model over 99 labels (Latin, Greek, Cyrillic and Hebrew letters + blank + space): more labels than the 64-bit
+    arc mask of a dictionary node holds -- the product then keeps sorted arc lists (lm_tables.h dict_find_wide).
+    -> (path, labels)"""
+    syms = [chr(c) for c in list(range(ord("a"), ord("z") + 1)) + list(range(0x3B1, 0x3B1 + 25)) + list(range(0x430, 0x430 + 32)) + list(range(0x5D0, 0x5D0 + 14))]
+    labels = ["_", " "] + syms
+    path = os.path.join(str(directory), "wide_words.arpa")
+    if not os.path.exists(path):
+        rng = np.random.default_rng(7)
+        words = set()
+        while len(words) < 400:
+            words.add("".join(syms[int(i)] for i in rng.integers(0, len(syms) if rng.random() < 0.5 else 12, size=int(rng.integers(1, 5)))))
+        words = sorted(words)
+        with open(path, "w", encoding="utf-8") as f:
+            bi = sorted({(words[int(x)], words[int(y)]) for x, y in rng.integers(0, len(words), size=(600, 2))})
+            f.write("\\data\\\nngram 1=%d\nngram 2=%d\n\n\\1-grams:\n" % (len(words) + 3, len(bi)))
+            f.write("-2.5\t<unk>\t-0.2\n-99\t<s>\t-0.5\n-1.2\t</s>\n")
+            for w in words:
+                f.write("%.3f\t%s\t%.3f\n" % (-rng.random() * 3 - 0.1, w, -rng.random()))
+            f.write("\n\\2-grams:\n")
+            for x, y in bi:
+                f.write("%.3f\t%s %s\n" % (-rng.random() * 2 - 0.1, x, y))
+            f.write("\n\\end\\\n")
+    return path, labels
+
+
+def wide_label_cases():
+    rng = np.random.default_rng(8)
+    for it in range(12):
+        yield it, int(rng.choice([5, 20, 60])), int(rng.integers(5, 50)), int(rng.choice([40, 40, 99]))
+
+
+def wide_label_inputs(it, T, V):
+    lp = ou.synth_logprobs(2, T, V, 100 + it)
+    lp[:, :, 1] += np.float32(2.0)
+    lp[:, :, 2:14] += np.float32(2.0)
+    return lp
+
+
+def test_word_model_over_more_than_64_labels(tmp_path):
+    """path_trie.cpp:59-96 / scorer.cpp:196-230 put no limit on the number of labels of a word model; round 2 refused > 64."""
+    path, labels = make_wide_label_lm(tmp_path)
+    sc = ou.Scorer(0.7, 0.5, path, labels, "restated")
+    for it, K, T, top_n in wide_label_cases():
+        lp = wide_label_inputs(it, T, len(labels))
+        kw = dict(beam=K, cutoff_top_n=top_n, blank_id=0)
+        want = ou.decode(lp, scorer=sc, **kw)
+        got = ou.decode_core_host_lm(lp, 0.7, 0.5, path, labels, **kw)
+        assert got["meta"] == (0, 2, 400)
+        ou.assert_same(got, want, "99 labels, case %d" % it)
+        if it % 4 == 0 and ou.have_reference():
+            ref = ou.Scorer(0.7, 0.5, path, labels, "reference")
+            ou.assert_same(ou.decode(lp, scorer=ref, which="reference", **kw), want, "99 labels, oracle vs live reference")
+    assert int(want["lens"][:, 0].max()) > 5
+
+
 def test_unigram_model_keeps_no_context():
     """An order-1 ARPA model that lists back-off weights: kenlm's state for it has length 0, so no back-off is
     ever added -- the product's tables, the restated oracle and the reference's scorer.cpp over the kenlm stand-in agree,
