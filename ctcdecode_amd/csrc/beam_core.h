@@ -118,16 +118,14 @@ struct Dims {
 // the step after next without racing with threads that still read this one.
 enum {
   VAR_STATUS = 0, VAR_CUT, VAR_TAUC,
-  VAR_DANGER,  // sticky: this utterance has seen a log-probability that can make log_sum_exp depend on the order of its
-               // arguments (decoder_utils.h:47-54); see Decoder::enter_danger
   VAR_FB0 = 4, VAR_FB1, VAR_FB2, VAR_FB3,   // 16-byte aligned groups: read back with one LDS access (X::uni4)
-  VAR_TAU = 8, VAR_G, VAR_E, VAR_SPARE,
+  VAR_TAU = 8, VAR_G, VAR_E,
+  VAR_DANGER,  // sticky: this utterance has seen a log-probability that can make log_sum_exp depend on the order of its
+               // arguments (decoder_utils.h:47-54): "danger mode" (Decoder::note_next_row).  Shares the 16-byte group of the
+               // select's result so that phase C reads it for free.
   VAR_PAR0 = 12,  // first per-parity set
   P_NPIN = 0, P_LCOUNT, P_NMAXKEY, P_NMINKEY, P_NCAND, P_SIZE = 8,
-  VAR_LASTN = VAR_PAR0 + 2 * P_SIZE,  // #candidates / #slots of the frame decoded last in this launch (-1: none yet):
-  VAR_LASTS,                          // what enter_danger needs to replay that frame's std::nth_element after the fact
-  VAR_LASTNENT, VAR_LASTBRANK,        // ... and (LAZY layouts) to rebuild its info words: #beam entries, rank of the blank
-  VAR_COUNT = VAR_LASTN + 4
+  VAR_COUNT = VAR_PAR0 + 2 * P_SIZE
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
 constexpr int kBinsLog = 10;
@@ -251,7 +249,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
 // Persistent decoder state of one audio stream (the reference's DecoderState object kept alive between decode()
 // calls, ctc_beam_search_decoder.h:73-124 / ctcdecode/__init__.py:253-272), stored in HBM between launches:
 // hdr[0..7] = {frames fed so far (abs_time_step, ctc_beam_search_decoder.cpp:69), beam size, pool count, window log,
-// best key, danger mode (enter_danger), worst key, reserved}; arrays = the 13 beam arrays then fin, K entries each (kStateArrays).  The node pool lives in
+// best key, danger mode, worst key, reserved}; arrays = the 13 beam arrays then fin, K entries each (kStateArrays).  The node pool lives in
 // the same allocation and is passed separately.
 struct StreamState {
   int *hdr;
@@ -377,7 +375,6 @@ struct Decoder {
   uint32_t st_maxkey = 0;
   uint32_t st_minkey = 0;  // LM tier: key of the worst score in the beam (min_cutoff, ctc_beam_search_decoder.cpp:79)
   int st_par = 0;  // which copy of the beam is current
-  int st_danger = 0;  // "danger mode" (see enter_danger): every frame replays std::nth_element and keeps apos[] / fin[]
 
   template <class P>
   CTC_HD static P *shifted(P *q, size_t bytes) { return reinterpret_cast<P *>(reinterpret_cast<char *>(q) + bytes); }
@@ -492,10 +489,13 @@ struct Decoder {
   // and the extension of its parent (:108-139) -- in the order in which the two sit in the reference's `prefixes` array:
   // the permutation std::nth_element (:150-154) left there (with a scorer: the frame's std::sort, :75-76, on top of it).
   // That order matters only once a -inf has come into play, which needs a log-probability that is -inf / NaN or so large
-  // that a sum can overflow: lp_bad().  Rows are checked where they are staged into LDS; the first bad one raises
-  // VAR_DANGER, and from then on ("danger mode", sticky for the utterance / stream) every frame replays std::nth_element
-  // exactly and records the array order: fin[p] = beam entry at position p, apos[j] = position of entry j.  Ordinary
-  // inputs (log-softmax outputs, probabilities) never get here and pay one compare per staged value.
+  // that a sum can overflow: lp_bad().  The row of frame t+1 is in registers while frame t is decoded (it is prefetched):
+  // the threads that hold it look at it after phase B (step(): note_next_row) and raise the sticky flag VAR_DANGER, which
+  // phase C of the SAME frame already sees: from that frame on ("danger mode", sticky for the utterance / stream) every
+  // frame replays std::nth_element exactly and records the array order -- fin[p] = beam entry at position p, apos[j] =
+  // position of entry j -- so the frame that first meets a bad row finds the order its predecessor left.  (The first row
+  // of a launch is checked where it is staged; the order it needs is the one init() / load_state() provide.)  Ordinary
+  // inputs (log-softmax outputs, probabilities) never get here and pay one compare per prefetched value.
   CTC_HD static bool lp_bad(float v) { return !((ctcmath::f32_to_bits(v) & 0x7fffffffu) <= 0x60ad78ecu); }  // !(|v| <= 1e20f), NaN included
   CTC_HD bool lm_params_extreme() const {  // (alpha, beta so large that scores can overflow without any bad row)
     if (!LM) return false;
@@ -505,9 +505,9 @@ struct Decoder {
   CTC_HD void note_lp(float v) const {
     if (CTC_RARE(lp_bad(v))) w.vars[VAR_DANGER] = 1;
   }
-  // The order std::nth_element leaves N candidates (w.skey / w.sinfo over S slots) in: fin[p] / apos[] of the K survivors.
-  // rk[p] = DFS rank (= index in the next beam) of the survivor at array position p is left in w.surv + K as well.
-  // Returns true when the replay used the block of the slot keys as its staging area (w.skey[] is then garbage).
+  // The order std::nth_element leaves N candidates (w.skey / w.sinfo over S slots) in: ord[] = slots of the K survivors by
+  // array position (w.surv + 2K).  Returns true when the replay used the block of the slot keys as its staging area
+  // (w.skey[] is then garbage).
   CTC_HD bool nth_element_order(int S, int N, int K, const SlotCtx *lz = nullptr) {
     const int tid = x.tid(), nt = x.nt();
     int *rk = w.surv + K, *ord = w.surv + 2 * K;
@@ -527,41 +527,6 @@ struct Decoder {
     x.sync();
     return keys_gone;
   }
-  // Called when VAR_DANGER has just been seen set: the frame decoded last (if any in this launch) was pruned without
-  // recording its permutation; its slots are still in place, so the replay is done now.
-  CTC_HD void enter_danger() {
-    const int tid = x.tid(), nt = x.nt(), K = d.K;
-    st_danger = 1;
-    select_beams();  // (the replay may stage its ranges in the block of the beam that is not current)
-    const int N = x.uni(w.vars[VAR_LASTN]), S = x.uni(w.vars[VAR_LASTS]);
-    if (N < 0) return;  // -1: nothing decoded in this launch yet: init() / load_state() left the order of the incoming beam;
-                        // -2: the last frame replayed std::nth_element itself and recorded the order
-    x.sync();
-    if (N > K) {
-      if (LAZY) {  // no info words exist: the frame's layout (ostart / cstart / anc), keys and candidate labels are still in place
-        const int np = x.uni(w.vars[VAR_LASTNENT]), brp = x.uni(w.vars[VAR_LASTBRANK]);
-        const SlotCtx lz = slot_ctx(w.nxt, np, S / np - 2, brp);
-        nth_element_order(S, N, K, &lz);
-        for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;  // (build_ek_lazy's scratch; the next frame's histogram)
-      } else {
-        nth_element_order(S, N, K);
-      }
-      int *ord = w.surv + 2 * K;
-      for (int q = tid; q < K; q += nt) {  // rank by slot = index in the current beam
-        const int mine = ord[q];
-        int r = 0;
-        for (int o = 0; o < K; ++o) r += ord[o] < mine;
-        w.fin[q] = r;
-        w.apos[r] = q;
-      }
-    } else {
-      for (int q = tid; q < st_n; q += nt) { w.fin[q] = q; w.apos[q] = q; }  // iterate_to_vec order, nothing pruned
-    }
-    x.sync();
-  }
-  CTC_HD void poll_danger() {
-    if (CTC_RARE(x.uni(w.vars[VAR_DANGER]) != 0 && !st_danger)) enter_danger();
-  }
   // K packed (key, entry) words for the std::sort replays: in LDS (the block of the slot keys is idle between frames and
   // after the last one) wherever the slot keys are
   CTC_HD uint64_t *sort_scratch() const { return FARREP && w.stage_skey ? reinterpret_cast<uint64_t *>(w.skey) : w.ek; }
@@ -579,6 +544,7 @@ struct Decoder {
     sort_like_std(pk, n, [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); });
     for (int p = tid; p < n; p += nt) w.apos[(int)(pk[p] & 0xFFFFu)] = p;
     for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;  // (the sort's task lists live in the histogram)
+    if (tid == 0) w.vars[VAR_DANGER] = 1;                              // (... and its counters in the flag's 16-byte group)
     x.sync();
   }
 
@@ -603,10 +569,9 @@ struct Decoder {
       w.vars[VAR_STATUS] = ST_OK;
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
-      w.vars[VAR_DANGER] = lm_params_extreme() ? 1 : 0; w.vars[VAR_LASTN] = -1; w.vars[VAR_LASTS] = 0;
+      w.vars[VAR_DANGER] = lm_params_extreme() ? 1 : 0;
       w.apos[0] = 0; w.fin[0] = 0;
     }
-    st_danger = 0;
     st_n = 1; st_pool = 1; st_wlog = 32;  // first select looks at the whole key range
     st_maxkey = ord_f32(0.f);
     st_minkey = ord_f32(0.f);
@@ -624,7 +589,6 @@ struct Decoder {
     st_n = x.uni(ss.hdr[SH_N]); st_pool = x.uni(ss.hdr[SH_POOL]); st_wlog = x.uni(ss.hdr[SH_WLOG]);
     st_maxkey = (uint32_t)x.uni(ss.hdr[SH_MAXKEY]);
     st_minkey = (uint32_t)x.uni(ss.hdr[SH_MINKEY]);
-    st_danger = x.uni(ss.hdr[SH_DANGER]);
     st_par = 0;
     select_beams();
     Beam &b = w.cur;
@@ -645,7 +609,7 @@ struct Decoder {
       w.vars[VAR_STATUS] = ST_OK;
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
-      w.vars[VAR_DANGER] = st_danger; w.vars[VAR_LASTN] = -1; w.vars[VAR_LASTS] = 0;
+      w.vars[VAR_DANGER] = ss.hdr[SH_DANGER];
     }
     for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
     for (int i = tid; i < 2 * K; i += nt) { w.hit[i] = 0; w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
@@ -671,7 +635,7 @@ struct Decoder {
     if (tid == 0) {
       ss.hdr[SH_FRAMES] = frames; ss.hdr[SH_N] = st_n; ss.hdr[SH_POOL] = st_pool; ss.hdr[SH_WLOG] = st_wlog;
       ss.hdr[SH_MAXKEY] = (int)st_maxkey; ss.hdr[SH_MINKEY] = (int)st_minkey;
-      ss.hdr[SH_DANGER] = st_danger;
+      ss.hdr[SH_DANGER] = w.vars[VAR_DANGER];
     }
   }
 
@@ -1000,7 +964,9 @@ struct Decoder {
   // `stage`/`stage_val`: in identity mode the caller hands over its prefetched value of the NEXT frame's row; it is
   // parked in the other half of clpbuf before the closing fence, so the next frame starts without a load phase.
   // Returns ST_OK or the failure (identical in every thread; also left in VAR_STATUS).
-  CTC_HD int step(const StepIn &in, bool last, bool stage = false, float stage_val = 0.f) {
+  // `next_cnt` / `next_val`: threads below next_cnt hold a log-probability of the NEXT frame's candidates (the caller's
+  // prefetch; both may still be in flight when the step starts): looked at after phase B for danger mode (see note_lp).
+  CTC_HD int step(const StepIn &in, bool last, bool stage = false, float stage_val = 0.f, int next_cnt = 0, float next_val = 0.f) {
     select_beams();
     const Beam b = w.cur;
     const Beam nb = w.nxt;
@@ -1027,7 +993,7 @@ struct Decoder {
       full_beam = n == K;
     }
     auto cut = [&](float lp, float prefix_score) { return LM && full_beam && lp + prefix_score < min_cutoff; };
-    if (LM && CTC_RARE(st_danger)) lm_sorted_order(b, n);
+    if (LM && CTC_RARE(x.uni(w.vars[VAR_DANGER]) != 0)) lm_sorted_order(b, n);
 
     // ---- A1: per beam entry, from the LCP array alone: the end of its subtree range (first later entry whose LCP
     // with its predecessor is shallower than the entry), found by a wave-wide search; every entry then "paints" its
@@ -1118,6 +1084,7 @@ struct Decoder {
       int ncand = 0;
       for (int j = tid; j < n; j += (split ? n1 : nt)) {
         const int c = b.ch[j];
+        const int danger = w.vars[VAR_DANGER];  // (set by an earlier frame at the latest: the flag for THIS frame's row was raised one frame ahead)
         const int r = rank_of_char(in, c);
         const float sc = b.score[j], nbp = b.nbprev[j];
         float bcur = (brank >= 0 && !cut(lp_blank, sc)) ? lp_blank + sc : CTC_NEG_MAX;             // :97-101
@@ -1137,7 +1104,7 @@ struct Decoder {
             float logp = child_logp(P, c, lp);
             if (LM && lm_scores(c)) logp = lm_apply(logp, lm_window(b, P, c));  // :120-137
             // :138-139.  (danger mode: the parent sits before the entry in `prefixes` -> its extension was added first)
-            if (CTC_RARE(st_danger) && has_rep && w.apos[P] < w.apos[j]) nbcur = lse(logp, nbcur);
+            if (CTC_RARE(danger != 0) && has_rep && w.apos[P] < w.apos[j]) nbcur = lse(logp, nbcur);
             else nbcur = lse(nbcur, logp);
           }
         }
@@ -1252,6 +1219,9 @@ struct Decoder {
       for (int s = tid; s < S; s += nt) hist_add(wd, w.skey[s]);
       x.sync();
     }
+    // the next frame's row (in the caller's prefetch registers since before this frame started: long arrived): a bad value
+    // puts the utterance into danger mode from THIS frame's selection on (the barriers of phase C order the store)
+    if (tid < next_cnt) note_lp(next_val);
     x.mark(2);
 
     // ---- C: the K-th best key.  #candidates = beam entries + new children - children that already exist as entries
@@ -1276,7 +1246,7 @@ struct Decoder {
       exact = true;
 #endif
       if (CTC_RARE(last)) exact = true;  // decode() sorts the array exactly as nth_element left it (:164-190)
-      if (CTC_RARE(st_danger)) exact = true;  // the next frame adds its contributions in that order (enter_danger)
+      if (CTC_RARE(tv[3] != 0)) exact = true;  // danger mode (VAR_DANGER, read with the select's result): the next frame adds its contributions in that order
     }
     x.mark(5);
 
@@ -1350,8 +1320,6 @@ struct Decoder {
           for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }
           if (t0 == 0) {
             reset_pvars(pvars(in.t + 1));
-            w.vars[VAR_LASTN] = exact ? -2 : N; w.vars[VAR_LASTS] = S;  // (enter_danger)
-            if (LAZY) { w.vars[VAR_LASTNENT] = n; w.vars[VAR_LASTBRANK] = brank; }
           }
         }
       }
@@ -1434,7 +1402,8 @@ struct Decoder {
       x.wave_max_to(&pv[P_NMAXKEY], kloc);
       if (LM) x.wave_min_to(&pv[P_NMINKEY], kmin);
     }
-    if (CTC_RARE(last || st_danger || exact)) {  // the order std::nth_element left the survivors in (identity when it was not called)
+    // the order std::nth_element left the survivors in (identity when it was not called: then the flag is looked up here)
+    if (CTC_RARE(last || exact || (N <= K && x.uni(w.vars[VAR_DANGER]) != 0))) {
       for (int q = tid; q < n_new; q += nt) {
         const int r = exact ? rk[q] : q;
         w.fin[q] = r;
@@ -1447,7 +1416,7 @@ struct Decoder {
       x.sync();
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
     }
-    if (stage && tid < d.V) { w.clpbuf[((in.t + 1) & 1) * d.Vc_max + tid] = stage_val; note_lp(stage_val); }
+    if (stage && tid < d.V) w.clpbuf[((in.t + 1) & 1) * d.Vc_max + tid] = stage_val;
     x.mark(7);
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
     x.mark(9);
@@ -1472,7 +1441,6 @@ struct Decoder {
     x.dump(in.t, n_new, nb.node, nb.dep, nb.lcp, nb.score);
     x.mark(8);
     st_par ^= 1;
-    if (IDENT) poll_danger();  // the row staged above is the next frame's (the other modes stage -- and poll -- between steps)
     return ST_OK;
   }
 
@@ -1726,9 +1694,8 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     }
   }
   if (IDENT && prefetch && len > 0) {  // frame 0 goes straight to LDS; from then on step() stages frame t+1
-    if (tid < d.V) { w.clpbuf[(t0 & 1) * d.Vc_max + tid] = pre_lp; dec.note_lp(pre_lp); }
+    if (tid < d.V) { w.clpbuf[(t0 & 1) * d.Vc_max + tid] = pre_lp; dec.note_lp(pre_lp); }  // (the launch's first row: checked here)
     x.sync();
-    dec.poll_danger();
   }
   for (int t = 0; t < len; ++t) {
     StepIn in;
@@ -1740,6 +1707,10 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     }
     x.trace_frame(in.t);
     bool stage = false;
+    // danger mode looks one row ahead: row t + 1 is examined while frame t is decoded (row 0 where it is loaded)
+    int next_cnt = 0;  // threads below it hold a value of row t + 1 in next_val
+    float next_val = 0.f;
+    using Dec = Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP>;
     if (IDENT) {
       in.Vc = d.V;
       in.identity = 1;
@@ -1748,29 +1719,30 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
         w.clp = w.clpbuf + ((t0 + t) & 1) * d.Vc_max;
         stage = t + 1 < len;
         if (stage && tid < d.V) pre_lp = rows[(size_t)(t + 1) * d.V + tid];  // consumed at the end of this frame
+        next_cnt = stage ? d.V : 0;
+        next_val = pre_lp;
       } else {
-        for (int r = tid; r < d.V; r += nt) { const float v = rows[(size_t)t * d.V + r]; w.clp[r] = v; dec.note_lp(v); }
+        for (int r = tid; r < d.V; r += nt) {
+          const float v = rows[(size_t)t * d.V + r];
+          w.clp[r] = v;
+          if (t == 0) dec.note_lp(v);
+          if (t + 1 < len && Dec::lp_bad(rows[(size_t)(t + 1) * d.V + r])) { next_cnt = tid + 1; next_val = -__builtin_huge_valf(); }
+        }
         x.sync();
-        dec.poll_danger();
       }
     } else {
       in.identity = 0;
-      if (LAZY) {  // danger must be noticed while the previous frame's candidate labels (w.cch) are still in place: fill_info
-        if (prefetch) {
-          if (tid < x.uni(pre_cnt)) dec.note_lp(pre_lp);
-        } else {
-          const int cn = x.uni(pr->cnt[t]);
-          for (int r = tid; r < cn; r += nt) dec.note_lp(pr->lp[(size_t)t * width + r]);
-        }
-        x.sync();
-        dec.poll_danger();
-      }
       if (prefetch) {
         in.Vc = x.uni(pre_cnt);
-        if (tid < in.Vc) { w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid; dec.note_lp(pre_lp); }
+        if (tid < in.Vc) {
+          w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid;
+          if (t == 0) dec.note_lp(pre_lp);
+        }
         if (t + 1 < len) {
           pre_cnt = pr->cnt[t + 1];
           if (tid < width) { pre_ch = pr->ch[(size_t)(t + 1) * width + tid]; pre_lp = pr->lp[(size_t)(t + 1) * width + tid]; }
+          next_cnt = pre_cnt;
+          next_val = pre_lp;
         }
       } else {
         in.Vc = x.uni(pr->cnt[t]);
@@ -1780,16 +1752,20 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
           w.cch[r] = c;
           w.clp[r] = v;
           w.rank_of[c] = (int16_t)r;
-          dec.note_lp(v);
+          if (t == 0) dec.note_lp(v);
+        }
+        if (t + 1 < len) {
+          const int cn = x.uni(pr->cnt[t + 1]);
+          for (int r = tid; r < cn; r += nt)
+            if (Dec::lp_bad(pr->lp[(size_t)(t + 1) * width + r])) { next_cnt = tid + 1; next_val = -__builtin_huge_valf(); }
         }
       }
       x.sync();
       in.blank_rank = x.uni((int)w.rank_of[blank]);
-      dec.poll_danger();
     }
     x.tick();
     x.mark(10);
-    const int st = dec.step(in, t == len - 1, stage, pre_lp);
+    const int st = dec.step(in, t == len - 1, stage, pre_lp, next_cnt, next_val);
     x.mark(12);
     if (st != ST_OK) return st;
   }
