@@ -59,11 +59,13 @@
 
 namespace ctcbeam {
 
-struct PoolNode {   // one alive-or-retired trie node in HBM (16 bytes, one dwordx4 access)
+struct PoolNode {   // one alive-or-retired trie node in HBM: 12 bytes (round 3; 16 before: a quarter of the kernel's HBM writes)
   int32_t parent;   // pool index, -1 for the root
-  int32_t ch;       // label, -1 for the root
-  int32_t tstep;    // time step of the best log_prob_c seen while the node lived (path_trie.cpp:42-45)
-  float lpc;        // that log_prob_c
+  float lpc;        // the best log_prob_c seen while the node lived (path_trie.cpp:42-45)
+  uint32_t cht;     // label (16 bits, 0xFFFF for the root) | low 16 bits of the time step of that log_prob_c << 16; the
+                    // step's high bits live in a side array that is only touched by launches that can pass frame 65535
+  CTC_HD int ch() const { const uint32_t c = cht & 0xFFFFu; return c == 0xFFFFu ? -1 : (int)c; }
+  CTC_HD static uint32_t pack(int ch, int tstep) { return ((uint32_t)ch & 0xFFFFu) | ((uint32_t)tstep << 16); }
 };
 
 enum : uint32_t { T_SELF = 0, T_CHILD = 1, T_REVIVED = 2, T_HOLE = 3 };
@@ -360,13 +362,22 @@ struct Decoder {
   const int blank;
   PoolNode *pool;
   int *pool_up;  // up(X), stored for the nodes whose depth is a multiple of kExpress only
+  int *pool_thi; // time step >> 16 per node (behind pool_up); read / written only when long_t
+  bool long_t = false;  // this launch may see absolute frame numbers beyond 65535
   const int pool_cap;
   const uint64_t *tbl;  // exact_math tables
   const ctclm::LmView *lm;  // LM tier only
 
   CTC_HD Decoder(X &x_, Work &w_, const Dims &d_, int blank_, PoolNode *pool_, int *pool_up_, int pool_cap_, const uint64_t *tbl_,
                  const ctclm::LmView *lm_ = nullptr)
-      : x(x_), w(w_), d(d_), blank(blank_), pool(pool_), pool_up(pool_up_), pool_cap(pool_cap_), tbl(tbl_), lm(lm_) {}
+      : x(x_), w(w_), d(d_), blank(blank_), pool(pool_), pool_up(pool_up_), pool_thi(pool_up_ + pool_cap_), pool_cap(pool_cap_), tbl(tbl_), lm(lm_) {}
+  CTC_HD int node_tstep(const PoolNode &pn, int id) const { return (int)(pn.cht >> 16) | (CTC_RARE(long_t) ? pool_thi[id] << 16 : 0); }
+  // a node's (label, time step) word and, where frame numbers need more than 16 bits, the step's high part
+  CTC_HD void set_node_time(int id, int ch, int tstep, float lpc) const {
+    pool[id].lpc = lpc;
+    pool[id].cht = PoolNode::pack(ch, tstep);
+    if (CTC_RARE(long_t)) pool_thi[id] = tstep >> 16;
+  }
 
   CTC_HD float lse(float a, float b) const { return ctcmath::lse(a, b, tbl); }
 
@@ -563,9 +574,10 @@ struct Decoder {
         b.dn[0] = 0; b.dmlo[0] = (int)info.mask_lo; b.dmhi[0] = (int)info.mask_hi; b.dfc[0] = (int)info.first_child;
         put_f64(ctclm::kOovScore, &b.spc_lo[0], &b.spc_hi[0]); b.spst[0] = 0; b.spcl[0] = 0;
       }
-      PoolNode r; r.parent = -1; r.ch = -1; r.tstep = 0; r.lpc = CTC_NEG_MAX;
+      PoolNode r; r.parent = -1; r.cht = PoolNode::pack(-1, 0); r.lpc = CTC_NEG_MAX;
       pool[0] = r;
       pool_up[0] = 0;
+      pool_thi[0] = 0;
       w.vars[VAR_STATUS] = ST_OK;
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
@@ -1054,7 +1066,7 @@ struct Decoder {
             for (int h = 0; h < hops; ++h) xn = pool[xn].parent;
             b.via[j] = xn;
             b.viaanc[j] = b.node[P];
-            b.viach[j] = pool[xn].ch;
+            b.viach[j] = pool[xn].ch();
           }
           // j is the first beam entry below X iff its predecessor is outside X's subtree: then j revives X
           if (b.lcp[j] <= b.dep[P]) rr = rank_of_char(in, b.viach[j]);
@@ -1098,8 +1110,7 @@ struct Decoder {
           if (!cut(lp, b.score[P])) {
             if (b.lpc[j] < lp) {                                             // path_trie.cpp:42-45
               b.lpc[j] = lp;
-              pool[b.node[j]].tstep = in.t;
-              pool[b.node[j]].lpc = lp;
+              set_node_time(b.node[j], c, in.t, lp);
             }
             float logp = child_logp(P, c, lp);
             if (LM && lm_scores(c)) logp = lm_apply(logp, lm_window(b, P, c));  // :120-137
@@ -1122,8 +1133,7 @@ struct Decoder {
           float xl = pool[xn].lpc;
           if (xl < lp) {
             xl = lp;
-            pool[xn].tstep = in.t;
-            pool[xn].lpc = lp;
+            set_node_time(xn, cx, in.t, lp);
           }
           w.rev_lpc[j] = xl;  // read back by whoever compacts the revived node (same step, other thread)
           float logp = child_logp(P, cx, lp);
@@ -1354,8 +1364,9 @@ struct Decoder {
           int o_node = self ? node_j : id, o_par = self ? par_j : node_j, o_ch = self ? ch_j : c;
           int o_dep = self ? dep_j : dep_j + 1, o_viaanc = self ? viaanc_j : -1, o_up = self ? up_j : upv;
           if (child) {                                                                // path_trie.cpp:97-105
-            PoolNode pn; pn.parent = node_j; pn.ch = c; pn.tstep = in.t; pn.lpc = w.clp[rank_of_char(in, c)];
+            PoolNode pn; pn.parent = node_j; pn.cht = PoolNode::pack(c, in.t); pn.lpc = w.clp[rank_of_char(in, c)];
             pool[id] = pn;
+            if (CTC_RARE(long_t)) pool_thi[id] = in.t >> 16;
             // (up(X) is read back only from express nodes -- the back-trace hops from one multiple of kExpress levels to
             //  the next -- so only those store it: 1 node in kExpress)
             if (((dep_j + 1) & (kExpress - 1)) == 0) pool_up[id] = upv;
@@ -1610,7 +1621,7 @@ struct Decoder {
         uint32_t *seg = o.c_rag + (size_t)cbase + w.pos[j] - lo;  // label at depth q (lo < q <= dj) sits at seg[q - 1]
         while (dd > stop) {
           const PoolNode pn = pool[xn];
-          seg[dd - 1] = (uint32_t)pn.ch | ((uint32_t)pn.tstep << 16);
+          seg[dd - 1] = pn.cht;  // label | time step << 16: the compact format's own packing (T <= 65536 there)
           xn = pn.parent;
           --dd;
         }
@@ -1620,8 +1631,8 @@ struct Decoder {
       int32_t *tk = out_tok + row, *ts = out_ts + row;
       while (dd > stop) {
         const PoolNode pn = pool[xn];
-        tk[dd - 1] = pn.ch;
-        ts[dd - 1] = pn.tstep;
+        tk[dd - 1] = pn.ch();
+        ts[dd - 1] = node_tstep(pn, xn);
         xn = pn.parent;
         --dd;
       }
@@ -1678,6 +1689,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
+  dec.long_t = (long long)t0 + len > 65536;  // (frame numbers 0 .. 65535 fit the node's 16 bits)
   if (t0 > 0) dec.load_state(*ss); else dec.init();
   const int tid = x.tid(), nt = x.nt();
   // Prefetch: the candidates of step t+1 are requested from HBM before step t runs, so the latency hides behind it.

@@ -888,9 +888,13 @@ struct StreamCall {          // extra arguments of a streaming decode
 
 // (the parked arrays are always laid out for the LM tier's larger set: a stream block is sized once, before its scorer matters)
 size_t stream_pool_offset(int beam) { return ((size_t)(SH_WORDS + kStateArraysLm * (size_t)beam) * 4 + 255) / 256 * 256; }
-// a stream block holds [header | beam arrays | node pool (nodes * 16 B) | express pointers (nodes * 4 B)]
+// a stream block holds [header | beam arrays | node pool (nodes * 12 B) | express pointers (nodes * 4 B) | high parts of the
+// nodes' time steps (nodes * 4 B, zero until the stream passes frame 65535)]
 size_t stream_nodes(long long frames, int beam) { return (size_t)frames * beam + 1; }
 size_t stream_block_bytes(long long cap_frames, int beam) {
+  return stream_pool_offset(beam) + stream_nodes(cap_frames, beam) * (sizeof(PoolNode) + 2 * sizeof(int));
+}
+size_t stream_thi_offset(long long cap_frames, int beam) {
   return stream_pool_offset(beam) + stream_nodes(cap_frames, beam) * (sizeof(PoolNode) + sizeof(int));
 }
 
@@ -1093,7 +1097,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     log_input = 1;
   }
   const long long pool_stride = (long long)beam * T + 1;
-  if (!sc && (rc = d->pool.ensure((size_t)B * pool_stride * (sizeof(PoolNode) + sizeof(int))))) return rc;
+  // per utterance: nodes (12 B each), then -- per utterance again -- express pointers and the time steps' high parts (4 B each)
+  if (!sc && (rc = d->pool.ensure((size_t)B * pool_stride * (sizeof(PoolNode) + 2 * sizeof(int))))) return rc;
   if ((rc = d->status.ensure((size_t)B * 4))) return rc;
   // every status word starts as -1 ("no result"): a workgroup that never ran cannot read back as ST_OK
   HIP_TRY(hipMemsetAsync(d->status.p, 0xff, (size_t)B * 4, stream));
@@ -1469,6 +1474,7 @@ int ctcd_stream_create(ctcd_decoder *d, ctcd_stream **out, int V, int beam, int 
   hipError_t e = hipMalloc((void **)&st->block, st->bytes);
   if (e != hipSuccess) { delete st; return fail(CTCD_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
   e = hipMemset(st->block, 0, stream_pool_offset(beam));  // frames == 0: the first call initialises the beam
+  if (e == hipSuccess) e = hipMemset(st->block + stream_thi_offset(st->cap_frames, beam), 0, stream_nodes(st->cap_frames, beam) * sizeof(int));
   if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(CTCD_EHIP, std::string("hipMemset: ") + hipGetErrorString(e)); }
   *out = st;
   return CTCD_OK;
@@ -1514,6 +1520,8 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
       HIP_TRY(hipMemcpy(nb, st->block, off + used * sizeof(PoolNode), hipMemcpyDeviceToDevice));
       HIP_TRY(hipMemcpy(nb + off + stream_nodes(cap, beam) * sizeof(PoolNode),
                         st->block + off + stream_nodes(st->cap_frames, beam) * sizeof(PoolNode), used * sizeof(int), hipMemcpyDeviceToDevice));
+      HIP_TRY(hipMemset(nb + stream_thi_offset(cap, beam), 0, stream_nodes(cap, beam) * sizeof(int)));
+      HIP_TRY(hipMemcpy(nb + stream_thi_offset(cap, beam), st->block + stream_thi_offset(st->cap_frames, beam), used * sizeof(int), hipMemcpyDeviceToDevice));
       (void)hipFree(st->block);
       st->block = nb;
       st->bytes = bytes;

@@ -453,7 +453,7 @@ struct KernelArgs {
   int B, T, V, K, blank;
   Dims dims;
   PoolNode *pool;           // [B, pool_stride]
-  int *pool_up;             // [B, pool_stride] express pointers (beam_core.h kExpress)
+  int *pool_up;             // [B, 2, pool_stride] express pointers (beam_core.h kExpress), then the time steps' high parts
   long long pool_stride;
   const uint64_t *tables;   // 64 words (exact_math.h)
   OutRefs outs;             // result tensors; read through the kernel-argument segment at the end of an utterance
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
     prow.stride = a.pr_stride;
   }
   PoolNode *pool = a.pool + (size_t)b * a.pool_stride;
-  int *pool_up = a.pool_up + (size_t)b * a.pool_stride;
+  int *pool_up = a.pool_up + (size_t)b * 2 * a.pool_stride;  // [express pointers | time steps' high parts] of this utterance
   int pool_cap = (int)a.pool_stride;
   StreamState ss;
   if (a.st_base) {

@@ -237,7 +237,7 @@ extern "C" int ctccore_decode_compact_f32(const float *probs, const int32_t *seq
   unsigned count = 0;
   for (int b = 0; b < B; ++b) {
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
-    std::vector<int> pool_up(pool.size());
+    std::vector<int> pool_up(2 * pool.size());  // express pointers | time steps' high parts
     int len = seq_lens ? seq_lens[b] : T;
     len = std::max(0, std::min(len, T));
     carve<0>(w, mem.data(), far.data(), d, nullptr);
@@ -286,7 +286,7 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
                                                                                    : carve<1>(w, nullptr, nullptr, d, &far_bytes)) + 64);
     std::vector<char> far(far_bytes + 64);
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
-    std::vector<int> pool_up(pool.size());
+    std::vector<int> pool_up(2 * pool.size());  // express pointers | time steps' high parts
     std::vector<int> pcnt(T), pch((size_t)T * d.Vc_max);
     std::vector<float> plp((size_t)T * d.Vc_max);
     for (;;) {
@@ -367,7 +367,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
   std::vector<char> far(far_bytes + 64);
   for (int b = 0; b < B; ++b) {
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
-    std::vector<int> pool_up(pool.size());
+    std::vector<int> pool_up(2 * pool.size());  // express pointers | time steps' high parts
     std::vector<int> hdr(SH_WORDS, 0), arrays((size_t)kStateArrays * beam, 0);
     for (int c = 0; c < nchunks; ++c) {
       const int lo = bounds[c], hi = bounds[c + 1];

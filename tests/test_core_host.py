@@ -154,6 +154,17 @@ def test_core_streaming_equals_one_shot():
         ou.assert_same(ou.decode(lp, beam=K), ou.decode_core_host_chunked(lp, bounds, beam=K), "chunks %s" % bounds)
 
 
+def test_core_time_steps_beyond_16_bits():
+    """A pool node packs its label and the low 16 bits of its time step into one word (12-byte nodes); launches that can pass
+    frame 65535 keep the high bits in a side array.  One-shot and streamed across the boundary."""
+    T = 66500
+    lp = ou.synth_logprobs(1, T, 3, 17, blank_bias=2.5)  # blank-dominated: the label sequences stay short, their time steps span all of T
+    want = ou.decode(lp, beam=4)
+    assert int(want["timesteps"][0, 0, : want["lens"][0, 0]].max()) > 65536
+    ou.assert_same(want, ou.decode_core_host(lp, beam=4), "T > 65536")
+    ou.assert_same(want, ou.decode_core_host_chunked(lp, [100, 65000, 65536, 65537, 66000], beam=4), "T > 65536, streamed")
+
+
 def test_core_helpers():
     """ord_f32 (score -> sortable key), the shift forms of the divisions, log2 helpers, info-word packing."""
     import ctypes

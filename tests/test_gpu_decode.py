@@ -349,6 +349,28 @@ def test_two_workgroups_per_cu_build(torch_mod):
     ou.assert_same(_with_nres(run(lp, mode=0, beam=100), want), want, "B > #CUs, default build")
 
 
+def test_time_steps_beyond_16_bits(torch_mod):
+    """12-byte pool nodes keep 16 bits of the time step; past frame 65535 the high bits live in a side array (one-shot and
+    streamed across the boundary)."""
+    import ctcdecode_amd
+
+    T = 66500
+    lp = ou.synth_logprobs(2, T, 3, 17, blank_bias=2.5)
+    want = ou.decode(lp, beam=4)
+    assert int(want["timesteps"][0, 0, : want["lens"][0, 0]].max()) > 65536
+    ou.assert_same(_with_nres(_decode(torch_mod, lp, beam=4), want), want, "T > 65536")
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder(["0", "1", "2"], beam_width=4, blank_id=0, log_probs_input=True)
+    states = [ctcdecode_amd.DecoderState(dec) for _ in range(2)]
+    bounds = [0, 100, 65000, 65536, 65537, 66000, T]
+    x = torch_mod.from_numpy(lp)
+    for i in range(len(bounds) - 1):
+        out, sc, ts, ln = dec.decode(x[:, bounds[i]:bounds[i + 1]], states, [i == len(bounds) - 2] * 2)
+    got = dict(tokens=np.zeros((2, 4, T), np.int32), timesteps=np.zeros((2, 4, T), np.int32), scores=sc.numpy(), lens=ln.numpy())
+    got["tokens"][:, : out.shape[1], : out.shape[2]] = out.numpy()
+    got["timesteps"][:, : out.shape[1], : out.shape[2]] = ts.numpy()
+    ou.assert_same(_with_nres(got, want), want, "T > 65536, streamed")
+
+
 def test_capability_boundaries(torch_mod):
     """Every CTCD_EUNSUPPORTED edge of the no-LM path: on the supported side of a limit the call decodes
     and matches the oracle; one step beyond, it raises NotImplementedError -- cleanly: the same decoder object then decodes
