@@ -772,13 +772,21 @@ struct Decoder {
     for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
     x.sync();
     x.mark(14);
-    for (int q = tid; q < inb; q += nt) {
-      const uint32_t mine = w.list[q];
+    // a long list (wide beams: up to kListCap keys share the bucket) is ranked by eight lanes per key, each comparing an
+    // eighth of the list; a short one by one lane per key
+    const bool wide_rank = !SMALLV && inb > 32 && nt >= 8 * kListCap;
+    for (int q0 = tid; q0 < (wide_rank ? 8 * kListCap : inb); q0 += nt) {
+      const int q = wide_rank ? q0 >> 3 : q0, part = wide_rank ? q0 & 7 : 0, stride = wide_rank ? 32 : 4;
+      const uint32_t mine = q < inb ? w.list[q] : 0u;
       int g = 0, e = 0;
-      for (int r = 0; r < inb; r += 4) {
+      for (int r = 4 * part; r < inb; r += stride) {
         const uint32_t o0 = w.list[r], o1 = w.list[r + 1], o2 = w.list[r + 2], o3 = w.list[r + 3];
         g += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
         e += (o0 == mine) + (o1 == mine) + (o2 == mine) + (o3 == mine);
+      }
+      if (wide_rank) {
+        g = x.sum8(g); e = x.sum8(e);
+        if (part != 0 || q >= inb) continue;
       }
       if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
         w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gsum + g; w.vars[VAR_E] = e;
@@ -1309,12 +1317,14 @@ struct Decoder {
     }
     {
       const int ne = (n_new + 63) & ~63;
-      const bool roles = nt >= 3 * ne;
+      // (wide beams: the workgroup has two sets of waves per survivor, not three: LCP + structure || probabilities [+ scorer state])
+      const bool two = !SMALLV && nt < 3 * ne && nt >= 2 * ne;
+      const bool roles = nt >= 3 * ne || two;
       // (LM tier: a fourth part -- the scorer state of the new entries, whose dependent table look-ups are the longest
       //  chain of the emission -- gets its own waves when there are enough)
-      const int nroles = (LM && nt >= 4 * ne) ? 4 : 3;
+      const int nroles = two ? 2 : (LM && nt >= 4 * ne) ? 4 : 3;
       const int role = roles ? (tid >= ne) + (tid >= 2 * ne) + (tid >= 3 * ne) + (tid >= 4 * ne) : -1;  // nroles and above = no part
-      const bool r_lcp = role <= 0, r_struct = role < 0 || role == 1, r_prob = role < 0 || role == 2;
+      const bool r_lcp = role <= 0, r_struct = role < 0 || (two ? role == 0 : role == 1), r_prob = role < 0 || (two ? role == 1 : role == 2);
       const bool r_lm = LM && (nroles == 4 && roles ? role == 3 : r_prob);
       r_prob_any = r_prob;
       // Per-frame resets for the next step, on the threads that have no part in the emission (all of them otherwise):

@@ -145,6 +145,11 @@ struct DevX {
     return n;
   }
   __device__ __forceinline__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+  // sum over the aligned group of eight lanes this lane belongs to (every lane of the wave must call it)
+  __device__ __forceinline__ int sum8(int v) const {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+  }
   // one LDS atomic per wave
   __device__ __forceinline__ void wave_add(int *p, int v) {
     v = wave_sum(v);
@@ -203,10 +208,13 @@ struct DevX {
     const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
     const int first = wave * rounds * 64;
 #define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
-    if (rounds <= 4) {
-      const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
-      const uint32_t k0 = s0 < S ? skey[s0] : 0u, k1 = (rounds > 1 && s1 < S) ? skey[s1] : 0u;
-      const uint32_t k2 = (rounds > 2 && s2 < S) ? skey[s2] : 0u, k3 = (rounds > 3 && s3 < S) ? skey[s3] : 0u;
+    // four rounds at a time, straight-line: their keys are requested together (one LDS round trip), and one returning
+    // atomic reserves the list space of all four.  (Wide beams take several such groups: 15 rounds at beam 500.)
+    for (int r0 = 0; r0 < rounds; r0 += 4) {
+      const int nr = rounds - r0;  // rounds left (uniform)
+      const int s0 = first + r0 * 64 + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
+      const uint32_t k0 = s0 < S ? skey[s0] : 0u, k1 = (nr > 1 && s1 < S) ? skey[s1] : 0u;
+      const uint32_t k2 = (nr > 2 && s2 < S) ? skey[s2] : 0u, k3 = (nr > 3 && s3 < S) ? skey[s3] : 0u;
       const uint32_t d0 = k0 - b32, d1 = k1 - b32, d2 = k2 - b32, d3 = k3 - b32;
       const bool g0 = k0 >= b32, g1 = k1 >= b32, g2 = k2 >= b32, g3 = k3 >= b32;  // (b32 >= 1: holes, key 0, never pass)
       const bool i0 = g0 && d0 <= bspan, i1 = g1 && d1 <= bspan, i2 = g2 && d2 <= bspan, i3 = g3 && d3 <= bspan;
@@ -224,27 +232,10 @@ struct DevX {
         if (i2) { const int p = base + c0 + c1 + CTC_BELOW(m2); list[p] = d2 + 1u; lslot[p] = s2; }
         if (i3) { const int p = base + c0 + c1 + c2 + CTC_BELOW(m3); list[p] = d3 + 1u; lslot[p] = s3; }
       }
-      if (lane < rounds) {
+      if (lane < 4 && lane < nr) {
         const unsigned long long m = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a3;
-        bitmap[2 * (wave * rounds + lane)] = (uint32_t)m;
-        bitmap[2 * (wave * rounds + lane) + 1] = (uint32_t)(m >> 32);
-      }
-      return;
-    }
-    for (int it = 0; it < rounds; ++it) {
-      const int s = first + it * 64 + lane;
-      const uint32_t k = s < S ? skey[s] : 0u, dk = k - b32;
-      const bool g = k >= b32, in = g && dk <= bspan;
-      const unsigned long long m = __ballot(in), am = __ballot(direct && g && !in);
-      if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(lcount, __popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (in) { const int p = base + CTC_BELOW(m); list[p] = dk + 1u; lslot[p] = s; }
-      }
-      if (lane == 0) {
-        bitmap[2 * (wave * rounds + it)] = (uint32_t)am;
-        bitmap[2 * (wave * rounds + it) + 1] = (uint32_t)(am >> 32);
+        bitmap[2 * (wave * rounds + r0 + lane)] = (uint32_t)m;
+        bitmap[2 * (wave * rounds + r0 + lane) + 1] = (uint32_t)(m >> 32);
       }
     }
 #undef CTC_BELOW
@@ -275,6 +266,31 @@ struct DevX {
         while (bits) {
           out[base++] = s0 + __builtin_ctz(bits);
           bits &= bits - 1u;
+        }
+      }
+      sync();
+      return;
+    }
+    if (nwords64 > 64 && ((nwords64 + 63) & ~63) <= nt()) {
+      // wide beams (beam 500: 243 words): one wave per 64 words, all at once; a wave first adds up the populations of the
+      // segments before its own (round 2 walked the segments one after the other on wave 0)
+      const int lane = (int)threadIdx.x & 63;
+      const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+      if (wv * 64 < nwords64) {
+        int running = 0;
+        for (int seg = 0; seg < wv; ++seg) {
+          const int wj = seg * 64 + lane;
+          running += wave_sum(__popc(bitmap[2 * wj]) + __popc(bitmap[2 * wj + 1]));
+        }
+        const int wi = wv * 64 + lane;
+        unsigned long long word = 0ull;
+        if (wi < nwords64) word = (unsigned long long)bitmap[2 * wi] | ((unsigned long long)bitmap[2 * wi + 1] << 32);
+        const int cnt = __popcll(word);
+        const int incl = wave_scan(cnt, 0, [](int a, int b) { return a + b; });
+        int base = running + incl - cnt;
+        while (word) {
+          out[base++] = wi * 64 + __builtin_ctzll(word);
+          word &= word - 1ull;
         }
       }
       sync();

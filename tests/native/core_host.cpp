@@ -57,6 +57,7 @@ struct HostX {
   }
   int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
   void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
+  int sum8(int v) const { return v; }
   void wave_add(int *p, int v) { *p += v; }
   void find_bucket(int *bins, int need, int *out) {
     using ctcbeam::kBins;
