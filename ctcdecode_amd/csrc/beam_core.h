@@ -68,6 +68,23 @@ struct PoolNode {   // one alive-or-retired trie node in HBM: 12 bytes (round 3;
   CTC_HD static uint32_t pack(int ch, int tstep) { return ((uint32_t)ch & 0xFFFFu) | ((uint32_t)tstep << 16); }
 };
 
+// Element of the exact replay's candidate list.  Up to 65535 slots the slot index rides in the low 16 bits of one word;
+// the widest layout (more slots: cutoff_top_n >= V with thousands of labels) keeps it beside the key.
+struct EkWide { uint64_t k; uint32_t slot, pad; };
+template <bool HUGE> struct EkOps;
+template <> struct EkOps<false> {
+  using E = uint64_t; using Pos = uint16_t;
+  CTC_HD static E make(uint64_t key48v, int slot) { return (key48v << 16) | (uint64_t)slot; }
+  CTC_HD static uint64_t key(const E &e) { return e >> 16; }
+  CTC_HD static int slot(const E &e) { return (int)(e & 0xFFFFu); }
+};
+template <> struct EkOps<true> {
+  using E = EkWide; using Pos = uint32_t;
+  CTC_HD static E make(uint64_t key48v, int slot) { E e; e.k = key48v; e.slot = (uint32_t)slot; e.pad = 0; return e; }
+  CTC_HD static uint64_t key(const E &e) { return e.k; }
+  CTC_HD static int slot(const E &e) { return (int)e.slot; }
+};
+
 enum : uint32_t { T_SELF = 0, T_CHILD = 1, T_REVIVED = 2, T_HOLE = 3 };
 enum : int { ST_OK = 0, ST_POOL_OVERFLOW = 1, ST_BAD_CONFIG = 2 };
 
@@ -156,8 +173,9 @@ struct Work {
   int16_t *rank_of;  // V entries, -1 = not a candidate (only when Dims::use_rank_table; V <= 32767 then)
   uint32_t *skey, *sinfo, *pos;  // S_max (+1 for pos): score key, info word, scratch
   int *surv;       // 3K: slots of the survivors | their rank in slot (= DFS) order | inverse of that ranking
-  uint64_t *ek;    // S_max: (key48 << 16 | slot) in DFS order, for the exact replay
-  uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition
+  uint64_t *ek;    // S_max: (key48 << 16 | slot) in DFS order, for the exact replay (widest layout: 16-byte elements, EkWide)
+  uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition (widest layout: 32 bit each)
+  uint32_t *wpre;  // build_ek_lazy's prefix over the bitmap's words (the histogram's block; widest layout: HBM scratch)
   int *bins;       // kBins buckets of the select histogram (+ kBins/16 more words: with them, the task lists of the final sorts)
   uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
   int *lslot;      // kListCap: their slots
@@ -184,12 +202,15 @@ CTC_HD P *carve_ptr(char *&p, size_t count) {
 // BIG != 0 (implies FARREP): the per-slot info words live in `far` as well (and are only written on the rare paths:
 // LAZY), so that wide beams still fit the 160 KiB of LDS; *far_bytes gets the size of everything in `far`.
 // BIG == 1: the rare-path per-slot arrays in HBM; BIG == 2: also the slot keys and the rarely read per-entry arrays
-// (dead-interior bookkeeping, existing-child ranks): the widest beams, slowly.
+// (dead-interior bookkeeping, existing-child ranks): the widest beams, slowly.  BIG == 3: as 2, for more than 65535
+// candidate slots (cutoff_top_n >= V with thousands of labels): 32-bit slot indices in the replay's arrays, the select's
+// bitmap and its word prefix in HBM as well -- everything per slot lives there; a capability, far from a fast path.
 template <int BIG, bool FARREP = false>
 CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_bytes) {
   char *p = base;
   char *q = far;
   constexpr bool deep = BIG >= 2;  // (a compile-time choice: every array keeps a static address space, LDS or global)
+  constexpr bool huge = BIG >= 3;
   const size_t K = (size_t)d.K, S = (size_t)d.S_max();
   const size_t Kr = ((K * 4 + 15) / 16) * 16;
   Beam *bs[2] = {&w.cur, &w.nxt};
@@ -232,7 +253,8 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.skey = carve_ptr<uint32_t>(deep ? q : p, S);
   w.surv = carve_ptr<int>(p, 3 * K + 4);
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
-  w.lslot = carve_ptr<int>(p, kListCap + 4); w.bitmap = carve_ptr<uint32_t>(p, 2 * ((S + 63) / 64 + 17));
+  w.lslot = carve_ptr<int>(p, kListCap + 4); w.bitmap = carve_ptr<uint32_t>(huge ? q : p, 2 * ((S + 63) / 64 + 17));
+  w.wpre = huge ? carve_ptr<uint32_t>(q, (S + 63) / 64 + 2) : reinterpret_cast<uint32_t *>(w.bins);
   w.fin = carve_ptr<int>(BIG ? q : p, K);  // (last / exact / danger frames and finish() only: HBM scratch in the wide-beam layouts)
   w.apos = carve_ptr<int>(BIG ? q : p, K);  // (read in danger mode only: HBM scratch in the wide-beam layouts)
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
@@ -242,7 +264,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.sinfo = carve_ptr<uint32_t>(p, BIG ? K : S);
   w.pos = carve_ptr<uint32_t>(BIG ? q : p, K + 2);  // (finish(): label offsets of the compact results)
   char *&rr = (BIG || FARREP) ? q : p;
-  w.ek = carve_ptr<uint64_t>(rr, S); w.lr = carve_ptr<uint16_t>(rr, 2 * S + 2);
+  w.ek = carve_ptr<uint64_t>(rr, huge ? 2 * S : S); w.lr = carve_ptr<uint16_t>(rr, (2 * S + 2) * (huge ? 2 : 1));
   w.stage_skey = deep ? 0 : 1;
   if (far_bytes) *far_bytes = (size_t)(q - far);
   return (size_t)(p - base);
@@ -353,9 +375,14 @@ constexpr int kSmallK = 128, kSmallV = 32;
 // candidates are scored.  The <= K survivors find theirs with a binary search over the entries' slot offsets
 // (info_of_slot); the rare paths that look at every slot (ties at the K boundary, exact replay) first rebuild all of them
 // (fill_info).  Round 2 wrote S info words per frame to HBM: 30 GB per configs[2] launch, 18x the algorithmic bytes.
-// FARREP: the exact replay's scratch lives in HBM (carve).
-template <class X, bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY>
+// FARREP: the exact replay's scratch lives in HBM (carve).  HUGE: more than 65535 candidate slots (carve BIG == 3).
+template <class X, bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false>
 struct Decoder {
+  using EO = EkOps<HUGE>;
+  using Ek = typename EO::E;
+  using LrT = typename EO::Pos;
+  CTC_HD Ek *ekp() const { return reinterpret_cast<Ek *>(w.ek); }
+  CTC_HD LrT *lrp() const { return reinterpret_cast<LrT *>(w.lr); }
   X &x;
   Work &w;
   const Dims d;
@@ -527,14 +554,14 @@ struct Decoder {
     } else {  // the candidates in DFS (= slot) order: (48-bit key, slot) of every slot that is not a hole
       const uint32_t *sinfo = w.sinfo;
       const uint32_t *skey = w.skey;
-      uint64_t *ek = w.ek;
+      Ek *ek = ekp();
       x.compact_slots_to(S, [=](int s) -> bool { return info_type(sinfo[s]) != T_HOLE; },
-                         [=](int r, int s) { ek[r] = (key48(skey[s], sinfo[s]) << 16) | (uint64_t)s; });
+                         [=](int r, int s) { ek[r] = EO::make(key48(skey[s], sinfo[s]), s); });
     }
     FullSyncView<X> fx{x};
     if (FARREP) fx.sync();  // the list is in HBM scratch
     const bool keys_gone = replay_nth_element(fx, N, K);
-    for (int k = tid; k < K; k += nt) { rk[k] = 0; ord[k] = (int)(w.ek[k] & 0xFFFFu); }  // ord: nth_element order
+    for (int k = tid; k < K; k += nt) { rk[k] = 0; ord[k] = EO::slot(ekp()[k]); }  // ord: nth_element order
     x.sync();
     return keys_gone;
   }
@@ -681,7 +708,7 @@ struct Decoder {
     if (off == 0) return mk_info(c.pb->viach[j], T_REVIVED, j);
     if (off == 1) return mk_info(c.pb->ch[j], T_SELF, j);
     const uint32_t q = (uint32_t)(off - 2);
-    const int g = (int)(((uint64_t)q * c.vmagic) >> 32);
+    const int g = HUGE ? (int)(q / (uint32_t)c.Vnb) : (int)(((uint64_t)q * c.vmagic) >> 32);
     const int rn = (int)q - g * c.Vnb;
     int i = j;
     for (int h = 0; h < g; ++h) i = w.anc[i];
@@ -694,10 +721,11 @@ struct Decoder {
   CTC_HD void build_ek_lazy(const SlotCtx &c, int S) {
     const int tid = x.tid(), nt = x.nt();
     const uint32_t *skey = w.skey;
-    uint32_t *bm = w.bitmap, *wpre = reinterpret_cast<uint32_t *>(w.bins);
+    uint32_t *bm = w.bitmap, *wpre = w.wpre;
+    Ek *ek = ekp();
     x.mark_slots(S, bm, [=](int sl) -> bool { return skey[sl] != 0u; });
     x.sync();
-    const int nw = (S + 63) / 64;  // <= 1024 (S < 65536): fits the histogram's 1024 + 64 words
+    const int nw = (S + 63) / 64;  // <= 1024 for S < 65536: fits the histogram's 1024 + 64 words (more slots: wpre is in HBM)
     for (int i = tid; i <= nw; i += nt) wpre[i] = i < nw ? (uint32_t)(__builtin_popcount(bm[2 * i]) + __builtin_popcount(bm[2 * i + 1])) : 0u;
     x.sync();
     x.scan_excl(wpre, nw + 1);
@@ -706,7 +734,7 @@ struct Decoder {
       const int bit = sl & 63;
       const uint32_t mlo = bit >= 32 ? 0xFFFFFFFFu : ((1u << bit) - 1u), mhi = bit > 32 ? ((1u << (bit - 32)) - 1u) : 0u;
       const int r = (int)wpre[sl >> 6] + __builtin_popcount(lo & mlo) + __builtin_popcount(hi & mhi);
-      w.ek[r] = (key48(skey[sl], mk_info(ch, 0, 0)) << 16) | (uint64_t)sl;
+      ek[r] = EO::make(key48(skey[sl], mk_info(ch, 0, 0)), sl);
     };
     for (int j = tid; j < c.n; j += nt) {
       const int s0 = w.ostart[j];
@@ -714,7 +742,7 @@ struct Decoder {
       put(s0 + 1, c.pb->ch[j]);
     }
     for (int idx = tid; idx < c.n * c.Vnb; idx += nt) {
-      const int i = (int)(((uint64_t)(uint32_t)idx * c.vmagic) >> 32), rn = idx - i * c.Vnb;
+      const int i = HUGE ? idx / c.Vnb : (int)(((uint64_t)(uint32_t)idx * c.vmagic) >> 32), rn = idx - i * c.Vnb;
       const int sl = w.cstart[i] + rn;
       if (skey[sl] != 0u) put(sl, cand_char(rn, c.brank));
     }
@@ -917,8 +945,8 @@ struct Decoder {
   // the rest: stl_emul.h split_with_median_pivot) by the whole workgroup.  Lp, Rp: scratch for last - first + 1 positions
   // each.  Returns the cut.
   template <class XX>
-  CTC_HD int hoare_round(XX &xx, uint64_t *v, int first, int last, uint16_t *Lp, uint16_t *Rp) {
-    return stlemu::hoare_round_parallel(xx, v, first, last, [](uint64_t e) { return e >> 16; }, Lp, Rp, &w.vars[VAR_CUT]);
+  CTC_HD int hoare_round(XX &xx, Ek *v, int first, int last, LrT *Lp, LrT *Rp) {
+    return stlemu::hoare_round_parallel(xx, v, first, last, [](const Ek &e) { return EO::key(e); }, Lp, Rp, &w.vars[VAR_CUT]);
   }
 
   // std::nth_element(begin, begin+K, end, prefix_compare) on the DFS-ordered candidate list (w.ek[0, N)).
@@ -931,34 +959,35 @@ struct Decoder {
   template <class XX>
   CTC_HD bool replay_nth_element(XX &fx, int N, int K) {
     const int tid = x.tid(), nt = x.nt();
-    uint64_t *v = w.ek;
-    auto before = [](uint64_t a, uint64_t c) { return (a >> 16) > (c >> 16); };
+    Ek *v = ekp();
+    LrT *lr = lrp();
+    auto before = [](const Ek &a, const Ek &c) { return EO::key(a) > EO::key(c); };
     int first = 0, last = N, depth = 2 * stlemu::floor_lg(N);
     if (!FARREP) {  // everything in LDS
       while (last - first > kSerialCut && depth > 0) {
         --depth;
-        const int cut = hoare_round(x, v, first, last, w.lr, w.lr + N + 1);
+        const int cut = hoare_round(x, v, first, last, lr, lr + N + 1);
         if (cut <= K) first = cut; else last = cut;
       }
       if (tid == 0) stlemu::introselect(v, first, K, last, depth, before);
       x.sync();
       return false;
     }
-    uint64_t *sv = reinterpret_cast<uint64_t *>(w.nxt.node);
-    int stage_cap = (int)((w.beam_blk - 16) / 12);  // 8 B per element + two 16-bit position lists
+    Ek *sv = reinterpret_cast<Ek *>(w.nxt.node);
+    int stage_cap = (int)((w.beam_blk - 16) / (sizeof(Ek) + 2 * sizeof(LrT)));  // an element + its place in the two position lists
     if (w.stage_skey) {
-      sv = reinterpret_cast<uint64_t *>(w.skey);
+      sv = reinterpret_cast<Ek *>(w.skey);
       const int cap_e = d.S_max() / 2, cap_p = (int)(w.beam_blk / 4) - 2;
       stage_cap = cap_e < cap_p ? cap_e : cap_p;
     }
     while (last - first > kSerialCut && depth > 0 && last - first > stage_cap) {
       --depth;
-      const int cut = hoare_round(fx, v, first, last, w.lr, w.lr + N + 1);
+      const int cut = hoare_round(fx, v, first, last, lr, lr + N + 1);
       if (cut <= K) first = cut; else last = cut;
     }
     if (last - first > kSerialCut && depth > 0) {
       const int m0 = last - first, base = first;
-      uint16_t *sLp = w.stage_skey ? reinterpret_cast<uint16_t *>(w.nxt.node) : reinterpret_cast<uint16_t *>(sv + m0), *sRp = sLp + m0 + 1;
+      LrT *sLp = w.stage_skey ? reinterpret_cast<LrT *>(w.nxt.node) : reinterpret_cast<LrT *>(sv + m0), *sRp = sLp + m0 + 1;
       for (int i = tid; i < m0; i += nt) sv[i] = v[base + i];
       x.sync();
       int f2 = 0, l2 = m0;
@@ -1282,7 +1311,7 @@ struct Decoder {
       }
       x.sync();
       if (keys_in_ord) {
-        for (int q = tid; q < K; q += nt) ord[rk[q]] = (int)(uint32_t)(w.ek[q] >> 32);
+        for (int q = tid; q < K; q += nt) ord[rk[q]] = (int)(uint32_t)(EO::key(ekp()[q]) >> 16);
         x.sync();
       }
       x.mark(6);
@@ -1690,13 +1719,13 @@ struct PrunedRows {
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
 // LM tier: `lm` = the scorer's tables, `raw` = the caller's own [len, V] rows (log-probabilities or probabilities,
 // `raw_log` says which): ctc_beam_search_decoder.cpp:78 takes the blank's log-probability from them directly.
-template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, class X>
+template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr, const ctclm::LmView *lm = nullptr, const float *raw = nullptr,
                             int raw_log = 1) {
   if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
-  Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
+  Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   dec.long_t = (long long)t0 + len > 65536;  // (frame numbers 0 .. 65535 fit the node's 16 bits)
@@ -1732,7 +1761,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     // danger mode looks one row ahead: row t + 1 is examined while frame t is decoded (row 0 where it is loaded)
     int next_cnt = 0;  // threads below it hold a value of row t + 1 in next_val
     float next_val = 0.f;
-    using Dec = Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP>;
+    using Dec = Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE>;
     if (IDENT) {
       in.Vc = d.V;
       in.identity = 1;

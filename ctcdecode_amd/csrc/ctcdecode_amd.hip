@@ -1034,8 +1034,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   CTC_ON_DEVICE(d->device);
   if (B == 0) return CTCD_OK;
   const Dims dims = make_dims(beam, V, cutoff_top_n, cutoff_prob, scorer != nullptr);
-  if (dims.S_max() > 65535)
-    return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) exceeds 65535 candidate slots");
+  // more than 65535 candidate slots (cutoff_top_n >= V with thousands of labels): the layout with 32-bit slot indices and
+  // everything per slot in HBM scratch (workspace level 3) -- the reference has no such limit (decoder_utils.cpp:33-35)
+  const bool huge = dims.S_max() > 65535;
+  if ((long long)beam * (dims.Vc_max + 2) > (1LL << 24) - 1)
+    return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) exceeds 16777215 candidate slots");
+  if (huge && scorer) return fail(CTCD_EUNSUPPORTED, "the LM tier is limited to 65535 candidate slots (beam_width * (candidates + 2))");
+  if (huge && d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the layout for more than 65535 candidate slots");
   if (dims.use_rank_table && V > 32767) return fail(CTCD_EUNSUPPORTED, "vocabulary pruning with more than 32767 labels");
   Work wtmp;
   size_t far_bytes = 0;
@@ -1051,7 +1056,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   size_t lds = occ2 ? carve<0, true>(wtmp, nullptr, nullptr, ldims, &far_bytes) : carve<0>(wtmp, nullptr, nullptr, ldims, &far_bytes);
   bool big = false;
   int far_level = 1;
-  if (lds + 2048 > (size_t)d->max_lds) {  // wide beam: rare-path arrays go to HBM scratch
+  if (huge) {
+    big = true;
+    far_level = 3;
+    lds = carve<3>(wtmp, nullptr, nullptr, dims, &far_bytes);
+  } else if (lds + 2048 > (size_t)d->max_lds) {  // wide beam: rare-path arrays go to HBM scratch
     big = true;
     lds = carve<1>(wtmp, nullptr, nullptr, dims, &far_bytes);
     if (lds + 2048 > (size_t)d->max_lds) {  // wider still: the slot keys and the rarely read per-entry arrays follow them
@@ -1331,6 +1340,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
        : fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 0, 1, true> : (const void *)ctc_beam_decode_kernel<PROF_, 0, 1, false>) \
                : (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 0, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, 0, 0, false>))
   fn = d->profile ? CTC_PICK(1) : CTC_PICK(0);
+  if (big && far_level == 3) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 3, 0, true> : (const void *)ctc_beam_decode_kernel<0, 3, 0, false>;
   if (big && far_level == 2) {  // the widest beams: their own instantiation (every workspace array keeps a static address space)
     if (d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the widest-beam layout");
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false>;

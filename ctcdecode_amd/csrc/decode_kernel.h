@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #else
   if (LM) lmv = &a.lm;
 #endif
-  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM, BIG != 0, BIG != 0 || OCC2>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
+  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM, BIG != 0, BIG != 0 || OCC2, BIG == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + (size_t)b * a.T * a.V : nullptr, a.raw_log);
   if (threadIdx.x == 0) a.status[b] = st;
@@ -592,7 +592,8 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(0, 0, 0, false, 0, true, false, 11) X(0, 0, 0, true, 0, true, false, 11) X(0, 0, 1, false, 1024, true, false, 2)                     \
   X(0, 0, 1, true, 1024, true, false, 3) X(2, 0, 1, false, 1024, true, false, 4)                                                       \
   X(0, 0, 1, false, 1024, false, true, 0) X(0, 0, 1, true, 1024, false, true, 1) X(0, 0, 1, false, 1024, true, true, 10) X(0, 0, 1, true, 1024, true, true, 11) \
-  X(0, 1, 0, false, 0, true, false, 6) X(0, 1, 0, true, 0, true, false, 7) X(0, 2, 0, false, 0, true, false, 8) X(0, 2, 0, true, 0, true, false, 9)
+  X(0, 1, 0, false, 0, true, false, 6) X(0, 1, 0, true, 0, true, false, 7) X(0, 2, 0, false, 0, true, false, 8) X(0, 2, 0, true, 0, true, false, 9) \
+  X(0, 3, 0, false, 0, false, false, 5) X(0, 3, 0, true, 0, false, false, 4)
 #endif
 
 }  // namespace ctcdk

@@ -302,30 +302,43 @@ STLEMU_HD void sort_parallel(X &x, T *v, int n, C before, I *cur, I *nxt, I *sma
 // than the pivot; right-to-left: elements not worse); one prefix over the threads turns the counts into the stops' ranks;
 // the t-th stop from the left is exchanged with the t-th from the right until the scans cross -- the exchanges of the
 // serial loop.  X additionally provides block_scan_u32(mine, &exclusive_prefix, &total) (contains a barrier).
-// Lp, Rp: scratch for last - first + 1 positions each (16 bit: n < 65536); *cutvar: one shared word.  Returns the cut.
-template <class X, class T, class KeyOf>
-STLEMU_HD int hoare_round_parallel(X &x, T *v, int first, int last, KeyOf key_of, uint16_t *Lp, uint16_t *Rp, int *cutvar) {
+// Lp, Rp: scratch for last - first + 1 positions each (P = uint16_t: n < 65536, the two counts travel in one scanned
+// word; P = uint32_t: any n, two scans); *cutvar: one shared word.  Returns the cut.
+template <class X, class T, class KeyOf, class P>
+STLEMU_HD int hoare_round_parallel(X &x, T *v, int first, int last, KeyOf key_of, P *Lp, P *Rp, int *cutvar) {
   const int tid = x.tid(), nt = x.nt();
+  constexpr bool wide = sizeof(P) > 2;
   auto before = [&](const T &a, const T &b) { return key_of(a) > key_of(b); };
   if (tid == 0) median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
   x.sync();
   const int lo = first + 1, m = last - lo;
   const auto kp = key_of(v[first]);
   const int chunk = (m + nt - 1) / nt, i0 = tid * chunk < m ? tid * chunk : m, i1 = i0 + chunk < m ? i0 + chunk : m;
-  uint32_t mine = 0;  // #left stops | #right stops << 16
+  uint32_t mineL = 0, mineR = 0;  // #left stops, #right stops of this thread's stretch
   for (int i = i0; i < i1; ++i) {
     const auto k = key_of(v[lo + i]);
-    mine += (k <= kp ? 1u : 0u) + (k >= kp ? 0x10000u : 0u);
+    mineL += k <= kp ? 1u : 0u;
+    mineR += k >= kp ? 1u : 0u;
   }
-  uint32_t run, tot;
-  x.block_scan_u32(mine, &run, &tot);
-  const int nL = (int)(tot & 0xFFFFu), nR = (int)(tot >> 16);
+  uint32_t runL, runR;
+  int nL, nR;
+  if (wide) {
+    uint32_t totL, totR;
+    x.block_scan_u32(mineL, &runL, &totL);
+    x.block_scan_u32(mineR, &runR, &totR);
+    nL = (int)totL; nR = (int)totR;
+  } else {
+    uint32_t run, tot;
+    x.block_scan_u32(mineL | (mineR << 16), &run, &tot);
+    runL = run & 0xFFFFu; runR = run >> 16;
+    nL = (int)(tot & 0xFFFFu); nR = (int)(tot >> 16);
+  }
   for (int i = i0; i < i1; ++i) {
     const auto k = key_of(v[lo + i]);
-    if (k <= kp) { Lp[run & 0xFFFFu] = (uint16_t)(lo + i); run += 1u; }
-    if (k >= kp) { Rp[nR - 1 - (int)(run >> 16)] = (uint16_t)(lo + i); run += 0x10000u; }
+    if (k <= kp) { Lp[runL] = (P)(lo + i); runL += 1u; }
+    if (k >= kp) { Rp[nR - 1 - (int)runR] = (P)(lo + i); runR += 1u; }
   }
-  if (tid == 0) Rp[nR] = (uint16_t)first;  // the pivot itself stops the right-to-left scan
+  if (tid == 0) Rp[nR] = (P)first;  // the pivot itself stops the right-to-left scan
   x.sync();
   // Iteration t of the serial loop stops its left scan at min(Lp[t], Rp[t-1]) (the element swapped into Rp[t-1] is itself
   // a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
@@ -336,7 +349,7 @@ STLEMU_HD int hoare_round_parallel(X &x, T *v, int first, int last, KeyOf key_of
       exch(v, (int)Lp[t], (int)Rp[t]);
     } else if (t == 0 || !crossed(t - 1)) {
       int c = t < nL ? (int)Lp[t] : 0x7fffffff;
-      if (t > 0 && (int)Rp[t - 1] < c) c = Rp[t - 1];
+      if (t > 0 && (int)Rp[t - 1] < c) c = (int)Rp[t - 1];
       *cutvar = c;
     }
   }

@@ -282,8 +282,8 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
     size_t far_bytes = 0;
     const bool big = getenv("CTC_HOST_BIG") != nullptr;  // exercise the HBM-scratch layouts too (CTC_HOST_BIG=1 or 2)
     const bool farrep = !big && getenv("CTC_HOST_FARREP") != nullptr;  // ... and the layout whose replay scratch alone is "far"
-    const int flevel = big && getenv("CTC_HOST_BIG")[0] == '2' ? 2 : 1;
-    std::vector<char> mem((farrep ? carve<0, true>(w, nullptr, nullptr, d, &far_bytes) : !big ? carve<0>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
+    const int flevel = big ? getenv("CTC_HOST_BIG")[0] - '0' : 1;  // 1, 2, 3 (3: 32-bit slot indices)
+    std::vector<char> mem((farrep ? carve<0, true>(w, nullptr, nullptr, d, &far_bytes) : !big ? carve<0>(w, nullptr, nullptr, d, &far_bytes) : flevel == 3 ? carve<3>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
                                                                                    : carve<1>(w, nullptr, nullptr, d, &far_bytes)) + 64);
     std::vector<char> far(far_bytes + 64);
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
@@ -297,6 +297,7 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
       len = std::max(0, std::min(len, T));
       if (farrep) carve<0, true>(w, mem.data(), far.data(), d, nullptr);
       else if (!big) carve<0>(w, mem.data(), far.data(), d, nullptr);
+      else if (flevel == 3) carve<3>(w, mem.data(), far.data(), d, nullptr);
       else if (flevel == 2) carve<2>(w, mem.data(), far.data(), d, nullptr);
       else carve<1>(w, mem.data(), far.data(), d, nullptr);
       HostX x;
@@ -319,6 +320,11 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
         else st = decode_utterance<true, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+      } else if (big && flevel == 3) {  // ... and the layout for more than 65535 candidate slots (32-bit slot indices)
+        if (pruned) st = decode_utterance<false, false, false, true, true, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
+        else st = decode_utterance<true, false, false, true, true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
       } else if (big) {  // the wide-beam layouts do not store the per-slot info words (LAZY)
         if (pruned) st = decode_utterance<false, false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b);
@@ -362,8 +368,8 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
   Work w;
   size_t far_bytes = 0;
   const bool big = getenv("CTC_HOST_BIG") != nullptr;  // the HBM-scratch layouts (CTC_HOST_BIG=1 or 2), as in decode_impl
-  const int flevel = big && getenv("CTC_HOST_BIG")[0] == '2' ? 2 : 1;
-  std::vector<char> mem((!big ? carve<0>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
+  const int flevel = big ? getenv("CTC_HOST_BIG")[0] - '0' : 1;
+  std::vector<char> mem((!big ? carve<0>(w, nullptr, nullptr, d, &far_bytes) : flevel == 3 ? carve<3>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
                                                                                  : carve<1>(w, nullptr, nullptr, d, &far_bytes)) + 64);
   std::vector<char> far(far_bytes + 64);
   for (int b = 0; b < B; ++b) {
@@ -376,6 +382,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       std::fill(mem.begin(), mem.end(), (char)0x5a);
       std::fill(far.begin(), far.end(), (char)0x5a);
       if (!big) carve<0>(w, mem.data(), far.data(), d, nullptr);
+      else if (flevel == 3) carve<3>(w, mem.data(), far.data(), d, nullptr);
       else if (flevel == 2) carve<2>(w, mem.data(), far.data(), d, nullptr);
       else carve<1>(w, mem.data(), far.data(), d, nullptr);
       HostX x;
@@ -383,7 +390,9 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u};
       int st;
-      if (big) st = decode_utterance<true, false, false, true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo,
+      if (big && flevel == 3) st = decode_utterance<true, false, false, true, true, true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo,
+                                pool.data(), pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss);
+      else if (big) st = decode_utterance<true, false, false, true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo,
                                 pool.data(), pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss);
       else st = decode_utterance<true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo, pool.data(),
                                 pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss);

@@ -371,11 +371,40 @@ def test_time_steps_beyond_16_bits(torch_mod):
     ou.assert_same(_with_nres(got, want), want, "T > 65536, streamed")
 
 
+@pytest.mark.parametrize("V,K,T,top_n,quant", [(700, 100, 20, 700, None), (1200, 60, 15, 1200, 0.5), (900, 120, 25, 900, 1.0), (2000, 40, 30, 5000, None)])
+def test_more_than_65535_candidate_slots(torch_mod, V, K, T, top_n, quant):
+    """cutoff_top_n >= V with hundreds to thousands of labels: beam * (V + 2) candidate slots exceed 16 bits (70 k - 108 k
+    here).  Workspace level 3: 32-bit slot indices in the exact replay's arrays, every per-slot array in HBM scratch.  Coarse
+    values (quant) make most frames tie at the beam boundary -> exact std::nth_element replays over 100 k elements."""
+    import ctcdecode_amd
+
+    assert K * (min(V, top_n) + 2) > 65535
+    lp = ou.synth_logprobs(2, T, V, 1000 + V, quant=quant)
+    sl = np.array([T, T // 2], np.int32)
+    want = ou.decode(lp, sl, beam=K, cutoff_top_n=top_n)
+    got = _decode(torch_mod, lp, sl, beam=K, cutoff_top_n=top_n)
+    ou.assert_same(_with_nres(got, want), want, "V=%d K=%d" % (V, K))
+    # the same, streamed in three chunks
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=top_n, beam_width=K, blank_id=0, log_probs_input=True)
+    states = [ctcdecode_amd.DecoderState(dec) for _ in range(2)]
+    x = torch_mod.from_numpy(lp)
+    bounds = [0, 3, T // 2, T]
+    for i in range(3):
+        lo, hi = bounds[i], bounds[i + 1]
+        out, sc, ts, ln = dec.decode(x[:, lo:hi], states, [i == 2] * 2, seq_lens=torch_mod.from_numpy(np.clip(sl - lo, 0, hi - lo).astype(np.int32)))
+    g2 = dict(tokens=np.zeros((2, K, T), np.int32), timesteps=np.zeros((2, K, T), np.int32), scores=sc.numpy(), lens=ln.numpy())
+    g2["tokens"][:, : out.shape[1], : out.shape[2]] = out.numpy()
+    g2["timesteps"][:, : out.shape[1], : out.shape[2]] = ts.numpy()
+    ou.assert_same(_with_nres(g2, want), want, "V=%d K=%d streamed" % (V, K))
+
+
 def test_capability_boundaries(torch_mod):
     """Every CTCD_EUNSUPPORTED edge of the no-LM path: on the supported side of a limit the call decodes
     and matches the oracle; one step beyond, it raises NotImplementedError -- cleanly: the same decoder object then decodes
-    an ordinary batch correctly.  The limits: K * (candidates + 2) <= 65535 slots, beam_width <= 16383, labels <= 65534
-    (<= 32767 when pruning), one workgroup's LDS (beam ~1100 at V=29), compact results T <= 65536."""
+    an ordinary batch correctly.  The limits: beam_width <= 16383, labels <= 65534 (<= 32767 when pruning), one workgroup's
+    LDS (beam ~1100 at V=29), K * (candidates + 2) <= 16 777 215 slots.  Up to 65535 slots the ordinary layouts apply;
+    beyond (cutoff_top_n >= V with thousands of labels: round 2 refused these) the layout with 32-bit slot indices and
+    everything per slot in HBM scratch takes over -- slowly, as the reference is at such shapes (decoder_utils.cpp:33-35)."""
     import ctcdecode_amd
 
     def dec_for(V, K, top_n=40, cutoff_prob=1.0):
@@ -398,13 +427,15 @@ def test_capability_boundaries(torch_mod):
         # the refusal left the decoder usable: a second, supported call on the same library state decodes correctly
         check(29, 10, 40)
 
-    # candidate slots: K * (min(V, top_n) + 2) <= 65535
+    # candidate slots: K * (min(V, top_n) + 2); 65535 is where the 32-bit-slot layout takes over
     check(1000, 65, 1000)              # 65 * 1002 = 65130 slots, no pruning (cutoff_top_n >= V)
-    refused(1000, 66, 1000)            # 66 * 1002 = 66132
+    check(1000, 66, 1000)              # 66 * 1002 = 66132: workspace level 3
     check(300, 200, 300, T=8)          # 200 * 302 = 60400
-    refused(300, 220, 300)             # 66440
+    check(300, 220, 300, T=8)          # 66440
     check(2000, 100, 600, T=8)         # pruned: 100 * 602 = 60200
-    refused(2000, 110, 600)            # 66220
+    check(2000, 110, 600, T=8)         # 66220
+    check(3000, 40, 5000, T=10, seed=8)   # 120 080 slots, every label a candidate
+    refused(60000, 300, 60000, T=2)    # 18 000 600 slots
     # the beam's own arrays: beam 1000 fits one workgroup's LDS (test_beam_width_1000), 1400 does not
     refused(29, 1400, 40)
     refused(29, 20000, 40)             # beyond the 14-bit entry index as well
