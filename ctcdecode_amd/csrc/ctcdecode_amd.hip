@@ -1039,7 +1039,6 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   const bool huge = dims.S_max() > 65535;
   if ((long long)beam * (dims.Vc_max + 2) > (1LL << 24) - 1)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) exceeds 16777215 candidate slots");
-  if (huge && scorer) return fail(CTCD_EUNSUPPORTED, "the LM tier is limited to 65535 candidate slots (beam_width * (candidates + 2))");
   if (huge && d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the layout for more than 65535 candidate slots");
   if (dims.use_rank_table && V > 32767) return fail(CTCD_EUNSUPPORTED, "vocabulary pruning with more than 32767 labels");
   Work wtmp;
@@ -1360,7 +1359,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
     if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true, true>;
     // wide beams: the scorer's per-entry state moves to the HBM scratch with the other rare-path arrays (a capability, not a fast path)
-    if (big) fn = far_level == 2 ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false, 0, true>)
+    if (big && far_level == 3) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 3, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 3, 0, false, 0, true>;
+    else if (big) fn = far_level == 2 ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false, 0, true>)
                                  : (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 1, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 1, 0, false, 0, true>);
     if (d->profile && d->tl_armed) {  // (shape conditions checked above)
       if (!fixed) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels");

@@ -308,7 +308,13 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
         for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
       int st;
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u};
-      if (lm && big) {  // wide-beam layouts with the scorer: its per-entry state lives in the HBM scratch, no info words (LAZY)
+      if (lm && big && flevel == 3) {  // ... with 32-bit slot indices
+        const float *rawb = raw + (size_t)b * T * V;
+        if (pruned) st = decode_utterance<false, false, true, true, true, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+        else st = decode_utterance<true, false, true, true, true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+      } else if (lm && big) {  // wide-beam layouts with the scorer: its per-entry state lives in the HBM scratch, no info words (LAZY)
         const float *rawb = raw + (size_t)b * T * V;
         if (pruned) st = decode_utterance<false, false, true, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);

@@ -110,6 +110,21 @@ def test_lm_word_model_over_more_than_64_labels(torch_mod, tmp_path):
         ou.assert_same(_with_nres(got, want), want, "99 labels, case %d" % it)
 
 
+def test_lm_more_than_65535_candidate_slots(torch_mod, tmp_path):
+    """The 99-label word model at beam 700 / 900: 70 700 / 90 900 candidate slots -- workspace level 3 with a scorer."""
+    from test_lm import make_wide_label_lm, wide_label_inputs
+
+    path, labels = make_wide_label_lm(tmp_path)
+    lm = dict(labels=labels, lm_path=path, alpha=0.7, beta=0.5)
+    sc = ou.Scorer(0.7, 0.5, path, labels, "restated")
+    for K, T in ((700, 15), (900, 10)):
+        lp = wide_label_inputs(3, T, len(labels))
+        kw = dict(beam=K, cutoff_top_n=99, blank_id=0)
+        want = ou.decode(lp, scorer=sc, **kw)
+        got, _ = _decode(torch_mod, lp, lm, **kw)
+        ou.assert_same(_with_nres(got, want), want, "99 labels, beam %d" % K)
+
+
 def test_lm_degenerate_inputs(torch_mod):
     """Whole frames of -inf / overflowing sums with the scorer: contributions in the order of the frame's
     std::sort (ctc_beam_search_decoder.cpp:75-76)."""
