@@ -846,6 +846,7 @@ struct ctcd_decoder {
   bool tl_armed = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // decode kernel | vocabulary-prune pass
   bool prune_timed = false;
+  hipEvent_t lab_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // label chunks of decode_to_host have arrived
   hipStream_t last_stream = nullptr;  // the stream of the last decode launch (ctcd_check_status reads the status words on it)
   std::mutex mu;
   std::mutex mu_host;  // the host-tensor entry points: compact buffers, page-locked staging and the worker threads are per decoder
@@ -993,6 +994,7 @@ int ctcd_create(ctcd_decoder **out, int device_id) {
 void ctcd_destroy(ctcd_decoder *d) {
   if (!d) return;
   DeviceGuard guard_(d->device);
+  for (auto &e : d->lab_ev) if (e) (void)hipEventDestroy(e);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->ev3); }
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->lsm.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
@@ -1674,18 +1676,51 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
     hs = (char *)d->h_stage;
     std::memcpy(hs, keep.data(), o_lab);
   }
-  if (nlab) HIP_TRY(hipMemcpyAsync(hs + o_lab, d->c_rag.p, nlab * 4, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
+  // The labels cross PCIe in a few chunks, each followed by an event, and the expansion of an utterance starts as soon as
+  // the chunk that holds the end of its labels has arrived (an utterance's labels are one contiguous stretch of the
+  // buffer): the copy of chunk i+1 overlaps the expansion of the utterances of chunk i.
+  constexpr int kChunks = 8;
+  if (!d->lab_ev[0])
+    for (int c = 0; c < kChunks; ++c) HIP_TRY(hipEventCreateWithFlags(&d->lab_ev[c], hipEventDisableTiming));
+  const size_t per = nlab ? (nlab + kChunks - 1) / kChunks : 0;
+  int nchunks = 0;
+  for (size_t lo = 0; lo < nlab; lo += per, ++nchunks) {
+    const size_t n = std::min(per, nlab - lo);
+    HIP_TRY(hipMemcpyAsync(hs + o_lab + lo * 4, (const char *)d->c_rag.p + lo * 4, n * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(d->lab_ev[nchunks], stream));
+  }
   if (!d->workers) {
     d->workers = new HostPool;
-    // host threads that expand the results: at least 16 (memory-bound work; the reference's default num_processes = 4 was
-    // chosen for its CPU decode), more if the caller asks, never more than the machine has
-    const int want = std::max(num_processes, 16);
-    d->workers->start(std::max(1, std::min({want, (int)std::thread::hardware_concurrency(), 64})));
+    // host threads that expand the results (memory-bound work: 8 bytes written per label position of the padded tensors;
+    // the reference's default num_processes = 4 was chosen for its CPU decode): one per 4 MB of output, between 16 and 64,
+    // more if the caller asks, never more than the machine has
+    const long long out_mb = (long long)B * beam * T * 8 >> 20;
+    const int want = std::max<long long>(num_processes, std::min<long long>(64, std::max<long long>(16, out_mb / 4)));
+    d->workers->start(std::max(1, std::min(want, (int)std::thread::hardware_concurrency())));
   }
   const int32_t *hh = (const int32_t *)(hs + o_hdr), *he = (const int32_t *)(hs + o_ent);
   const uint32_t *hl = (const uint32_t *)(hs + o_lab);
-  d->workers->run(B, [=](int b) { ctcbeam::expand_item_host(hh, he, hl, b, beam, T, out_tok, out_ts); });
+  // utterances in the order their labels arrive (by the end of their stretch)
+  std::vector<int> order(B);
+  for (int b = 0; b < B; ++b) order[b] = b;
+  auto end_of = [hh](int b) { return (unsigned)hh[(size_t)b * 4 + 2] + (unsigned)hh[(size_t)b * 4 + 1]; };
+  std::sort(order.begin(), order.end(), [&](int a, int c) { return end_of(a) < end_of(c); });
+  const int *ord = order.data();
+  hipEvent_t *evs = d->lab_ev;
+  const int dev = d->device;
+  std::atomic<int> bad{0};
+  d->workers->run(B, [=, &bad](int i) {
+    const int b = ord[i];
+    const unsigned cnt = (unsigned)hh[(size_t)b * 4 + 1];
+    if (cnt && per) {
+      const int c = (int)(((size_t)end_of(b) - 1) / per);
+      (void)hipSetDevice(dev);
+      if (hipEventSynchronize(evs[c < nchunks ? c : nchunks - 1]) != hipSuccess) bad = 1;
+    }
+    ctcbeam::expand_item_host(hh, he, hl, b, beam, T, out_tok, out_ts);
+  });
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (bad) return fail(CTCD_EHIP, "waiting for the results to cross PCIe failed");
   return CTCD_OK;
 }
 
