@@ -332,6 +332,13 @@ struct OutRefs {
   uint32_t *c_rag;
   unsigned *c_count;
   unsigned c_cap;
+  // Mirrors in page-locked HOST memory (device-visible addresses; null: none): an utterance that has finished copies its
+  // compact results there itself -- coalesced stores over PCIe while other utterances are still being decoded -- and then
+  // raises m_done[item] (1: mirrored; 2: its labels did not fit the mirror, fetch them from c_rag), so that the host can
+  // expand utterance by utterance without waiting for the kernel to end (ctcd_beam_decode_to_host).
+  int32_t *m_hdr, *m_ent, *m_done;
+  uint32_t *m_rag;
+  unsigned m_cap;
 };
 enum : int { ST_COMPACT_OVERFLOW = 3 };
 
@@ -1615,6 +1622,7 @@ struct Decoder {
     x.mark(4);
     const bool compact = o.c_hdr != nullptr;
     unsigned cbase = 0;
+    uint32_t ctotal = 0;
     if (compact) {
       for (int j = tid; j < nres; j += nt) {
         const int lo = b.lcp[j] > 0 ? b.lcp[j] : 0;
@@ -1626,6 +1634,7 @@ struct Decoder {
       if (tid == 0) w.vars[VAR_CUT] = (int)x.global_add(o.c_count, total);
       x.sync();
       cbase = (unsigned)x.uni(w.vars[VAR_CUT]);
+      ctotal = total;
       const bool fits = cbase + total <= o.c_cap && cbase + total >= cbase;
       if (tid == 0) {
         int32_t *h = o.c_hdr + (size_t)item * 4;
@@ -1676,7 +1685,23 @@ struct Decoder {
         --dd;
       }
     }
-    if (compact) return ST_OK;
+    if (compact) {
+      if (o.m_done) {  // hand the finished utterance to the host right away
+        x.sync_full();  // (its labels are complete in c_rag)
+        const bool mirror = cbase + ctotal <= o.m_cap;
+        if (mirror) {
+          for (uint32_t i = (uint32_t)tid; i < ctotal; i += (uint32_t)nt) o.m_rag[cbase + i] = o.c_rag[cbase + i];
+          const int32_t *es = o.c_ent + (size_t)item * o.K * 4;
+          int32_t *ed = o.m_ent + (size_t)item * o.K * 4;
+          for (int i = tid; i < nres * 4; i += nt) ed[i] = es[i];
+          if (tid < 4) o.m_hdr[(size_t)item * 4 + tid] = o.c_hdr[(size_t)item * 4 + tid];
+        }
+        x.fence_system();
+        x.sync_full();
+        if (tid == 0) x.store_system(&o.m_done[item], mirror ? 1 : 2);
+      }
+      return ST_OK;
+    }
     x.sync_full();  // rows are read back below by other waves
     x.mark(15);
     const int grp = x.group(), ngr = x.ngroups(), lane = x.lane(), lanes = x.lanes();

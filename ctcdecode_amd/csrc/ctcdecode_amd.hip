@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -879,6 +880,10 @@ struct CompactOut {          // compact result delivery (beam_core.h OutRefs::c_
   uint32_t *rag;
   unsigned *count;
   unsigned cap;
+  // mirrors in page-locked host memory the kernel writes a finished utterance's results to (OutRefs::m_*); null: none
+  int32_t *m_hdr = nullptr, *m_ent = nullptr, *m_done = nullptr;
+  uint32_t *m_rag = nullptr;
+  unsigned m_cap = 0;
 };
 
 struct StreamCall {          // extra arguments of a streaming decode
@@ -1291,9 +1296,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   a.outs.tok = out_tok; a.outs.ts = out_ts; a.outs.len = out_len; a.outs.n_results = n_results; a.outs.score = out_sc;
   a.outs.K = beam; a.outs.T_stride = out_T;
   a.outs.c_hdr = nullptr; a.outs.c_ent = nullptr; a.outs.c_rag = nullptr; a.outs.c_count = nullptr; a.outs.c_cap = 0;
+  a.outs.m_hdr = nullptr; a.outs.m_ent = nullptr; a.outs.m_done = nullptr; a.outs.m_rag = nullptr; a.outs.m_cap = 0;
   if (co) {
     a.outs.tok = nullptr; a.outs.ts = nullptr;
     a.outs.c_hdr = co->hdr; a.outs.c_ent = co->ent; a.outs.c_rag = co->rag; a.outs.c_count = co->count; a.outs.c_cap = co->cap;
+    a.outs.m_hdr = co->m_hdr; a.outs.m_ent = co->m_ent; a.outs.m_done = co->m_done; a.outs.m_rag = co->m_rag; a.outs.m_cap = co->m_cap;
   }
   a.status = (int32_t *)d->status.p;
   a.st_base = st_base; a.st_poolcap = st_cap; a.st_eos = st_eos; a.st_pool_off = (long long)stream_pool_offset(beam);
@@ -1641,54 +1648,36 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
       (rc = d->c_cnt.ensure(256)) || (rc = d->c_sc.ensure(kk * 4)) || (rc = d->c_ln.ensure(kk * 4 + (size_t)B * 4)))
     return rc;
   int32_t *d_nres = (int32_t *)((char *)d->c_ln.p + kk * 4);
-  CompactOut co{(int32_t *)d->c_hdr.p, (int32_t *)d->c_ent.p, (uint32_t *)d->c_rag.p, (unsigned *)d->c_cnt.p, (unsigned)cap};
-  rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, (float *)d->c_sc.p,
-                     (int32_t *)d->c_ln.p, d_nres, stream, nullptr, scorer, &co);
-  if (rc) return rc;
-  // page-locked staging: [count | hdr | ent | labels]
-  const size_t o_hdr = 256, o_ent = o_hdr + (size_t)B * 16, o_lab = (o_ent + kk * 16 + 255) / 256 * 256;
-  const size_t first = o_lab;
-  size_t need = o_lab + (size_t)64 * 1024 * 1024 / 4;  // grown below when the labels need more
-  if (d->h_stage_cap < first + 4096) {
+  // Page-locked, device-visible staging the KERNEL writes to: [done flags | hdr | ent | labels].  A workgroup that has
+  // finished its utterance copies the compact results there itself and raises the utterance's flag (beam_core.h
+  // OutRefs::m_*): the results cross PCIe while the stragglers of the launch are still being decoded, and host threads
+  // expand utterance after utterance as the flags come up -- when the kernel ends only its last utterances are left.
+  const size_t o_done = 256, o_hdr = (o_done + (size_t)B * 4 + 255) / 256 * 256, o_ent = o_hdr + (size_t)B * 16,
+               o_lab = (o_ent + kk * 16 + 255) / 256 * 256;
+  // the mirror holds a third of the worst case (typical sharing: a tenth); an utterance whose labels fall beyond it is
+  // fetched from the device buffer afterwards
+  const size_t mcap = std::max<size_t>((size_t)1 << 20, (size_t)cap / 3);
+  const size_t need = o_lab + mcap * 4;
+  if (d->h_stage_cap < need) {
     if (d->h_stage) (void)hipHostFree(d->h_stage);
     d->h_stage = nullptr;
     d->h_stage_cap = 0;
-    HIP_TRY(hipHostMalloc(&d->h_stage, need, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&d->h_stage, need, hipHostMallocMapped | hipHostMallocCoherent));
     d->h_stage_cap = need;
   }
-  char *hs = (char *)d->h_stage;
-  HIP_TRY(hipMemcpyAsync(hs, d->c_cnt.p, 4, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipMemcpyAsync(hs + o_hdr, d->c_hdr.p, (size_t)B * 16, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipMemcpyAsync(hs + o_ent, d->c_ent.p, kk * 16, hipMemcpyDeviceToHost, stream));
+  char *hs = (char *)d->h_stage, *ds = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void **)&ds, d->h_stage, 0));
+  volatile int32_t *done = (volatile int32_t *)(hs + o_done);
+  for (int b = 0; b < B; ++b) done[b] = 0;
+  CompactOut co{(int32_t *)d->c_hdr.p, (int32_t *)d->c_ent.p, (uint32_t *)d->c_rag.p, (unsigned *)d->c_cnt.p, (unsigned)cap};
+  co.m_hdr = (int32_t *)(ds + o_hdr); co.m_ent = (int32_t *)(ds + o_ent); co.m_done = (int32_t *)(ds + o_done);
+  co.m_rag = (uint32_t *)(ds + o_lab); co.m_cap = (unsigned)std::min<size_t>(mcap, 0xFFFFFFFFu);
+  rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, (float *)d->c_sc.p,
+                     (int32_t *)d->c_ln.p, d_nres, stream, nullptr, scorer, &co);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(out_sc, d->c_sc.p, kk * 4, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(out_len, d->c_ln.p, kk * 4, hipMemcpyDeviceToHost, stream));
   if (n_results) HIP_TRY(hipMemcpyAsync(n_results, d_nres, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
-  if ((rc = ctcd_check_status(d, B))) return rc;  // (synchronises the stream)
-  const size_t nlab = *(const unsigned *)hs;
-  if (o_lab + nlab * 4 > d->h_stage_cap) {  // rare: more unshared labels than the staging block holds -- take a bigger one
-    std::vector<char> keep(hs, hs + o_lab);
-    (void)hipHostFree(d->h_stage);
-    d->h_stage = nullptr;
-    d->h_stage_cap = 0;
-    need = o_lab + nlab * 4 + (nlab * 4) / 4;
-    HIP_TRY(hipHostMalloc(&d->h_stage, need, hipHostMallocDefault));
-    d->h_stage_cap = need;
-    hs = (char *)d->h_stage;
-    std::memcpy(hs, keep.data(), o_lab);
-  }
-  // The labels cross PCIe in a few chunks, each followed by an event, and the expansion of an utterance starts as soon as
-  // the chunk that holds the end of its labels has arrived (an utterance's labels are one contiguous stretch of the
-  // buffer): the copy of chunk i+1 overlaps the expansion of the utterances of chunk i.
-  constexpr int kChunks = 8;
-  if (!d->lab_ev[0])
-    for (int c = 0; c < kChunks; ++c) HIP_TRY(hipEventCreateWithFlags(&d->lab_ev[c], hipEventDisableTiming));
-  const size_t per = nlab ? (nlab + kChunks - 1) / kChunks : 0;
-  int nchunks = 0;
-  for (size_t lo = 0; lo < nlab; lo += per, ++nchunks) {
-    const size_t n = std::min(per, nlab - lo);
-    HIP_TRY(hipMemcpyAsync(hs + o_lab + lo * 4, (const char *)d->c_rag.p + lo * 4, n * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(d->lab_ev[nchunks], stream));
-  }
   if (!d->workers) {
     d->workers = new HostPool;
     // host threads that expand the results (memory-bound work: 8 bytes written per label position of the padded tensors;
@@ -1700,27 +1689,47 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
   }
   const int32_t *hh = (const int32_t *)(hs + o_hdr), *he = (const int32_t *)(hs + o_ent);
   const uint32_t *hl = (const uint32_t *)(hs + o_lab);
-  // utterances in the order their labels arrive (by the end of their stretch)
-  std::vector<int> order(B);
-  for (int b = 0; b < B; ++b) order[b] = b;
-  auto end_of = [hh](int b) { return (unsigned)hh[(size_t)b * 4 + 2] + (unsigned)hh[(size_t)b * 4 + 1]; };
-  std::sort(order.begin(), order.end(), [&](int a, int c) { return end_of(a) < end_of(c); });
-  const int *ord = order.data();
-  hipEvent_t *evs = d->lab_ev;
+  std::atomic<int> finished{0}, sync_rc{0};
+  std::mutex late_mu;
+  std::vector<int> late;  // utterances the kernel did not mirror (labels beyond the mirror) -- or that never reported
   const int dev = d->device;
-  std::atomic<int> bad{0};
-  d->workers->run(B, [=, &bad](int i) {
-    const int b = ord[i];
-    const unsigned cnt = (unsigned)hh[(size_t)b * 4 + 1];
-    if (cnt && per) {
-      const int c = (int)(((size_t)end_of(b) - 1) / per);
+  // job 0 waits for the stream (kernel + the small copies above) and tells the others; jobs 1 .. B expand utterance i - 1
+  // as soon as its flag is up
+  d->workers->run(B + 1, [&, hh, he, hl, done, dev, stream](int i) {
+    if (i == 0) {
       (void)hipSetDevice(dev);
-      if (hipEventSynchronize(evs[c < nchunks ? c : nchunks - 1]) != hipSuccess) bad = 1;
+      if (hipStreamSynchronize(stream) != hipSuccess) sync_rc = 1;
+      finished = 1;
+      return;
     }
-    ctcbeam::expand_item_host(hh, he, hl, b, beam, T, out_tok, out_ts);
+    const int b = i - 1;
+    int v;
+    for (int spin = 0; (v = done[b]) == 0 && !finished.load(std::memory_order_acquire); ++spin)
+      if (spin > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    if (v == 0) v = done[b];  // (the kernel has ended: whatever it wrote is visible)
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (v == 1) {
+      ctcbeam::expand_item_host(hh, he, hl, b, beam, T, out_tok, out_ts);
+    } else {
+      std::lock_guard<std::mutex> g(late_mu);
+      late.push_back(b);
+    }
   });
-  HIP_TRY(hipStreamSynchronize(stream));
-  if (bad) return fail(CTCD_EHIP, "waiting for the results to cross PCIe failed");
+  if (sync_rc) return fail(CTCD_EHIP, "hipStreamSynchronize failed");
+  if ((rc = ctcd_check_status(d, B))) return rc;
+  if (!late.empty()) {  // rare: fetch the whole compact form from the device and expand the utterances left
+    std::vector<int32_t> fh((size_t)B * 4), fe(kk * 4);
+    unsigned nlab = 0;
+    HIP_TRY(hipMemcpy(&nlab, d->c_cnt.p, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> fl(nlab ? nlab : 1);
+    HIP_TRY(hipMemcpy(fh.data(), d->c_hdr.p, (size_t)B * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fe.data(), d->c_ent.p, kk * 16, hipMemcpyDeviceToHost));
+    if (nlab) HIP_TRY(hipMemcpy(fl.data(), d->c_rag.p, (size_t)nlab * 4, hipMemcpyDeviceToHost));
+    const int *lt = late.data();
+    const int32_t *ph = fh.data(), *pe = fe.data();
+    const uint32_t *pl = fl.data();
+    d->workers->run((int)late.size(), [=](int i) { ctcbeam::expand_item_host(ph, pe, pl, lt[i], beam, T, out_tok, out_ts); });
+  }
   return CTCD_OK;
 }
 

@@ -145,6 +145,9 @@ struct DevX {
     return n;
   }
   __device__ __forceinline__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+  // results mirrored into host memory: make this thread's stores visible system-wide / publish a flag there
+  __device__ __forceinline__ void fence_system() const { __threadfence_system(); }
+  __device__ __forceinline__ void store_system(int32_t *p, int v) const { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
   // sum over the aligned group of eight lanes this lane belongs to (every lane of the wave must call it)
   __device__ __forceinline__ int sum8(int v) const {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);

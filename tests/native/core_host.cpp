@@ -58,6 +58,8 @@ struct HostX {
   int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
   void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
   int sum8(int v) const { return v; }
+  void fence_system() const {}
+  void store_system(int32_t *p, int v) const { *p = v; }
   void wave_add(int *p, int v) { *p += v; }
   void find_bucket(int *bins, int need, int *out) {
     using ctcbeam::kBins;
@@ -235,6 +237,9 @@ extern "C" int ctccore_decode_compact_f32(const float *probs, const int32_t *seq
   std::vector<char> far(far_bytes + 64);  // (the exact replay's scratch: HBM on the device)
   std::vector<int32_t> hdr((size_t)B * 4, 0), ent((size_t)B * beam * 4, 0);
   std::vector<uint32_t> rag((size_t)B * beam * T + 1);
+  // the host mirrors a finished utterance copies its results into (OutRefs::m_*): the expansion below reads THEM
+  std::vector<int32_t> m_hdr((size_t)B * 4, -7), m_ent((size_t)B * beam * 4, -7), m_done((size_t)B, 0);
+  std::vector<uint32_t> m_rag(rag.size(), 0xDEADBEEFu);
   unsigned count = 0;
   for (int b = 0; b < B; ++b) {
     std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
@@ -243,12 +248,16 @@ extern "C" int ctccore_decode_compact_f32(const float *probs, const int32_t *seq
     len = std::max(0, std::min(len, T));
     carve<0>(w, mem.data(), far.data(), d, nullptr);
     HostX x;
-    const OutRefs outs{nullptr, nullptr, out_scores, out_lens, n_results, beam, T, hdr.data(), ent.data(), rag.data(), &count, (unsigned)(rag.size() - 1)};
+    const OutRefs outs{nullptr, nullptr, out_scores, out_lens, n_results, beam, T, hdr.data(), ent.data(), rag.data(), &count, (unsigned)(rag.size() - 1),
+                       m_hdr.data(), m_ent.data(), m_done.data(), m_rag.data(), (unsigned)(rag.size() - 1)};
     int st = decode_utterance<true>(x, w, d, blank_id, probs + (size_t)b * T * V, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(),
                                     (int)pool.size(), ctcmath::host_tables().w, &outs, b);
     if (st != ST_OK) return -st;
   }
-  for (int b = 0; b < B; ++b) expand_item_host(hdr.data(), ent.data(), rag.data(), b, beam, T, out_tokens, out_timesteps);
+  for (int b = 0; b < B; ++b) {
+    if (m_done[b] != 1) return -90;
+    expand_item_host(m_hdr.data(), m_ent.data(), m_rag.data(), b, beam, T, out_tokens, out_timesteps);
+  }
   if (labels_used) *labels_used = count;
   return 1;
 }
@@ -307,7 +316,7 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
       if (pruned)
         for (int t = 0; t < len; ++t) prune_row(rows + (size_t)t * V, V, cutoff_prob, cutoff_top_n, &pcnt[t], &pch[(size_t)t * d.Vc_max], &plp[(size_t)t * d.Vc_max]);
       int st;
-      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u};
+      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, 0u};
       if (lm && big && flevel == 3) {  // ... with 32-bit slot indices
         const float *rawb = raw + (size_t)b * T * V;
         if (pruned) st = decode_utterance<false, false, true, true, true, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
@@ -394,7 +403,7 @@ extern "C" int ctccore_decode_chunked_f32(const float *probs, int B, int T, int 
       HostX x;
       x.far_ = big;
       StreamState ss{hdr.data(), arrays.data(), c == nchunks - 1 ? 1 : 0};
-      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u};
+      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, 0u};
       int st;
       if (big && flevel == 3) st = decode_utterance<true, false, false, true, true, true>(x, w, d, blank_id, probs + ((size_t)b * T + lo) * V, (const PrunedRows *)nullptr, hi - lo,
                                 pool.data(), pool_up.data(), (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss);
