@@ -137,6 +137,7 @@ struct Dims {
 // the step after next without racing with threads that still read this one.
 enum {
   VAR_STATUS = 0, VAR_CUT, VAR_TAUC,
+  VAR_INTO,  // the input rows did not arrive in time (streamed input, decode_utterance)
   VAR_FB0 = 4, VAR_FB1, VAR_FB2, VAR_FB3,   // 16-byte aligned groups: read back with one LDS access (X::uni4)
   VAR_TAU = 8, VAR_G, VAR_E,
   VAR_DANGER,  // sticky: this utterance has seen a log-probability that can make log_sum_exp depend on the order of its
@@ -340,7 +341,7 @@ struct OutRefs {
   uint32_t *m_rag;
   unsigned m_cap;
 };
-enum : int { ST_COMPACT_OVERFLOW = 3 };
+enum : int { ST_COMPACT_OVERFLOW = 3, ST_INPUT_TIMEOUT = 4 };
 
 // What it takes to name a slot of a frame: the beam the frame started from, its #entries, #non-blank candidates (and the
 // multiplier that divides by it), the blank's rank; the layout itself is in w.ostart / w.cstart / w.anc.
@@ -616,6 +617,7 @@ struct Decoder {
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
       w.vars[VAR_DANGER] = lm_params_extreme() ? 1 : 0;
+      w.vars[VAR_INTO] = 0;
       w.apos[0] = 0; w.fin[0] = 0;
     }
     st_n = 1; st_pool = 1; st_wlog = 32;  // first select looks at the whole key range
@@ -656,6 +658,7 @@ struct Decoder {
       reset_pvars(pvars(0));
       reset_pvars(pvars(1));
       w.vars[VAR_DANGER] = ss.hdr[SH_DANGER];
+      w.vars[VAR_INTO] = 0;
     }
     for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
     for (int i = tid; i < 2 * K; i += nt) { w.hit[i] = 0; w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
@@ -1748,7 +1751,7 @@ template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, b
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr, const ctclm::LmView *lm = nullptr, const float *raw = nullptr,
-                            int raw_log = 1) {
+                            int raw_log = 1, const int *frames_ready = nullptr) {
   if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
   Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
@@ -1761,11 +1764,27 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   const bool prefetch = width <= nt;
   float pre_lp = 0.f;
   int pre_ch = 0, pre_cnt = 0;
+  // Streamed input (frames_ready != null; identity mode with prefetch only): the rows are still crossing PCIe, frame block
+  // by frame block, while this kernel runs; *frames_ready (uncached memory, written by the copy stream behind every
+  // block) says how many frames of every utterance have arrived.  The threads that fetch a row wait for it -- once per
+  // block; a wait that lasts absurdly long gives up (status ST_INPUT_TIMEOUT) rather than hang the GPU.
+  int ready_cached = 0;
+  auto wait_frames = [&](int need) {
+    if (frames_ready != nullptr && need > ready_cached) {
+      for (int spins = 0;; ++spins) {
+        ready_cached = x.load_system(frames_ready);
+        if (ready_cached >= need) break;
+        if (spins > (1 << 20)) { w.vars[VAR_INTO] = 1; break; }  // (~1 s)
+        x.nap();
+      }
+    }
+  };
   if (prefetch && len > 0) {
     if (!IDENT) {
       pre_cnt = pr->cnt[0];
       if (tid < width) { pre_ch = pr->ch[tid]; pre_lp = pr->lp[tid]; }
     } else if (tid < width) {
+      wait_frames(1);
       pre_lp = rows[tid];
     }
   }
@@ -1794,7 +1813,10 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       if (prefetch) {
         w.clp = w.clpbuf + ((t0 + t) & 1) * d.Vc_max;
         stage = t + 1 < len;
-        if (stage && tid < d.V) pre_lp = rows[(size_t)(t + 1) * d.V + tid];  // consumed at the end of this frame
+        if (stage && tid < d.V) {
+          wait_frames(t + 2);
+          pre_lp = rows[(size_t)(t + 1) * d.V + tid];  // consumed at the end of this frame
+        }
         next_cnt = stage ? d.V : 0;
         next_val = pre_lp;
       } else {
@@ -1850,6 +1872,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   if (!ss || ss->finish) fs = dec.finish(t0 + len > 0, t0 + len, outs, item);
   x.sync();
   x.mark(11);
+  if (frames_ready != nullptr && x.uni(w.vars[VAR_INTO]) != 0) return ST_INPUT_TIMEOUT;
   return fs;
 }
 

@@ -847,7 +847,14 @@ struct ctcd_decoder {
   bool tl_armed = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // decode kernel | vocabulary-prune pass
   bool prune_timed = false;
-  hipEvent_t lab_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // label chunks of decode_to_host have arrived
+  // streamed input of the host-tensor entry point: rows cross PCIe frame block by frame block while the kernel runs
+  void *fg_in = nullptr;          // fine-grained (uncached) device memory: [frames-arrived counter | rows | seq_lens]
+  size_t fg_in_cap = 0;
+  int *h_cnt = nullptr;           // page-locked: the counter values the copy stream writes behind each block
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_in = nullptr;
+  const int *frames_ready_next = nullptr;  // handed to the next decode launch (decode_common clears it)
+  bool no_input_streaming = false;
   hipStream_t last_stream = nullptr;  // the stream of the last decode launch (ctcd_check_status reads the status words on it)
   std::mutex mu;
   std::mutex mu_host;  // the host-tensor entry points: compact buffers, page-locked staging and the worker threads are per decoder
@@ -992,6 +999,7 @@ int ctcd_create(ctcd_decoder **out, int device_id) {
   HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id));
   d->cu_count = v;
   if (const char *e = getenv("CTCD_LDS_FLOOR")) d->lds_floor = atoll(e);
+  if (const char *e = getenv("CTCD_NO_INPUT_STREAMING")) d->no_input_streaming = atoi(e) != 0;
   *out = d;
   return CTCD_OK;
 }
@@ -999,7 +1007,10 @@ int ctcd_create(ctcd_decoder **out, int device_id) {
 void ctcd_destroy(ctcd_decoder *d) {
   if (!d) return;
   DeviceGuard guard_(d->device);
-  for (auto &e : d->lab_ev) if (e) (void)hipEventDestroy(e);
+  if (d->fg_in) (void)hipFree(d->fg_in);
+  if (d->h_cnt) (void)hipHostFree(d->h_cnt);
+  if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
+  if (d->ev_in) (void)hipEventDestroy(d->ev_in);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->ev3); }
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->lsm.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
@@ -1311,6 +1322,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     a.lm.alpha = scorer->host.alpha;  // reset_params (binding.cpp:283-287) takes effect at the next decode
     a.lm.beta = scorer->host.beta;
   }
+  a.frames_ready = d->frames_ready_next;
+  d->frames_ready_next = nullptr;
   a.pr_cnt = nullptr; a.pr_ch = nullptr; a.pr_lp = nullptr; a.pr_stride = 0;
   if (dims.use_rank_table) {
     a.pr_cnt = (const int *)d->pr_cnt.p; a.pr_ch = (const int *)d->pr_ch.p; a.pr_lp = (const float *)d->pr_lp.p;
@@ -1615,7 +1628,40 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
   const size_t nin = (size_t)B * T * V * 4, kk = (size_t)B * beam;
   const float *dprobs = probs;
   const int32_t *dlens = seq_lens;
-  if (!probs_on_device) {
+  // Streamed input: with log-probabilities in host memory and no vocabulary pruning the kernel is launched BEFORE its
+  // input has crossed PCIe; the rows follow frame block by frame block on a second stream (the input is [B, T, V]: a
+  // block is a strided copy), each block followed by an update of the "frames arrived" counter the kernel's row fetch
+  // waits on (beam_core.h decode_utterance).  Hides the 0.5 ms the 30 MB of a configs[1] batch take.
+  const bool pruned_in = cutoff_prob < 1.0 || cutoff_top_n < V;
+  const bool stream_in = !probs_on_device && log_input == 1 && !pruned_in && T >= 128 && T <= 65536 && V <= 512 && nin >= ((size_t)1 << 20) &&
+                         !d->no_input_streaming && !d->profile;
+  int nblk = 0;
+  int blk[10];
+  if (stream_in) {
+    const size_t off_rows = 256, off_sl = off_rows + (nin + 15) / 16 * 16, fg_need = off_sl + (size_t)B * 4 + 16;
+    if (d->fg_in_cap < fg_need) {
+      if (d->fg_in) (void)hipFree(d->fg_in);
+      d->fg_in = nullptr; d->fg_in_cap = 0;
+      HIP_TRY(hipExtMallocWithFlags(&d->fg_in, fg_need, hipDeviceMallocFinegrained));
+      d->fg_in_cap = fg_need;
+    }
+    if (!d->copy_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
+      HIP_TRY(hipHostMalloc((void **)&d->h_cnt, 256, hipHostMallocDefault));
+    }
+    char *fg = (char *)d->fg_in;
+    HIP_TRY(hipMemsetAsync(fg, 0, 4, stream));  // no frame has arrived
+    if (seq_lens) HIP_TRY(hipMemcpyAsync(fg + off_sl, seq_lens, (size_t)B * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(d->ev_in, stream));
+    HIP_TRY(hipStreamWaitEvent(d->copy_stream, d->ev_in, 0));  // (the blocks must not overtake the reset)
+    dprobs = (const float *)(fg + off_rows);
+    dlens = seq_lens ? (const int32_t *)(fg + off_sl) : nullptr;
+    d->frames_ready_next = (const int *)fg;
+    // a small first block, so that the kernel starts at once; the rest in seven equal parts
+    blk[0] = 0; blk[1] = 16; nblk = 1;
+    for (int c = 1; c <= 7; ++c) blk[++nblk] = 16 + (int)((long long)(T - 16) * c / 7);
+  } else if (!probs_on_device) {
     const size_t off_sl = (nin + 15) / 16 * 16;
     if ((rc = d->stage_in.ensure(off_sl + (size_t)B * 4 + 16))) return rc;
     char *din = (char *)d->stage_in.p;
@@ -1674,7 +1720,19 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
   co.m_rag = (uint32_t *)(ds + o_lab); co.m_cap = (unsigned)std::min<size_t>(mcap, 0xFFFFFFFFu);
   rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, (float *)d->c_sc.p,
                      (int32_t *)d->c_ln.p, d_nres, stream, nullptr, scorer, &co);
-  if (rc) return rc;
+  if (rc) { d->frames_ready_next = nullptr; return rc; }
+  if (stream_in) {  // the kernel is queued and waits for its rows: send them, frame block by frame block
+    char *fg = (char *)d->fg_in;
+    const size_t pitch = (size_t)T * V * 4;
+    for (int c = 0; c < nblk; ++c) {
+      const int f0 = blk[c], f1 = blk[c + 1];
+      if (f1 <= f0) continue;
+      HIP_TRY(hipMemcpy2DAsync(fg + 256 + (size_t)f0 * V * 4, pitch, (const char *)probs + (size_t)f0 * V * 4, pitch, (size_t)(f1 - f0) * V * 4, (size_t)B,
+                               hipMemcpyHostToDevice, d->copy_stream));
+      d->h_cnt[c] = f1;
+      HIP_TRY(hipMemcpyAsync(fg, &d->h_cnt[c], 4, hipMemcpyHostToDevice, d->copy_stream));
+    }
+  }
   HIP_TRY(hipMemcpyAsync(out_sc, d->c_sc.p, kk * 4, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(out_len, d->c_ln.p, kk * 4, hipMemcpyDeviceToHost, stream));
   if (n_results) HIP_TRY(hipMemcpyAsync(n_results, d_nres, (size_t)B * 4, hipMemcpyDeviceToHost, stream));

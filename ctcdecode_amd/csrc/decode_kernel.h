@@ -147,6 +147,9 @@ struct DevX {
   __device__ __forceinline__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
   // results mirrored into host memory: make this thread's stores visible system-wide / publish a flag there
   __device__ __forceinline__ void fence_system() const { __threadfence_system(); }
+  // streamed input: a counter another agent (the copy stream) advances in uncached memory; a short pause between two looks
+  __device__ __forceinline__ int load_system(const int *p) const { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  __device__ __forceinline__ void nap() const { __builtin_amdgcn_s_sleep(8); }
   __device__ __forceinline__ void store_system(int32_t *p, int v) const { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
   // sum over the aligned group of eight lanes this lane belongs to (every lane of the wave must call it)
   __device__ __forceinline__ int sum8(int v) const {
@@ -493,6 +496,7 @@ struct KernelArgs {
   ctclm::LmView lm;
   const float *raw;         // [B, T, V] as given by the caller
   int raw_log;              // 1: they are log-probabilities
+  const int *frames_ready;  // streamed input (host-tensor entry point): frames of every utterance that have arrived; null: all
   const int *pr_cnt;        // pruned mode: [B, T] candidates per frame (null in identity mode)
   const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
   const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
@@ -570,7 +574,8 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #endif
   const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM, BIG != 0, BIG != 0 || OCC2, BIG == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
-                                  a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + (size_t)b * a.T * a.V : nullptr, a.raw_log);
+                                  a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + (size_t)b * a.T * a.V : nullptr, a.raw_log,
+                                  PRUNED ? (const int *)nullptr : a.frames_ready);
   if (threadIdx.x == 0) a.status[b] = st;
   if (PROF == 2 && a.tl && b == 0) {
     __syncthreads();

@@ -59,6 +59,8 @@ struct HostX {
   void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
   int sum8(int v) const { return v; }
   void fence_system() const {}
+  int load_system(const int *p) const { return *p; }
+  void nap() const {}
   void store_system(int32_t *p, int v) const { *p = v; }
   void wave_add(int *p, int v) { *p += v; }
   void find_bucket(int *bins, int need, int *out) {
