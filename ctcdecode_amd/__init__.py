@@ -95,6 +95,11 @@ class CTCBeamDecoder(object):
         that keeps several launches in flight; 0: never; -1 (default): when a batch has more utterances than the GPU has CUs."""
         _native.check(_native.lib.ctcd_set_cu_sharing(self._handle, int(mode)))
 
+    def set_host_path(self, input_streaming=None, mirror_cap_labels=None):
+        """Test hook for decode(): turn the streamed input off / on; shrink the host mirror of the compact results."""
+        _native.check(_native.lib.ctcd_debug_set_host_path(self._handle, -1 if input_streaming is None else int(bool(input_streaming)),
+                                                           -2 if mirror_cap_labels is None else int(mirror_cap_labels)))
+
     def set_fixed_layout(self, on=True):
         """Test hook: False forces the run-time workspace layout also for small shapes (identical results)."""
         _native.check(_native.lib.ctcd_debug_set_fixed_layout(self._handle, 1 if on else 0))

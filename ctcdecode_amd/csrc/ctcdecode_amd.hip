@@ -855,6 +855,8 @@ struct ctcd_decoder {
   hipEvent_t ev_in = nullptr;
   const int *frames_ready_next = nullptr;  // handed to the next decode launch (decode_common clears it)
   bool no_input_streaming = false;
+  bool input_timed_out = false;   // set by ctcd_check_status when an utterance reports ST_INPUT_TIMEOUT
+  long long mirror_cap_override = -1;  // tests: labels the host mirror of the compact results holds (-1: a third of the worst case)
   hipStream_t last_stream = nullptr;  // the stream of the last decode launch (ctcd_check_status reads the status words on it)
   std::mutex mu;
   std::mutex mu_host;  // the host-tensor entry points: compact buffers, page-locked staging and the worker threads are per decoder
@@ -1019,6 +1021,13 @@ void ctcd_destroy(ctcd_decoder *d) {
   if (d->h_stage) (void)hipHostFree(d->h_stage);
   delete d->workers;
   delete d;
+}
+
+int ctcd_debug_set_host_path(ctcd_decoder *d, int input_streaming, long long mirror_cap_labels) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  if (input_streaming >= 0) d->no_input_streaming = input_streaming == 0;
+  if (mirror_cap_labels >= -1) d->mirror_cap_override = mirror_cap_labels;
+  return CTCD_OK;
 }
 
 int ctcd_set_cu_sharing(ctcd_decoder *d, int mode) {
@@ -1614,6 +1623,11 @@ int ctcd_expand_compact(ctcd_decoder *d, const int32_t *c_hdr, const int32_t *c_
 // The reference's call as its Python makes it (ctcdecode/__init__.py:77-123 -> paddle_beam_decode[_lm]): the four results
 // arrive as HOST tensors.  probs / seq_lens may live on either side (probs_on_device != 0: both are device pointers).
 // The kernel hands its results over in compact form, they cross PCIe compact, and host threads expand them.
+static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int probs_on_device, int B, int T, int V,
+                                 int beam, int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                                 ctcd_scorer *scorer, int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len,
+                                 int32_t *n_results, void *stream_);
+
 int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int probs_on_device, int B, int T, int V,
                              int beam, int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
                              ctcd_scorer *scorer, int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len,
@@ -1623,6 +1637,25 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
   if (rc) return rc;
   if (B == 0) return CTCD_OK;
   std::lock_guard<std::mutex> host_lock(d->mu_host);
+  rc = decode_to_host_locked(d, probs, seq_lens, probs_on_device, B, T, V, beam, num_processes, cutoff_prob, cutoff_top_n, blank_id, log_input,
+                             scorer, out_tok, out_ts, out_sc, out_len, n_results, stream_);
+  if (rc == CTCD_EINTERNAL && d->input_timed_out) {
+    // The streamed rows did not reach the kernel in time (its row fetch gives up after about a second): on this system the
+    // copy stream evidently does not run beside the kernel.  Decode again the plain way, and stay with it.
+    d->input_timed_out = false;
+    d->no_input_streaming = true;
+    if (d->copy_stream) (void)hipStreamSynchronize(d->copy_stream);
+    rc = decode_to_host_locked(d, probs, seq_lens, probs_on_device, B, T, V, beam, num_processes, cutoff_prob, cutoff_top_n, blank_id, log_input,
+                               scorer, out_tok, out_ts, out_sc, out_len, n_results, stream_);
+  }
+  return rc;
+}
+
+static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int probs_on_device, int B, int T, int V,
+                                 int beam, int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
+                                 ctcd_scorer *scorer, int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len,
+                                 int32_t *n_results, void *stream_) {
+  int rc;
   CTC_ON_DEVICE(d->device);
   hipStream_t stream = (hipStream_t)stream_;
   const size_t nin = (size_t)B * T * V * 4, kk = (size_t)B * beam;
@@ -1702,7 +1735,7 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
                o_lab = (o_ent + kk * 16 + 255) / 256 * 256;
   // the mirror holds a third of the worst case (typical sharing: a tenth); an utterance whose labels fall beyond it is
   // fetched from the device buffer afterwards
-  const size_t mcap = std::max<size_t>((size_t)1 << 20, (size_t)cap / 3);
+  const size_t mcap = d->mirror_cap_override >= 0 ? (size_t)d->mirror_cap_override + 1 : std::max<size_t>((size_t)1 << 20, (size_t)cap / 3);
   const size_t need = o_lab + mcap * 4;
   if (d->h_stage_cap < need) {
     if (d->h_stage) (void)hipHostFree(d->h_stage);
@@ -1774,6 +1807,7 @@ int ctcd_beam_decode_to_host(ctcd_decoder *d, const float *probs, const int32_t 
     }
   });
   if (sync_rc) return fail(CTCD_EHIP, "hipStreamSynchronize failed");
+  if (stream_in) HIP_TRY(hipStreamSynchronize(d->copy_stream));  // (long done: the kernel has consumed every row)
   if ((rc = ctcd_check_status(d, B))) return rc;
   if (!late.empty()) {  // rare: fetch the whole compact form from the device and expand the utterances left
     std::vector<int32_t> fh((size_t)B * 4), fe(kk * 4);
@@ -1946,7 +1980,10 @@ int ctcd_check_status(ctcd_decoder *d, int B) {
   HIP_TRY(hipMemcpyAsync(st.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, d->last_stream));
   HIP_TRY(hipStreamSynchronize(d->last_stream));
   for (int b = 0; b < B; ++b)
-    if (st[b] != ST_OK) return fail(CTCD_EINTERNAL, "decoder status " + std::to_string(st[b]) + " for item " + std::to_string(b));
+    if (st[b] != ST_OK) {
+      if (st[b] == ST_INPUT_TIMEOUT) d->input_timed_out = true;
+      return fail(CTCD_EINTERNAL, "decoder status " + std::to_string(st[b]) + " for item " + std::to_string(b));
+    }
   return CTCD_OK;
 }
 

@@ -184,6 +184,13 @@ int ctcd_debug_timeline(ctcd_decoder *dec, int frame0, int nframes, long long *o
  * (node, depth, lcp, score bits) per entry.  Call with on=1 before a decode, then with out != NULL to fetch. */
 int ctcd_debug_beam_dump(ctcd_decoder *dec, int on, int *out, int T, int beam);
 
+/* Test hook for the host-tensor entry points (ctcd_beam_decode_to_host / _host / _lm_host): input_streaming = 0 / 1 turns
+ * the streamed input off / on (-1: leave; on by default: the kernel is launched before its rows have crossed PCIe and
+ * waits for them frame block by frame block); mirror_cap_labels >= 0 shrinks the page-locked mirror a finished utterance
+ * copies its compact results into (utterances beyond it are fetched from the device buffer afterwards; -1: default size,
+ * -2: leave). */
+int ctcd_debug_set_host_path(ctcd_decoder *dec, int input_streaming, long long mirror_cap_labels);
+
 /* Tuning / introspection. */
 int ctcd_set_threads(ctcd_decoder *dec, int threads_per_workgroup); /* 0 = automatic (default); else a power of two in [64, 1024] */
 /* Two workgroups per CU.  The fixed-layout class (beam <= 128, <= 32 labels) has a second build of its kernel that fits

@@ -398,6 +398,42 @@ def test_more_than_65535_candidate_slots(torch_mod, V, K, T, top_n, quant):
     ou.assert_same(_with_nres(g2, want), want, "V=%d K=%d streamed" % (V, K))
 
 
+def test_host_path_of_decode(torch_mod):
+    """decode() = CPU tensor in, four CPU tensors out.  Round 3: (a) the kernel is launched before its input has crossed PCIe and
+    its row fetch waits for the frame blocks that follow on a second stream; (b) a finished utterance mirrors its compact
+    results into page-locked host memory itself and host threads expand utterance by utterance while the kernel still runs.
+    Every combination of the two, ragged lengths, the mirror too small for some / all utterances, with a scorer -- all
+    against the oracle, and identical to each other."""
+    import ctcdecode_amd
+    from test_lm import DATA, LABELS29
+
+    B, T, V, K = 48, 300, 29, 60
+    lp = ou.synth_logprobs(B, T, V, 4711, quant=0.5)
+    sl = np.random.default_rng(3).integers(0, T + 1, size=B).astype(np.int32)
+    sl[:4] = [T, 0, 1, 127]
+    for seq in (None, sl):
+        want = ou.decode(lp, seq, beam=K)
+        for streaming in (True, False):
+            for mcap in (None, 0, 20000):
+                d = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], beam_width=K, log_probs_input=True, device="cuda:0")
+                d.set_host_path(input_streaming=streaming, mirror_cap_labels=mcap)
+                for rep in range(2):  # (the second call reuses the staging buffers of the first)
+                    out, sc, ts, ln = d.decode(torch_mod.from_numpy(lp), torch_mod.from_numpy(seq) if seq is not None else None)
+                    got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+                    ou.assert_same(_with_nres(got, want), want, "streaming=%s mirror=%s ragged=%s rep %d" % (streaming, mcap, seq is not None, rep))
+    path = os.path.join(DATA, "test.arpa")
+    lp = ou.synth_logprobs(40, 260, 29, 4712)
+    lp[:, :, LABELS29.index(" ")] += np.float32(1.0)
+    scr = ou.Scorer(0.5, 1.0, path, LABELS29, "restated")
+    want = ou.decode(lp, scorer=scr, beam=40)
+    for streaming in (True, False):
+        d = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=path, alpha=0.5, beta=1.0, beam_width=40, log_probs_input=True, device="cuda:0")
+        d.set_host_path(input_streaming=streaming)
+        out, sc, ts, ln = d.decode(torch_mod.from_numpy(lp))
+        got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+        ou.assert_same(_with_nres(got, want), want, "with scorer, streaming=%s" % streaming)
+
+
 def test_capability_boundaries(torch_mod):
     """Every CTCD_EUNSUPPORTED edge of the no-LM path: on the supported side of a limit the call decodes
     and matches the oracle; one step beyond, it raises NotImplementedError -- cleanly: the same decoder object then decodes
