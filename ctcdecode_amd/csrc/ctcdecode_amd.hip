@@ -853,7 +853,6 @@ struct ctcd_decoder {
   int *h_cnt = nullptr;           // page-locked: the counter values the copy stream writes behind each block
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_in = nullptr;
-  const int *frames_ready_next = nullptr;  // handed to the next decode launch (decode_common clears it)
   bool no_input_streaming = false;
   bool input_timed_out = false;   // set by ctcd_check_status when an utterance reports ST_INPUT_TIMEOUT
   long long mirror_cap_override = -1;  // tests: labels the host mirror of the compact results holds (-1: a third of the worst case)
@@ -1045,7 +1044,7 @@ int ctcd_set_threads(ctcd_decoder *d, int t) {
 static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                          double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, int32_t *out_tok, int32_t *out_ts,
                          float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_, const StreamCall *sc,
-                         ctcd_scorer *scorer = nullptr, const CompactOut *co = nullptr) {
+                         ctcd_scorer *scorer = nullptr, const CompactOut *co = nullptr, const int *frames_ready = nullptr) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   if (scorer && scorer->device != d->device) return fail(CTCD_EINVAL, "the scorer's tables live on another device than the decoder");
   if (scorer && (int)scorer->host.labels.size() != V) return fail(CTCD_EINVAL, "the scorer was built for a different number of labels");
@@ -1331,8 +1330,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     a.lm.alpha = scorer->host.alpha;  // reset_params (binding.cpp:283-287) takes effect at the next decode
     a.lm.beta = scorer->host.beta;
   }
-  a.frames_ready = d->frames_ready_next;
-  d->frames_ready_next = nullptr;
+  a.frames_ready = frames_ready;  // (streamed input of the host-tensor entry point; null: every row is in place)
   a.pr_cnt = nullptr; a.pr_ch = nullptr; a.pr_lp = nullptr; a.pr_stride = 0;
   if (dims.use_rank_table) {
     a.pr_cnt = (const int *)d->pr_cnt.p; a.pr_ch = (const int *)d->pr_ch.p; a.pr_lp = (const float *)d->pr_lp.p;
@@ -1670,6 +1668,7 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
                          !d->no_input_streaming && !d->profile;
   int nblk = 0;
   int blk[10];
+  const int *frames_ready = nullptr;
   if (stream_in) {
     const size_t off_rows = 256, off_sl = off_rows + (nin + 15) / 16 * 16, fg_need = off_sl + (size_t)B * 4 + 16;
     if (d->fg_in_cap < fg_need) {
@@ -1690,7 +1689,7 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
     HIP_TRY(hipStreamWaitEvent(d->copy_stream, d->ev_in, 0));  // (the blocks must not overtake the reset)
     dprobs = (const float *)(fg + off_rows);
     dlens = seq_lens ? (const int32_t *)(fg + off_sl) : nullptr;
-    d->frames_ready_next = (const int *)fg;
+    frames_ready = (const int *)fg;
     // a small first block, so that the kernel starts at once; the rest in seven equal parts
     blk[0] = 0; blk[1] = 16; nblk = 1;
     for (int c = 1; c <= 7; ++c) blk[++nblk] = 16 + (int)((long long)(T - 16) * c / 7);
@@ -1752,8 +1751,8 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
   co.m_hdr = (int32_t *)(ds + o_hdr); co.m_ent = (int32_t *)(ds + o_ent); co.m_done = (int32_t *)(ds + o_done);
   co.m_rag = (uint32_t *)(ds + o_lab); co.m_cap = (unsigned)std::min<size_t>(mcap, 0xFFFFFFFFu);
   rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, (float *)d->c_sc.p,
-                     (int32_t *)d->c_ln.p, d_nres, stream, nullptr, scorer, &co);
-  if (rc) { d->frames_ready_next = nullptr; return rc; }
+                     (int32_t *)d->c_ln.p, d_nres, stream, nullptr, scorer, &co, frames_ready);
+  if (rc) return rc;
   if (stream_in) {  // the kernel is queued and waits for its rows: send them, frame block by frame block
     char *fg = (char *)d->fg_in;
     const size_t pitch = (size_t)T * V * 4;
