@@ -405,7 +405,12 @@ struct Decoder {
 
   CTC_HD Decoder(X &x_, Work &w_, const Dims &d_, int blank_, PoolNode *pool_, int *pool_up_, int pool_cap_, const uint64_t *tbl_,
                  const ctclm::LmView *lm_ = nullptr)
-      : x(x_), w(w_), d(d_), blank(blank_), pool(pool_), pool_up(pool_up_), pool_thi(pool_up_ + pool_cap_), pool_cap(pool_cap_), tbl(tbl_), lm(lm_) {}
+      : x(x_), w(w_), d(d_), blank(blank_), pool(pool_), pool_up(pool_up_), pool_thi(pool_up_ + pool_cap_), pool_cap(pool_cap_), tbl(tbl_), lm(lm_) {
+    if (LM) {
+      const ctclm::DictNode root = lm->dict[0];
+      root_lo = (int)root.mask_lo; root_hi = (int)root.mask_hi; root_fc = (int)root.first_child;
+    }
+  }
   CTC_HD int node_tstep(const PoolNode &pn, int id) const { return (int)(pn.cht >> 16) | (CTC_RARE(long_t) ? pool_thi[id] << 16 : 0); }
   // a node's (label, time step) word and, where frame numbers need more than 16 bits, the step's high part
   CTC_HD void set_node_time(int id, int ch, int tstep, float lpc) const {
@@ -420,6 +425,8 @@ struct Decoder {
   int st_n = 1, st_pool = 1, st_wlog = 32;
   uint32_t st_maxkey = 0;
   uint32_t st_minkey = 0;  // LM tier: key of the worst score in the beam (min_cutoff, ctc_beam_search_decoder.cpp:79)
+  int root_lo = 0, root_hi = 0, root_fc = 0;  // LM tier: the dictionary's root record (where every word starts)
+  static constexpr int kLmPending = -1;       // dfc of an entry whose dictionary record / cached window are not fetched yet
   int st_par = 0;  // which copy of the beam is current
 
   template <class P>
@@ -497,35 +504,50 @@ struct Decoder {
     if (lm->char_based) {
       acc += ctclm::lm_cond(*lm, &st, &cl, lm->label_word[c]);  // Scorer::get_log_prob sums the same windows (scorer.cpp:111-120)
       dst.dn[k] = 0; dst.dmlo[k] = 0; dst.dmhi[k] = 0; dst.dfc[k] = 0; dst.spc_lo[k] = 0; dst.spc_hi[k] = 0; dst.spst[k] = 0; dst.spcl[k] = 0;
+    } else if (c == lm->space_id) {  // a word is complete: its window joins the sum, the speller restarts at the root (path_trie.cpp:83-92)
+      acc += mk_f64(src.spc_lo[from], src.spc_hi[from]);
+      st = (uint32_t)src.spst[from];
+      cl = src.spcl[from];
+      dst.dn[k] = 0; dst.dmlo[k] = root_lo; dst.dmhi[k] = root_hi; dst.dfc[k] = root_fc;  // (no word ends at the root)
+      put_f64(ctclm::kOovScore, &dst.spc_lo[k], &dst.spc_hi[k]);
+      dst.spst[k] = 0; dst.spcl[k] = 0;
     } else {
-      ctclm::DictNode info;
-      uint32_t node;
-      if (c == lm->space_id) {  // a word is complete: its window joins the sum, the speller restarts (path_trie.cpp:83-92)
-        acc += mk_f64(src.spc_lo[from], src.spc_hi[from]);
-        st = (uint32_t)src.spst[from];
-        cl = src.spcl[from];
-        node = 0;
-      } else {
-        ctclm::DictNode pin;
-        pin.mask_lo = (uint32_t)src.dmlo[from]; pin.mask_hi = (uint32_t)src.dmhi[from]; pin.first_child = (uint32_t)src.dfc[from]; pin.word = 0;
-        node = CTC_RARE(lm->dict_wide) ? pin.first_child + (uint32_t)ctclm::dict_find_wide(*lm, pin.mask_lo, pin.mask_hi, c) : ctclm::dict_child(pin, c);
-      }
-      info = lm->dict[node];
-      dst.dn[k] = (int)node; dst.dmlo[k] = (int)info.mask_lo; dst.dmhi[k] = (int)info.mask_hi; dst.dfc[k] = (int)info.first_child;
-      // the window "…, word spelled so far": used when a space follows (:128) and for the last word in decode() (:173-185)
-      double cond = ctclm::kOovScore;
-      uint32_t st2 = 0;
-      int cl2 = 0;
-      if (info.word != ctclm::kNoWord) {
-        st2 = st;
-        cl2 = cl;
-        cond = ctclm::lm_cond(*lm, &st2, &cl2, info.word);
-      }
-      put_f64(cond, &dst.spc_lo[k], &dst.spc_hi[k]);
-      dst.spst[k] = (int)st2; dst.spcl[k] = cl2;
+      // The new node's record and the window "..., word spelled so far" need table look-ups (dependent global accesses):
+      // the entry is left PENDING (dfc = -1) and resolved by lm_resolve_entry() while the next frame's phase A runs --
+      // nothing reads these fields before that frame's phase B.
+      ctclm::DictNode pin;
+      pin.mask_lo = (uint32_t)src.dmlo[from]; pin.mask_hi = (uint32_t)src.dmhi[from]; pin.first_child = (uint32_t)src.dfc[from]; pin.word = 0;
+      const uint32_t node = CTC_RARE(lm->dict_wide) ? pin.first_child + (uint32_t)ctclm::dict_find_wide(*lm, pin.mask_lo, pin.mask_hi, c) : ctclm::dict_child(pin, c);
+      dst.dn[k] = (int)node; dst.dfc[k] = kLmPending;
     }
     dst.lmst[k] = (int)st; dst.lmcl[k] = cl;
     put_f64(acc, &dst.acc_lo[k], &dst.acc_hi[k]);
+  }
+
+  // Second half of lm_emit for a pending entry k of beam b, given its dictionary node's record: the node's arcs (the gate
+  // of path_trie.cpp:59-70) and the window "..., word spelled so far" -- used when a space follows
+  // (ctc_beam_search_decoder.cpp:128) and for the last word in decode() (:173-185).
+  CTC_HD void lm_resolve_entry(const Beam &b, int k, const ctclm::DictNode &info) const {
+    b.dmlo[k] = (int)info.mask_lo; b.dmhi[k] = (int)info.mask_hi; b.dfc[k] = (int)info.first_child;
+    double cond = ctclm::kOovScore;
+    uint32_t st2 = 0;
+    int cl2 = 0;
+    if (info.word != ctclm::kNoWord) {
+      st2 = (uint32_t)b.lmst[k];
+      cl2 = b.lmcl[k];
+      cond = ctclm::lm_cond(*lm, &st2, &cl2, info.word);
+    }
+    put_f64(cond, &b.spc_lo[k], &b.spc_hi[k]);
+    b.spst[k] = (int)st2; b.spcl[k] = cl2;
+  }
+  // Every pending entry of the current beam, with a barrier: before the beam is parked (streams) or read by finish().
+  CTC_HD void lm_resolve_pending() {
+    if (!LM) return;
+    select_beams();
+    const Beam b = w.cur;
+    for (int k = x.tid(); k < st_n; k += x.nt())
+      if (b.dfc[k] == kLmPending) lm_resolve_entry(b, k, lm->dict[b.dn[k]]);
+    x.sync();
   }
 
   // ---- danger mode ---------------------------------------------------------------------------------------------------
@@ -1060,6 +1082,17 @@ struct Decoder {
     // range) and in acnt[] the number of in-beam ancestors.  Cost is bounded even for deeply nested beams.
     w.anc = w.ancbuf + (in.t & 1) * K;
     int *acnt = w.acntbuf + (in.t & 1) * K;
+    // LM tier (word models): the entries the previous frame created are pending (lm_emit) -- their dictionary record is
+    // requested here and everything that hangs on it is settled between the barriers of phase A2, on threads that have
+    // no part in A2 when the workgroup has them; phase B is the first reader.
+    const bool lm_job = LM && !lm->char_based;
+    const int lm_joff = nt >= 2 * ((n + 63) & ~63) ? ((n + 63) & ~63) : 0;
+    int lm_jk = -1;
+    ctclm::DictNode lm_jinfo;
+    if (lm_job) {
+      const int k = tid - lm_joff;
+      if (k >= 0 && k < n && b.dfc[k] == kLmPending) { lm_jk = k; lm_jinfo = lm->dict[b.dn[k]]; }
+    }
     x.tick();
     {
       const int grp = x.group(), ngr = x.ngroups();
@@ -1129,6 +1162,11 @@ struct Decoder {
       npin += pr >= 0;
     }
     if (x.group() * x.lanes() < n) x.wave_add(&pv[P_NPIN], npin);  // (the other waves had no entry: skip the reduction)
+    if (lm_job && tid >= lm_joff) {
+      if (lm_jk >= 0) lm_resolve_entry(b, lm_jk, lm_jinfo);
+      for (int k = tid - lm_joff + (nt - lm_joff); k < n; k += nt - lm_joff)  // (workgroups with fewer threads than entries)
+        if (b.dfc[k] == kLmPending) lm_resolve_entry(b, k, lm->dict[b.dn[k]]);
+    }
     x.sync();
     x.mark(0);
     const int npin_total = pv[P_NPIN];  // final since the barrier above; requested here so that phase C does not wait for it
@@ -1867,6 +1905,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     x.mark(12);
     if (st != ST_OK) return st;
   }
+  if (LM) dec.lm_resolve_pending();
   if (ss) dec.save_state(*ss, t0 + len);
   int fs = ST_OK;
   if (!ss || ss->finish) fs = dec.finish(t0 + len > 0, t0 + len, outs, item);

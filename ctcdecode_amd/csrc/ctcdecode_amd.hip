@@ -1355,7 +1355,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
   const bool pruned_mode = a.pr_cnt != nullptr;
   const void *fn;
-#if defined(CTC_QUICK_BUILD)
+#if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2
+  if (big || !fixed || pruned_mode || !scorer || occ2 || threads != 1024 || (d->profile && !d->tl_armed))
+    return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD=2: only the fixed-layout, no-prune, 1024-thread kernel of the LM tier was compiled");
+  fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
+#elif defined(CTC_QUICK_BUILD)
   // Experiment builds (tools/build_variants.sh, seconds instead of minutes): only the north-star class kernel and its
   // barrier-timeline twin exist; everything else is refused.
   if (big || !fixed || pruned_mode || scorer || threads != 1024 || (d->profile && !d->tl_armed))

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--frame0", type=int, default=500)
     ap.add_argument("--frames", type=int, default=6)
     ap.add_argument("--out", default="")
+    ap.add_argument("--repeat", type=int, default=1, help="launches to average over (frame0 moves by 37 each)")
     ap.add_argument("--lm", default="", help="ARPA model: time the LM tier's kernel (labels _ ' space a..z)")
     a = ap.parse_args()
     import numpy as np
@@ -52,30 +53,37 @@ def main():
         dec.set_threads(a.threads)
     dec.set_timing(True)
     _native.check(_native.lib.ctcd_debug_set_profile(dec._handle, 1))
-    _native.check(_native.lib.ctcd_debug_timeline(dec._handle, a.frame0, a.frames, None))
-    dec.decode_device(lp)
-    torch.cuda.synchronize()
-    dec.decode_device(lp)
-    torch.cuda.synchronize()
-    kernel_ms = dec.last_kernel_ms()
-    cap = _native.lib.ctcd_debug_timeline_cap()
-    buf = np.zeros((16, cap), np.int64)
-    _native.check(_native.lib.ctcd_debug_timeline(dec._handle, 0, 0, buf.ctypes.data_as(ctypes.c_void_p)))
-    if a.lm:  # the LM build of the timeline kernel records half as many stamps per wave
-        cap //= 2
-        buf = buf.reshape(-1)[:16 * cap].reshape(16, cap)
-    nw = int((buf[:, 0] != 0).sum())
-    n = int((buf[0] != 0).sum())
-    per = n // a.frames
-    t = buf[:nw, :n].astype(np.float64)
-    d = np.diff(t, axis=1)
-    acc = np.zeros((nw, per))
-    cnt = 0
-    for f in range(1, a.frames - 1):  # whole frames only
-        acc += d[:, f * per:(f + 1) * per]
-        cnt += 1
-    acc /= max(cnt, 1)
-    clocks_per_frame = float((t[0, (a.frames - 1) * per] - t[0, per]) / max(a.frames - 2, 1))
+    acc_sum, cpf_sum, cnt_sum = None, 0.0, 0
+    for rep in range(a.repeat):  # (the LM build keeps 64 stamps per wave = 3 frames per launch: average over several launches)
+        _native.check(_native.lib.ctcd_debug_timeline(dec._handle, a.frame0 + 37 * rep, a.frames, None))
+        dec.decode_device(lp)
+        torch.cuda.synchronize()
+        dec.decode_device(lp)
+        torch.cuda.synchronize()
+        kernel_ms = dec.last_kernel_ms()
+        cap = _native.lib.ctcd_debug_timeline_cap()
+        buf = np.zeros((16, cap), np.int64)
+        _native.check(_native.lib.ctcd_debug_timeline(dec._handle, 0, 0, buf.ctypes.data_as(ctypes.c_void_p)))
+        if a.lm:  # the LM build of the timeline kernel records half as many stamps per wave
+            cap //= 2
+            buf = buf.reshape(-1)[:16 * cap].reshape(16, cap)
+        nw = int((buf[:, 0] != 0).sum())
+        n = int((buf[0] != 0).sum())
+        assert n < cap, "the recorded frames do not fit the timeline buffer: fewer --frames"
+        per = n // a.frames
+        t = buf[:nw, :n].astype(np.float64)
+        d = np.diff(t, axis=1)
+        acc = np.zeros((nw, per))
+        cnt = 0
+        for f in range(1, a.frames - 1):  # whole frames only
+            acc += d[:, f * per:(f + 1) * per]
+            cnt += 1
+        acc_sum = acc if acc_sum is None else acc_sum + acc
+        cnt_sum += cnt
+        cpf_sum += float((t[0, (a.frames - 1) * per] - t[0, per]) / max(a.frames - 2, 1))
+    acc = acc_sum / max(cnt_sum, 1)
+    cnt = cnt_sum
+    clocks_per_frame = cpf_sum / a.repeat
     print("timeline build: kernel %.3f ms; %d waves, %d stamps per frame, %.0f clocks per frame (%.2f GHz if every frame takes kernel/T)"
           % (kernel_ms, nw, per, clocks_per_frame, clocks_per_frame / (kernel_ms * 1e3 / a.T) / 1e3))
     overhead = float(acc[:, 2].mean()) if per == len(LABELS) else 0.0
