@@ -155,6 +155,11 @@ constexpr int kSerialCut = 24;  // introselect ranges at most this long are fini
 // depth ((d - 1) / kExpress) * kExpress, so a label sequence of length d is read back as d / kExpress + 1 independent
 // segments of at most kExpress parent hops each instead of one chain of d dependent loads.
 constexpr int kExpress = 32;
+// Event statistics (X::count; the host build of the core adds them up, tools/beam_stats.py prints them; nothing on the GPU):
+// how often a frame takes the paths that are rare on random input and common on beams shaped by a dictionary or by
+// peaky acoustic posteriors.
+enum Event { EV_FRAMES, EV_CANDIDATES, EV_EXACT, EV_INTERNAL, EV_PINNED, EV_LPC_UPDATE, EV_DEAD_PARENT, EV_REVIVE_CAND, EV_REVIVED, EV_WALK,
+             EV_WALK_HOPS, EV_COUNT };
 
 struct Work {
   // The beam is double-buffered: step t reads the copy of parity p and writes the other one.  cur / nxt are re-derived
@@ -409,6 +414,9 @@ struct Decoder {
     if (LM) {
       const ctclm::DictNode root = lm->dict[0];
       root_lo = (int)root.mask_lo; root_hi = (int)root.mask_hi; root_fc = (int)root.first_child;
+      lm_char = lm->char_based != 0; lm_wide = lm->dict_wide != 0; lm_space = lm->space_id;
+      lm_alpha = lm->alpha; lm_beta = lm->beta;
+      lm_dict = lm->dict;
     }
   }
   CTC_HD int node_tstep(const PoolNode &pn, int id) const { return (int)(pn.cht >> 16) | (CTC_RARE(long_t) ? pool_thi[id] << 16 : 0); }
@@ -426,6 +434,11 @@ struct Decoder {
   uint32_t st_maxkey = 0;
   uint32_t st_minkey = 0;  // LM tier: key of the worst score in the beam (min_cutoff, ctc_beam_search_decoder.cpp:79)
   int root_lo = 0, root_hi = 0, root_fc = 0;  // LM tier: the dictionary's root record (where every word starts)
+  // the scorer's parameters the per-candidate code needs, read once (the tables stay behind `lm`)
+  bool lm_char = false, lm_wide = false;
+  int lm_space = -1;
+  double lm_alpha = 0.0, lm_beta = 0.0;
+  const ctclm::DictNode *lm_dict = nullptr;
   static constexpr int kLmPending = -1;       // dfc of an entry whose dictionary record / cached window are not fetched yet
   int st_par = 0;  // which copy of the beam is current
 
@@ -469,25 +482,25 @@ struct Decoder {
   // log_p += score * alpha; log_p += beta, with the reference's types (float score = double * double; float += double)
   CTC_HD float lm_apply(float log_p, double cond) const {  // ctc_beam_search_decoder.cpp:131-136
     float score = 0.0f;
-    score = (float)(cond * lm->alpha);
+    score = (float)(cond * lm_alpha);
     log_p += score;
-    log_p = (float)((double)log_p + lm->beta);
+    log_p = (float)((double)log_p + lm_beta);
     return log_p;
   }
   // does extending an entry with label c call the scorer?  (:121-122)
-  CTC_HD bool lm_scores(int c) const { return lm->char_based || c == lm->space_id; }
+  CTC_HD bool lm_scores(int c) const { return lm_char || c == lm_space; }
   // get_log_cond_prob(make_ngram(.)) for "entry P of beam b extended by c" (:123-134).  Word model: the window ends with
   // the word P spells (cached when P was created).  Character model: the window ends with c itself.
   CTC_HD double lm_window(const Beam &b, int P, int c) const {
-    if (!lm->char_based) return mk_f64(b.spc_lo[P], b.spc_hi[P]);
+    if (!lm_char) return mk_f64(b.spc_lo[P], b.spc_hi[P]);
     uint32_t st = (uint32_t)b.lmst[P];
     int cl = b.lmcl[P];
     return ctclm::lm_cond(*lm, &st, &cl, lm->label_word[c]);
   }
   // may entry P be extended by c at all?  path_trie.cpp:59-70: only along the dictionary (word models)
   CTC_HD bool lm_allows(const Beam &b, int P, int c) const {
-    if (lm->char_based) return true;
-    if (CTC_RARE(lm->dict_wide)) return ctclm::dict_find_wide(*lm, (uint32_t)b.dmlo[P], (uint32_t)b.dmhi[P], c) >= 0;
+    if (lm_char) return true;
+    if (CTC_RARE(lm_wide)) return ctclm::dict_find_wide(*lm, (uint32_t)b.dmlo[P], (uint32_t)b.dmhi[P], c) >= 0;
     return c < 32 ? (((uint32_t)b.dmlo[P] >> c) & 1u) != 0u : (((uint32_t)b.dmhi[P] >> (c - 32)) & 1u) != 0u;
   }
   // The LM fields of a prefix: `from` = the entry it copies them from (self) or hangs off (child via label c >= 0).
@@ -501,10 +514,10 @@ struct Decoder {
       dst.spc_lo[k] = src.spc_lo[from]; dst.spc_hi[k] = src.spc_hi[from]; dst.spst[k] = src.spst[from]; dst.spcl[k] = src.spcl[from];
       return;
     }
-    if (lm->char_based) {
+    if (lm_char) {
       acc += ctclm::lm_cond(*lm, &st, &cl, lm->label_word[c]);  // Scorer::get_log_prob sums the same windows (scorer.cpp:111-120)
       dst.dn[k] = 0; dst.dmlo[k] = 0; dst.dmhi[k] = 0; dst.dfc[k] = 0; dst.spc_lo[k] = 0; dst.spc_hi[k] = 0; dst.spst[k] = 0; dst.spcl[k] = 0;
-    } else if (c == lm->space_id) {  // a word is complete: its window joins the sum, the speller restarts at the root (path_trie.cpp:83-92)
+    } else if (c == lm_space) {  // a word is complete: its window joins the sum, the speller restarts at the root (path_trie.cpp:83-92)
       acc += mk_f64(src.spc_lo[from], src.spc_hi[from]);
       st = (uint32_t)src.spst[from];
       cl = src.spcl[from];
@@ -517,7 +530,7 @@ struct Decoder {
       // nothing reads these fields before that frame's phase B.
       ctclm::DictNode pin;
       pin.mask_lo = (uint32_t)src.dmlo[from]; pin.mask_hi = (uint32_t)src.dmhi[from]; pin.first_child = (uint32_t)src.dfc[from]; pin.word = 0;
-      const uint32_t node = CTC_RARE(lm->dict_wide) ? pin.first_child + (uint32_t)ctclm::dict_find_wide(*lm, pin.mask_lo, pin.mask_hi, c) : ctclm::dict_child(pin, c);
+      const uint32_t node = CTC_RARE(lm_wide) ? pin.first_child + (uint32_t)ctclm::dict_find_wide(*lm, pin.mask_lo, pin.mask_hi, c) : ctclm::dict_child(pin, c);
       dst.dn[k] = (int)node; dst.dfc[k] = kLmPending;
     }
     dst.lmst[k] = (int)st; dst.lmcl[k] = cl;
@@ -567,7 +580,7 @@ struct Decoder {
   CTC_HD static bool lp_bad(float v) { return !((ctcmath::f32_to_bits(v) & 0x7fffffffu) <= 0x60ad78ecu); }  // !(|v| <= 1e20f), NaN included
   CTC_HD bool lm_params_extreme() const {  // (alpha, beta so large that scores can overflow without any bad row)
     if (!LM) return false;
-    const double a = lm->alpha, bt = lm->beta;
+    const double a = lm_alpha, bt = lm_beta;
     return !(a > -1e15 && a < 1e15 && bt > -1e15 && bt < 1e15);
   }
   CTC_HD void note_lp(float v) const {
@@ -1069,7 +1082,7 @@ struct Decoder {
     float min_cutoff = CTC_NEG_MAX;
     bool full_beam = false;
     if (LM) {
-      const double bpos = lm->beta > 0.0 ? lm->beta : 0.0;  // std::max(0.0, beta)
+      const double bpos = lm_beta > 0.0 ? lm_beta : 0.0;  // std::max(0.0, beta)
       min_cutoff = (float)((double)(unord_f32(st_minkey) + in.blank_prob) - bpos);
       full_beam = n == K;
     }
@@ -1085,13 +1098,16 @@ struct Decoder {
     // LM tier (word models): the entries the previous frame created are pending (lm_emit) -- their dictionary record is
     // requested here and everything that hangs on it is settled between the barriers of phase A2, on threads that have
     // no part in A2 when the workgroup has them; phase B is the first reader.
-    const bool lm_job = LM && !lm->char_based;
+    const bool lm_job = LM && !lm_char;
     const int lm_joff = nt >= 2 * ((n + 63) & ~63) ? ((n + 63) & ~63) : 0;
     int lm_jk = -1;
     ctclm::DictNode lm_jinfo;
     if (lm_job) {
       const int k = tid - lm_joff;
-      if (k >= 0 && k < n && b.dfc[k] == kLmPending) { lm_jk = k; lm_jinfo = lm->dict[b.dn[k]]; }
+      if (k >= 0 && k < n) {
+        const int fc = b.dfc[k], dnk = b.dn[k];
+        if (fc == kLmPending) { lm_jk = k; lm_jinfo = lm_dict[dnk]; }
+      }
     }
     x.tick();
     {
@@ -1114,6 +1130,8 @@ struct Decoder {
           if (!internal) w.e[j] = j + 1;
         }
         unsigned long long todo = x.ballot(internal);
+        if (internal) x.count(EV_INTERNAL, 1);
+        if (LM && x.subtrees_by_quarters(todo, k0, grp, ngr, b.dep, b.lcp, n, w.e, w.anc, acnt)) todo = 0;
         while (todo) {
           const int kk = __builtin_ctzll(todo);
           todo &= todo - 1;
@@ -1143,6 +1161,7 @@ struct Decoder {
           // dead-interior child X of the nearest in-beam ancestor on the way down to j (alive because j is below it)
           if (CTC_RARE(b.viaanc[j] != b.node[P])) {
             int hops = dj - b.dep[P] - 1, xn = b.node[j];
+            x.count(EV_WALK, 1); x.count(EV_WALK_HOPS, hops);
             for (int h = 0; h < hops; ++h) xn = pool[xn].parent;
             b.via[j] = xn;
             b.viaanc[j] = b.node[P];
@@ -1150,6 +1169,7 @@ struct Decoder {
           }
           // j is the first beam entry below X iff its predecessor is outside X's subtree: then j revives X
           if (b.lcp[j] <= b.dep[P]) rr = rank_of_char(in, b.viach[j]);
+          x.count(EV_DEAD_PARENT, 1); if (rr >= 0) x.count(EV_REVIVE_CAND, 1);
         }
         const int r = pr >= 0 ? pr : rr;
         if (r >= 0 && small_vocab) {
@@ -1190,12 +1210,18 @@ struct Decoder {
         if (has_rep) nbcur = w.clp[r] + nbp;  // :103-106 -- log_sum_exp(-FLT_MAX, y) returns y (decoder_utils.h:50)
         const int P = w.anc[j];
         const int pr = w.pinr[j];
+        // Pool updates (global stores) are issued after everything else of the iteration: the memory waits the compiler
+        // places in the arithmetic below would otherwise also wait for their acknowledgement.
+        int upd_node = -1, upd_xn = -1, upd_xc = 0;
+        float upd_lp = 0.f, upd_xlp = 0.f;
         if (pr >= 0) {
           const float lp = w.clp[pr];
           if (!cut(lp, b.score[P])) {
+            x.count(EV_PINNED, 1);
             if (b.lpc[j] < lp) {                                             // path_trie.cpp:42-45
+              x.count(EV_LPC_UPDATE, 1);
               b.lpc[j] = lp;
-              set_node_time(b.node[j], c, in.t, lp);
+              upd_node = b.node[j]; upd_lp = lp;  // (the pool is updated at the end of the iteration: see below)
             }
             float logp = child_logp(P, c, lp);
             if (LM && lm_scores(c)) logp = lm_apply(logp, lm_window(b, P, c));  // :120-137
@@ -1218,7 +1244,7 @@ struct Decoder {
           float xl = pool[xn].lpc;
           if (xl < lp) {
             xl = lp;
-            set_node_time(xn, cx, in.t, lp);
+            upd_xn = xn; upd_xc = cx; upd_xlp = lp;
           }
           w.rev_lpc[j] = xl;  // read back by whoever compacts the revived node (same step, other thread)
           float logp = child_logp(P, cx, lp);
@@ -1233,6 +1259,8 @@ struct Decoder {
         w.skey[s0 + 1] = k1;
         if (!LAZY) { w.sinfo[s0] = i0; w.sinfo[s0 + 1] = mk_info(c, T_SELF, j); }
         if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
+        if (upd_node >= 0) set_node_time(upd_node, c, in.t, upd_lp);
+        if (CTC_RARE(upd_xn >= 0)) set_node_time(upd_xn, upd_xc, in.t, upd_xlp);
       }
       if (LM) x.wave_add(&pv[P_NCAND], ncand);
     }
@@ -1348,6 +1376,7 @@ struct Decoder {
     // ---- D: who survives, in DFS (= slot) order.  Normally an ordered compaction of the slots that pass the
     // threshold; when the outcome depends on it, an exact replay of std::nth_element followed by a ranking by slot.
     const int n_new = N < K ? N : K;
+    if (tid == 0) { x.count(EV_FRAMES, 1); x.count(EV_CANDIDATES, N); if (exact) x.count(EV_EXACT, 1); }
     if (CTC_RARE(exact)) {
       keys_in_ord = nth_element_order(S, N, K, &lz);
       for (int q = tid; q < K; q += nt) {  // rank by slot
@@ -1450,6 +1479,14 @@ struct Decoder {
           const int upv = (dep_j & (kExpress - 1)) == 0 ? node_j : up_j;
           int o_node = self ? node_j : id, o_par = self ? par_j : node_j, o_ch = self ? ch_j : c;
           int o_dep = self ? dep_j : dep_j + 1, o_viaanc = self ? viaanc_j : -1, o_up = self ? up_j : upv;
+          // A new child presets the dead-interior cache (phase A2) for the commonest case: its parent entry j leaves the
+          // beam while j's own parent stays -- then the nearest in-beam ancestor is node par_j and the child of that node
+          // on the way down is node_j, reached by label ch_j.  (The cache is keyed by the ancestor's node: a preset that
+          // does not apply is simply never matched.)
+          int o_via = via_j, o_viach = viach_j;
+          // (when j's own parent is not in the beam, j's cache entry is the one that will apply to the child as well)
+          if (child && (w.pinr[j] >= 0 || par_j < 0)) { o_viaanc = par_j; o_via = node_j; o_viach = ch_j; }
+          else if (child) o_viaanc = viaanc_j;
           if (child) {                                                                // path_trie.cpp:97-105
             PoolNode pn; pn.parent = node_j; pn.cht = PoolNode::pack(c, in.t); pn.lpc = w.clp[rank_of_char(in, c)];
             pool[id] = pn;
@@ -1459,13 +1496,13 @@ struct Decoder {
             if (((dep_j + 1) & (kExpress - 1)) == 0) pool_up[id] = upv;
           } else if (CTC_RARE(!self)) {                                                         // path_trie.cpp:50-56 : revived
             const int P = w.anc[j];
+            x.count(EV_REVIVED, 1);
             o_node = via_j; o_par = b.node[P]; o_dep = b.dep[P] + 1;
-            int xu = via_j;  // up(revived node): its ancestor at depth ((d - 1) / kExpress) * kExpress, found by walking (rare)
-            for (int h = o_dep - ((o_dep - 1) / kExpress) * kExpress; h > 0; --h) xu = pool[xu].parent;
-            o_up = xu;
+            // up(revived node), as for a new child of P: P's node when P sits on an express level, else P's own express pointer
+            o_up = (b.dep[P] & (kExpress - 1)) == 0 ? b.node[P] : b.up[P];
           }
           nb.node[k] = o_node; nb.par[k] = o_par; nb.ch[k] = o_ch; nb.dep[k] = o_dep;
-          nb.via[k] = via_j; nb.viaanc[k] = o_viaanc; nb.viach[k] = viach_j; nb.up[k] = o_up;  // via/viach: only read when viaanc matches
+          nb.via[k] = o_via; nb.viaanc[k] = o_viaanc; nb.viach[k] = o_viach; nb.up[k] = o_up;  // via/viach: only read when viaanc matches
         }
         if (r_prob) {
           const float b_n = w.b_new[j], nb_n = w.nb_new[j], sc_n = w.sc_new[j], lpc_j = b.lpc[j];
@@ -1592,14 +1629,14 @@ struct Decoder {
       if (LM) {
         for (int a = tid; a < n; a += nt) {
           // the word the prefix ends in, when it does not end in a space (:173-185; word models only)
-          const bool partial = !lm->char_based && b.dep[a] > 0 && ch[a] != lm->space_id;
-          const bool word_here = partial && lm_allows(b, a, lm->space_id);  // a word of the model ends exactly here
+          const bool partial = !lm_char && b.dep[a] > 0 && ch[a] != lm_space;
+          const bool word_here = partial && lm_allows(b, a, lm_space);  // a word of the model ends exactly here
           const double wcond = word_here ? mk_f64(b.spc_lo[a], b.spc_hi[a]) : ctclm::kOovScore;
           float e = sc[a];
           if (partial) {
             float score = 0.0f;
-            score = (float)(wcond * lm->alpha);
-            score = (float)((double)score + lm->beta);
+            score = (float)(wcond * lm_alpha);
+            score = (float)((double)score + lm_beta);
             e += score;
           }
           ext[a] = e;
@@ -1616,8 +1653,8 @@ struct Decoder {
           }
           total += ctclm::lm_cond(*lm, &st, &cl, lm->w_eos);
           double ap = (double)e;
-          ap = ap - (double)(size_t)b.dep[a] * lm->beta;   // "remove word insert": per label (:203)
-          ap -= total * lm->alpha;                          // :205
+          ap = ap - (double)(size_t)b.dep[a] * lm_beta;   // "remove word insert": per label (:203)
+          ap -= total * lm_alpha;                          // :205
           approx[a] = (float)ap;
         }
         x.sync();

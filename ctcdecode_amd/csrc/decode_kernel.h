@@ -119,6 +119,7 @@ struct DevX {
   // alone in a phase, or for the child-scoring waves of phase B, was measured: neutral to 0.6 % slower -- not used.)
   template <int P>
   __device__ __forceinline__ void prio() const { __builtin_amdgcn_s_setprio(P); }
+  __device__ __forceinline__ void count(int, int) const {}  // (event statistics of the host build)
   // a pointer the compiler must treat as new: what it points to is (re)loaded after this point, not kept live before it
   template <class P>
   __device__ __forceinline__ const P *fresh(const P *p) const {
@@ -143,6 +144,49 @@ struct DevX {
       if (m) return base + __ffsll((long long)m) - 1;
     }
     return n;
+  }
+  // Phase A1 for a wave that holds several entries with in-beam descendants (`todo`: their lanes; the entry of lane l is
+  // row k0 + l of this wave's column walk, beam_core.h step()): four of them at a time, one per quarter of the wave --
+  // the end of each one's subtree range (first later entry whose LCP with its predecessor is shallower than the entry),
+  // then the entry painted onto its descendants.  Returns false (nothing done) when a single entry is pending: the
+  // whole wave then searches for that one.  Beams decoded under a dictionary are long chains: most entries are interior.
+  __device__ __forceinline__ bool subtrees_by_quarters(unsigned long long todo, int k0, int grp, int ngr, const int *dep, const int *lcp, int n,
+                                                       int *e, int *anc, int *acnt) {
+    if ((todo & (todo - 1)) == 0) return false;
+    constexpr int L = 16;  // lanes per entry (measured: 8 is slower, 64 = the single-entry search below)
+    const int lane = (int)threadIdx.x & 63, sub = lane / L, sl = lane & (L - 1);
+    while (todo) {
+      int kk = -1;
+      for (int s4 = 0; s4 < 64 / L; ++s4) {  // this quarter's entry: the sub-th lowest pending lane
+        const int bit = todo ? __builtin_ctzll(todo) : -1;
+        if (s4 == sub) kk = bit;
+        todo &= todo - 1;  // (0 stays 0)
+      }
+      const bool act = kk >= 0;
+      const int r = k0 + (act ? kk : 0);
+      const int jj = r * ngr + ((grp - r) & (ngr - 1));
+      const int dj = act ? dep[jj] : 0;
+      int q = n;
+      bool done = !act;
+      for (int base = jj + 2;; base += L) {
+        const int p = base + sl;
+        const unsigned long long m = __ballot(!done && p < n && lcp[p] < dj);
+        const unsigned mine = (unsigned)(m >> (L * sub)) & ((1u << L) - 1u);
+        if (!done) {
+          if (mine) { q = base + __builtin_ctz(mine); done = true; }
+          else if (base + L >= n) done = true;
+        }
+        if (__ballot(!done) == 0) break;
+      }
+      if (act) {
+        if (sl == 0) e[jj] = q;
+        for (int c = jj + 1 + sl; c < q; c += L) {
+          atomicMax(&anc[c], jj);
+          atomicAdd(&acnt[c], 1);
+        }
+      }
+    }
+    return true;
   }
   __device__ __forceinline__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
   // results mirrored into host memory: make this thread's stores visible system-wide / publish a flag there

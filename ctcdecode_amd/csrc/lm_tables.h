@@ -77,7 +77,9 @@ CTC_HD uint32_t ng_hash(uint32_t state, uint32_t word) {
 
 // log10 p(word | state) as kenlm computes it, and the state after the word.  word must be a known word (id != 0).
 CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *next) {
-  float bos[kMaxOrder];
+  // back-off weights met so far, the most recent (= shortest context) first: a register "stack" (an indexed array would
+  // live in scratch memory on the GPU)
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f, b5 = 0.f;
   int nb = 0;
   uint32_t q = state;
   float prob = 0.f;
@@ -106,7 +108,7 @@ CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *
       h = (h + 1) & L.ng_mask;
     }
     if (!hit) {
-      if (nb < kMaxOrder) bos[nb++] = bo_q;
+      if (nb < kMaxOrder) { b5 = b4; b4 = b3; b3 = b2; b2 = b1; b1 = b0; b0 = bo_q; ++nb; }
       q = fail_q;
     }
   }
@@ -114,8 +116,13 @@ CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *
     prob = uni_p;
     nx = uni_s;
   }
-  float r = prob;
-  for (int i = nb - 1; i >= 0; --i) r += bos[i];  // float32, from the shorter context to the longer (lm/model.cc)
+  float r = prob;  // float32, from the shorter context to the longer (lm/model.cc)
+  if (nb > 0) r += b0;
+  if (nb > 1) r += b1;
+  if (nb > 2) r += b2;
+  if (nb > 3) r += b3;
+  if (nb > 4) r += b4;
+  if (nb > 5) r += b5;
   *next = nx;
   return r;
 }

@@ -37,6 +37,7 @@ struct HostX {
     while (q < n && arr[q] >= bound) ++q;
     return q;
   }
+  bool subtrees_by_quarters(unsigned long long, int, int, int, const int *, const int *, int, int *, int *, int *) { return false; }  // (one lane: nothing to split)
   void atomic_max(int *p, int v) { *p = std::max(*p, v); }
   float unif(float v) const { return v; }
   int pick(int v, int) const { return v; }  // the value lane `idx` holds (one lane here)
@@ -44,6 +45,9 @@ struct HostX {
   void trace_frame(int) {}
   template <int P> void prio() const {}
   template <class P> const P *fresh(const P *p) const { return p; }
+  // event statistics (beam_core.h Event): summed over every decode of the process, read by ctccore_event_counts()
+  static long long *counters() { static long long c[ctcbeam::EV_COUNT]; return c; }
+  void count(int k, int v) const { counters()[k] += v; }
   void tick() {}
   void dump(int, int, const int *, const int *, const int *, const float *) {}
   uint32_t scan_excl(uint32_t *a, int n) {
@@ -162,6 +166,13 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
 
 // Host twin of the product's log_softmax pre-pass (ctcdecode_amd.hip log_softmax_rows_kernel; input mode 2 / ctcd_log_softmax):
 // the same float32 operations in the same order, with the C library's expf / logf.
+// event statistics since the process started (or since the last call with reset != 0): out[ctcbeam::EV_COUNT].  Decodes that run on
+// several host threads add up racily -- use num_threads = 1 for exact counts.
+extern "C" int ctccore_event_counts(long long *out, int reset) {
+  for (int i = 0; i < ctcbeam::EV_COUNT; ++i) { out[i] = HostX::counters()[i]; if (reset) HostX::counters()[i] = 0; }
+  return ctcbeam::EV_COUNT;
+}
+
 extern "C" void ctccore_log_softmax_rows(const float *x, long long rows, int V, float *out) {
   for (long long r = 0; r < rows; ++r) {
     const float *xr = x + (size_t)r * V;
