@@ -1098,6 +1098,9 @@ struct Decoder {
     // LM tier (word models): the entries the previous frame created are pending (lm_emit) -- their dictionary record is
     // requested here and everything that hangs on it is settled between the barriers of phase A2, on threads that have
     // no part in A2 when the workgroup has them; phase B is the first reader.
+    // (Measured and dropped: requesting the record from the emitting thread one frame earlier and the first level of the
+    //  n-gram look-up here -- the look-up's cost in phase A2 is its arithmetic and its later levels, not the first round
+    //  trip; and spreading the pending entries over all idle waves -- every wave then pays the set-up.)
     const bool lm_job = LM && !lm_char;
     const int lm_joff = nt >= 2 * ((n + 63) & ~63) ? ((n + 63) & ~63) : 0;
     int lm_jk = -1;
@@ -1211,7 +1214,8 @@ struct Decoder {
         const int P = w.anc[j];
         const int pr = w.pinr[j];
         // Pool updates (global stores) are issued after everything else of the iteration: the memory waits the compiler
-        // places in the arithmetic below would otherwise also wait for their acknowledgement.
+        // places in the arithmetic below would otherwise also wait for their acknowledgement.  (Scorer instantiations only:
+        // dozens of updates per frame there, one in ten frames on random rows.)
         int upd_node = -1, upd_xn = -1, upd_xc = 0;
         float upd_lp = 0.f, upd_xlp = 0.f;
         if (pr >= 0) {
@@ -1221,7 +1225,8 @@ struct Decoder {
             if (b.lpc[j] < lp) {                                             // path_trie.cpp:42-45
               x.count(EV_LPC_UPDATE, 1);
               b.lpc[j] = lp;
-              upd_node = b.node[j]; upd_lp = lp;  // (the pool is updated at the end of the iteration: see below)
+              if (LM) { upd_node = b.node[j]; upd_lp = lp; }  // (the pool is updated at the end of the iteration: see below)
+              else set_node_time(b.node[j], c, in.t, lp);
             }
             float logp = child_logp(P, c, lp);
             if (LM && lm_scores(c)) logp = lm_apply(logp, lm_window(b, P, c));  // :120-137
@@ -1244,7 +1249,8 @@ struct Decoder {
           float xl = pool[xn].lpc;
           if (xl < lp) {
             xl = lp;
-            upd_xn = xn; upd_xc = cx; upd_xlp = lp;
+            if (LM) { upd_xn = xn; upd_xc = cx; upd_xlp = lp; }
+            else set_node_time(xn, cx, in.t, lp);
           }
           w.rev_lpc[j] = xl;  // read back by whoever compacts the revived node (same step, other thread)
           float logp = child_logp(P, cx, lp);
@@ -1259,8 +1265,8 @@ struct Decoder {
         w.skey[s0 + 1] = k1;
         if (!LAZY) { w.sinfo[s0] = i0; w.sinfo[s0 + 1] = mk_info(c, T_SELF, j); }
         if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
-        if (upd_node >= 0) set_node_time(upd_node, c, in.t, upd_lp);
-        if (CTC_RARE(upd_xn >= 0)) set_node_time(upd_xn, upd_xc, in.t, upd_xlp);
+        if (LM && upd_node >= 0) set_node_time(upd_node, c, in.t, upd_lp);
+        if (LM && CTC_RARE(upd_xn >= 0)) set_node_time(upd_xn, upd_xc, in.t, upd_xlp);
       }
       if (LM) x.wave_add(&pv[P_NCAND], ncand);
     }
@@ -1485,8 +1491,12 @@ struct Decoder {
           // does not apply is simply never matched.)
           int o_via = via_j, o_viach = viach_j;
           // (when j's own parent is not in the beam, j's cache entry is the one that will apply to the child as well)
-          if (child && (w.pinr[j] >= 0 || par_j < 0)) { o_viaanc = par_j; o_via = node_j; o_viach = ch_j; }
-          else if (child) o_viaanc = viaanc_j;
+          // (kept to the scorer's instantiations: beams on random rows have next to no dead interior nodes -- tools/beam_stats.py --
+          //  and the north-star kernel is not to pay an LDS read for them)
+          if (LM) {
+            if (child && (w.pinr[j] >= 0 || par_j < 0)) { o_viaanc = par_j; o_via = node_j; o_viach = ch_j; }
+            else if (child) o_viaanc = viaanc_j;
+          }
           if (child) {                                                                // path_trie.cpp:97-105
             PoolNode pn; pn.parent = node_j; pn.cht = PoolNode::pack(c, in.t); pn.lpc = w.clp[rank_of_char(in, c)];
             pool[id] = pn;

@@ -75,8 +75,27 @@ CTC_HD uint32_t ng_hash(uint32_t state, uint32_t word) {
   return h;
 }
 
+// The table words the FIRST level of an n-gram query reads -- all independent of one another, so a caller that knows
+// (state, word) early can request them long before it needs the result (the decode kernel does: lm_probe_issue() at the top
+// of a frame, lm_score_with() two barriers later).
+struct LmProbe {
+  float uni_p; uint32_t uni_s;  // the unigram fall-back (depends on the word alone)
+  float bo; uint32_t fail;      // back-off weight and failure link of the state
+  NgSlot slot;                  // first probe of (state, word)
+};
+CTC_HD LmProbe lm_probe_issue(const LmView &L, uint32_t state, uint32_t word) {
+  LmProbe p;
+  p.uni_p = L.uni_prob[word];
+  p.uni_s = L.uni_state[word];
+  p.bo = L.st_bo[state];      // (state 0: weight 0, no failure link, and no n-gram is keyed by it -- the probe misses)
+  p.fail = L.st_fail[state];
+  p.slot = L.ng[ng_hash(state, word) & L.ng_mask];
+  return p;
+}
+
 // log10 p(word | state) as kenlm computes it, and the state after the word.  word must be a known word (id != 0).
-CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *next) {
+// `first` = lm_probe_issue(L, state, word).
+CTC_HD float lm_score_with(const LmView &L, uint32_t state, uint32_t word, const LmProbe &first, uint32_t *next) {
   // back-off weights met so far, the most recent (= shortest context) first: a register "stack" (an indexed array would
   // live in scratch memory on the GPU)
   float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f, b5 = 0.f;
@@ -86,16 +105,14 @@ CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *
   uint32_t nx = 0;
   bool hit = false;
   // Every table word that MAY be needed is requested before anything is waited for: the unigram fall-back (it depends on the
-  // word alone) here, a level's back-off weight and failure link together with its first probe below -- on the GPU each
-  // dependent global access is a round trip of more than a thousand clocks on the critical path of a frame.
-  const float uni_p = L.uni_prob[word];
-  const uint32_t uni_s = L.uni_state[word];
+  // word alone) with the first level, a level's back-off weight and failure link together with its first probe -- on the GPU
+  // each dependent global access is a round trip of more than a thousand clocks.
+  float bo_q = first.bo;
+  uint32_t fail_q = first.fail;
+  NgSlot s = first.slot;
   while (q != 0 && !hit) {
-    const float bo_q = L.st_bo[q];
-    const uint32_t fail_q = L.st_fail[q];
     uint32_t h = ng_hash(q, word) & L.ng_mask;
     for (;;) {
-      const NgSlot s = L.ng[h];
       if (s.state == q && s.word == word) {
         union { uint32_t u; float f; } cv;
         cv.u = s.prob_bits;
@@ -106,15 +123,21 @@ CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *
       }
       if (s.state == kEmptySlot) break;
       h = (h + 1) & L.ng_mask;
+      s = L.ng[h];
     }
     if (!hit) {
       if (nb < kMaxOrder) { b5 = b4; b4 = b3; b3 = b2; b2 = b1; b1 = b0; b0 = bo_q; ++nb; }
       q = fail_q;
+      if (q != 0) {  // the next level
+        bo_q = L.st_bo[q];
+        fail_q = L.st_fail[q];
+        s = L.ng[ng_hash(q, word) & L.ng_mask];
+      }
     }
   }
   if (!hit) {
-    prob = uni_p;
-    nx = uni_s;
+    prob = first.uni_p;
+    nx = first.uni_s;
   }
   float r = prob;  // float32, from the shorter context to the longer (lm/model.cc)
   if (nb > 0) r += b0;
@@ -126,23 +149,29 @@ CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *
   *next = nx;
   return r;
 }
+CTC_HD float lm_score(const LmView &L, uint32_t state, uint32_t word, uint32_t *next) {
+  return lm_score_with(L, state, word, lm_probe_issue(L, state, word), next);
+}
 
 // Scorer::get_log_cond_prob of the window that ends with `word` (scorer.cpp:74-93), given the entry's automaton state
 // and clean counter: natural-log probability (double), or OOV_SCORE when the window holds an unknown word.  Also
 // advances (state, clean) past the word.
+CTC_HD double lm_cond_with(const LmView &L, uint32_t *state, int *clean, uint32_t word, const LmProbe &first) {  // word != 0, first = lm_probe_issue(L, *state, word)
+  uint32_t nx;
+  const float p10 = lm_score_with(L, *state, word, first, &nx);
+  const bool oov = *clean < L.order - 1;
+  *state = nx;
+  *clean = *clean + 1 < L.order - 1 ? *clean + 1 : L.order - 1;
+  if (oov) return kOovScore;
+  return (double)p10 / (double)0.4342944819f;  // decoder_utils.h:14 NUM_FLT_LOGE is a float constant
+}
 CTC_HD double lm_cond(const LmView &L, uint32_t *state, int *clean, uint32_t word) {
   if (word == 0) {  // unknown: this window and the next N-1 are OOV; the history restarts after it
     *state = 0;
     *clean = 0;
     return kOovScore;
   }
-  uint32_t nx;
-  const float p10 = lm_score(L, *state, word, &nx);
-  const bool oov = *clean < L.order - 1;
-  *state = nx;
-  *clean = *clean + 1 < L.order - 1 ? *clean + 1 : L.order - 1;
-  if (oov) return kOovScore;
-  return (double)p10 / (double)0.4342944819f;  // decoder_utils.h:14 NUM_FLT_LOGE is a float constant
+  return lm_cond_with(L, state, clean, word, lm_probe_issue(L, *state, word));
 }
 
 // position of `label` among the arcs of a wide-dictionary node (lo = first arc, cnt = #arcs), -1 if it has no such arc
