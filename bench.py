@@ -452,7 +452,7 @@ def main():
             line["config"]["oversubscribed"] = "%d ranks on %d device(s): a dry run of the N-rank path, not a scaling number" % (world, ndev)
         if world == 1 and not a.no_extras and a.config == 1:
             e2e = time_e2e(torch, dec, lp_cpu)
-            line["e2e"] = {"what": "drop-in decode(): CPU float32 tensor in, four CPU tensors out (SURVEY 8(d) primary definition)",
+            line["e2e"] = {"what": "drop-in decode(): CPU float32 tensor (pageable) in, four CPU tensors out (SURVEY 8(d) primary definition); the input streams to the kernel in slices while it decodes and the kernel mirrors its compact results into page-locked host memory (DESIGN.md 2c)",
                            "ms_per_batch": round(e2e * 1e3, 3), "value": round(B / e2e, 1), "unit": "utterances/s"}
             try:
                 cp = time_compact(torch, ctcdecode_amd, dec, lp)

@@ -12,5 +12,5 @@ export TMPDIR=/tmp
 ( timeout 300 python tests/sweeps/gpu_stress.py --n 400 --seed 202 --degenerate ) > "$OUT/stress_degenerate.log" 2>&1; echo "stress degenerate rc=$? $(tail -1 $OUT/stress_degenerate.log | cut -c1-90)"
 ( timeout 300 python tests/sweeps/gpu_stress_lm.py --n 300 --seed 203 ) > "$OUT/stress_lm.log" 2>&1; echo "stress lm rc=$? $(tail -1 $OUT/stress_lm.log | cut -c1-90)"
 ( timeout 300 python tests/sweeps/gpu_stress_lm.py --n 200 --seed 204 --degenerate ) > "$OUT/stress_lm_degenerate.log" 2>&1; echo "stress lm degenerate rc=$? $(tail -1 $OUT/stress_lm_degenerate.log | cut -c1-90)"
-( timeout 600 python tests/sweeps/parity_sweep.py --n 512 --out "$OUT/parity_sweep.json" --head "$2" ) > "$OUT/parity_sweep.log" 2>&1; echo "parity sweep rc=$?"; cat "$OUT/parity_sweep.log" | cut -c1-200
+( timeout 600 python tests/sweeps/parity_sweep.py --n ${PARITY_N:-512} --out "$OUT/parity_sweep.json" --head "$2" ) > "$OUT/parity_sweep.log" 2>&1; echo "parity sweep rc=$?"; cat "$OUT/parity_sweep.log" | cut -c1-200
 SKIP_TESTS=1 bash tools/gpu_round3e.sh "$TAG"

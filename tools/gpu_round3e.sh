@@ -27,6 +27,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd "$GRAFT_REPO_ROOT"
 timeout 200 python tools/barrier_timeline.py --out "$OUT/timeline.json" > "$OUT/timeline.log" 2>&1; echo "timeline rc=$?"
+timeout 200 python tools/barrier_timeline.py --lm tests/data/test.arpa --batch 128 --T 1500 --frames 3 --repeat 12 --out "$OUT/timeline_lm.json" > "$OUT/timeline_lm.log" 2>&1; echo "timeline lm rc=$?"
 python3 - <<PY
 import csv,glob,collections
 for pat in ["pmc_*","pmc_cfg_*","pmc_extras_*"]:
