@@ -451,7 +451,14 @@ def main():
         if shared:
             line["config"]["oversubscribed"] = "%d ranks on %d device(s): a dry run of the N-rank path, not a scaling number" % (world, ndev)
         if world == 1 and not a.no_extras and a.config == 1:
-            e2e = time_e2e(torch, dec, lp_cpu)
+            # (its own decoder, released afterwards: decode() keeps a second HIP stream for the streamed input, and HIP maps
+            #  streams onto a few hardware queues -- 4 by default, GPU_MAX_HW_QUEUES -- so a stream left behind here can end up
+            #  sharing a queue with one of the `pipelined` measurement's three: INTEGRATION.md 5)
+            dec_e2e = make_decoder()
+            e2e = time_e2e(torch, dec_e2e, lp_cpu)
+            del dec_e2e
+            import gc
+            gc.collect()
             line["e2e"] = {"what": "drop-in decode(): CPU float32 tensor (pageable) in, four CPU tensors out (SURVEY 8(d) primary definition); the input streams to the kernel in slices while it decodes and the kernel mirrors its compact results into page-locked host memory (DESIGN.md 2c)",
                            "ms_per_batch": round(e2e * 1e3, 3), "value": round(B / e2e, 1), "unit": "utterances/s"}
             try:
