@@ -1757,6 +1757,12 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
   rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, (float *)d->c_sc.p,
                      (int32_t *)d->c_ln.p, d_nres, stream, nullptr, scorer, &co, frames_ready);
   if (rc) return rc;
+  // From here on work is queued that reads the caller's input and writes the caller's outputs: no way out of this
+  // function -- error or not -- without both streams drained.
+  struct Drain {
+    hipStream_t a, b;
+    ~Drain() { if (b) (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(a); }
+  } drain{stream, stream_in ? d->copy_stream : nullptr};
   if (stream_in) {  // the kernel is queued and waits for its rows: send them, frame block by frame block
     char *fg = (char *)d->fg_in;
     const size_t pitch = (size_t)T * V * 4;

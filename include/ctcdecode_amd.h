@@ -65,7 +65,11 @@ int ctcd_beam_decode(ctcd_decoder *dec, const float *probs, const int32_t *seq_l
  * below -88 taken as 0.  Frames at or beyond seq_lens[b] are not touched.  Asynchronous on `stream`. */
 int ctcd_log_softmax(ctcd_decoder *dec, const float *logits, const int32_t *seq_lens, int B, int T, int V, float *out, void *stream);
 
-/* Same, with HOST pointers for every tensor (what paddle_beam_decode receives).  Synchronous. */
+/* Same, with HOST pointers for every tensor (what paddle_beam_decode receives).  Synchronous: when it returns -- with or
+ * without an error -- nothing queued by the call still reads `probs` or writes the outputs.  Both PCIe legs overlap the
+ * kernel: log-probability input without pruning is streamed to the already running kernel on a second
+ * stream the decoder owns; finished utterances write their results into page-locked host memory themselves and host
+ * threads (max(num_processes, 16)) expand them into the padded tensors.  `probs` may be pageable. */
 int ctcd_beam_decode_host(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                           int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input,
                           int32_t *out_tokens, int32_t *out_timesteps, float *out_scores, int32_t *out_lens,
