@@ -854,6 +854,7 @@ struct ctcd_decoder {
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_in = nullptr;
   bool no_input_streaming = false;
+  bool general_lm_kernel = false;  // CTCD_GENERAL_LM_KERNEL=1: word models, too, run the scorer instantiations that serve every model
   bool input_timed_out = false;   // set by ctcd_check_status when an utterance reports ST_INPUT_TIMEOUT
   long long mirror_cap_override = -1;  // tests: labels the host mirror of the compact results holds (-1: a third of the worst case)
   hipStream_t last_stream = nullptr;  // the stream of the last decode launch (ctcd_check_status reads the status words on it)
@@ -1001,6 +1002,7 @@ int ctcd_create(ctcd_decoder **out, int device_id) {
   d->cu_count = v;
   if (const char *e = getenv("CTCD_LDS_FLOOR")) d->lds_floor = atoll(e);
   if (const char *e = getenv("CTCD_NO_INPUT_STREAMING")) d->no_input_streaming = atoi(e) != 0;
+  if (const char *e = getenv("CTCD_GENERAL_LM_KERNEL")) d->general_lm_kernel = atoi(e) != 0;
   *out = d;
   return CTCD_OK;
 }
@@ -1359,6 +1361,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (big || !fixed || pruned_mode || !scorer || occ2 || threads != 1024 || (d->profile && !d->tl_armed))
     return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD=2: only the fixed-layout, no-prune, 1024-thread kernel of the LM tier was compiled");
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
+  if (!d->profile && !scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel) fn = (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>;
 #elif defined(CTC_QUICK_BUILD)
   // Experiment builds (tools/build_variants.sh, seconds instead of minutes): only the north-star class kernel and its
   // barrier-timeline twin exist; everything else is refused.
@@ -1391,6 +1394,12 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
       fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
     if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, true, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true, true>;
+    // word models over at most 64 labels (the usual scorer): the instantiations without the character-model and
+    // wide-dictionary branches (-3.6 % per frame; CTCD_GENERAL_LM_KERNEL=1 keeps the general ones: tests run both)
+    if (fixed && !big && !scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel) {
+      fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, 2> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>;
+      if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, 2, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2, true>;
+    }
     // wide beams: the scorer's per-entry state moves to the HBM scratch with the other rare-path arrays (a capability, not a fast path)
     if (big && far_level == 3) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 3, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 3, 0, false, 0, true>;
     else if (big) fn = far_level == 2 ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false, 0, true>)

@@ -559,7 +559,9 @@ __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <=
 // replay's scratch in HBM (67 KB of LDS instead of 132 KB).  A lone workgroup runs ~7 % slower than in the default build
 // (fewer registers, replay rounds in HBM), two per CU together 1.4-1.5x faster: the library launches this build for
 // batches that outnumber the CUs and when the caller keeps several launches in flight (ctcd_set_cu_sharing).
-template <int PROF, int BIG, int LAYOUT, bool PRUNED, int NT = 0, bool LM = false, bool OCC2 = false>
+// LM: 0 = no scorer, 1 = any scorer, 2 = word model over at most 64 labels (the character-model and wide-dictionary
+// branches are not compiled in: beam_core.h WORDLM).
+template <int PROF, int BIG, int LAYOUT, bool PRUNED, int NT = 0, int LM = 0, bool OCC2 = false>
 __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint64_t tbl[64];
@@ -568,7 +570,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   if (threadIdx.x < 64) tbl[threadIdx.x] = a.tables[threadIdx.x];
   Work w;
   // (every layout keeps the exact replay's scratch in per-utterance HBM scratch; the wide-beam layouts more: beam_core.h carve)
-  if (LAYOUT == 1) carve<0, OCC2>(w, smem, a.far + (size_t)b * a.far_stride, fixed_layout_dims(LM), nullptr);
+  if (LAYOUT == 1) carve<0, OCC2>(w, smem, a.far + (size_t)b * a.far_stride, fixed_layout_dims(LM != 0), nullptr);
   else carve<BIG>(w, smem, a.far + (size_t)b * a.far_stride, a.dims, nullptr);
   __shared__ long long prof[16];
   constexpr int kTlCap = LM ? kTimelineCap / 2 : kTimelineCap;  // (the LM tier's workspace leaves 8 KB for the stamps)
@@ -616,7 +618,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #else
   if (LM) lmv = &a.lm;
 #endif
-  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM, BIG != 0, BIG != 0 || OCC2, BIG == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
+  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + (size_t)b * a.T * a.V : nullptr, a.raw_log,
                                   PRUNED ? (const int *)nullptr : a.frames_ready);
@@ -632,7 +634,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 // decode_kernels.hip instantiates the ones of its group (-DCTC_KERNEL_GROUP=g); ctcdecode_amd.hip declares them all extern.
 #define CTC_KERNEL_GROUPS 12
 #if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2  // experiment builds of the LM tier: its north-star class kernel and the timeline twin
-#define CTC_KERNEL_LIST(X) X(0, 0, 1, false, 1024, true, false, 0) X(2, 0, 1, false, 1024, true, false, 1)
+#define CTC_KERNEL_LIST(X) X(0, 0, 1, false, 1024, 2, false, 0) X(2, 0, 1, false, 1024, true, false, 1) X(0, 0, 1, false, 1024, true, false, 1)
 #elif defined(CTC_QUICK_BUILD)  // experiment builds: the north-star class kernels and the barrier-timeline twin only
 #define CTC_KERNEL_LIST(X) \
   X(0, 0, 1, false, 1024, false, false, 0) X(2, 0, 1, false, 1024, false, false, 1) X(0, 0, 1, false, 1024, false, true, 1)
@@ -645,6 +647,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(1, 0, 0, false, 0, false, false, 10) X(1, 0, 0, true, 0, false, false, 10)                                                       \
   X(0, 0, 0, false, 0, true, false, 11) X(0, 0, 0, true, 0, true, false, 11) X(0, 0, 1, false, 1024, true, false, 2)                     \
   X(0, 0, 1, true, 1024, true, false, 3) X(2, 0, 1, false, 1024, true, false, 4)                                                       \
+  X(0, 0, 1, false, 1024, 2, false, 0) X(0, 0, 1, true, 1024, 2, false, 1) X(0, 0, 1, false, 1024, 2, true, 2) X(0, 0, 1, true, 1024, 2, true, 3) \
   X(0, 0, 1, false, 1024, false, true, 0) X(0, 0, 1, true, 1024, false, true, 1) X(0, 0, 1, false, 1024, true, true, 10) X(0, 0, 1, true, 1024, true, true, 11) \
   X(0, 1, 0, false, 0, true, false, 6) X(0, 1, 0, true, 0, true, false, 7) X(0, 2, 0, false, 0, true, false, 8) X(0, 2, 0, true, 0, true, false, 9) \
   X(0, 3, 0, false, 0, false, false, 5) X(0, 3, 0, true, 0, false, false, 4) X(0, 3, 0, false, 0, true, false, 6) X(0, 3, 0, true, 0, true, false, 7)

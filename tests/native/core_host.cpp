@@ -342,6 +342,12 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
         else st = decode_utterance<true, false, true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+      } else if (lm && !lm->char_based && !lm->dict_wide && !getenv("CTC_HOST_GENERAL_LM")) {  // the word-model instantiation, as the product picks it
+        const float *rawb = raw + (size_t)b * T * V;
+        if (pruned) st = decode_utterance<false, false, true, false, false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+        else st = decode_utterance<true, false, true, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
       } else if (lm) {
         const float *rawb = raw + (size_t)b * T * V;
         if (pruned) st = decode_utterance<false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),

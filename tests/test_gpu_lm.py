@@ -80,6 +80,18 @@ def test_lm_generated_mid_size_model(torch_mod, tmp_path):
         ou.assert_same(_with_nres(got, want), want, "mid-size model seed %d" % seed)
 
 
+@pytest.mark.parametrize("cu_sharing", [0, 1])
+@pytest.mark.parametrize("name", gu.lm_names())
+def test_lm_reference_fixtures_general_scorer_kernels(torch_mod, name, cu_sharing, monkeypatch):
+    """Word models over <= 64 labels normally run the instantiations that leave the character-model / wide-dictionary branches
+    out (LM == 2); CTCD_GENERAL_LM_KERNEL=1 (read when a decoder is created) keeps them on the general ones: same results."""
+    monkeypatch.setenv("CTCD_GENERAL_LM_KERNEL", "1")
+    args, lm, want = gu.load_lm(name)
+    got, meta = _decode(torch_mod, lm=lm, cu_sharing=cu_sharing, **args)
+    assert meta == lm["meta"]
+    ou.assert_same(_with_nres(got, want), want, name)
+
+
 @pytest.mark.parametrize("arpa,labels,K,T", [("test.arpa", LABELS29, 400, 120), ("abcd_words.arpa", ["_", "a", "b", "c", "d", "'", " "], 600, 100),
                                             ("chars.arpa", ["_", "a", "b", "c", "d", "'", "é", " "], 500, 80), ("test.arpa", LABELS29, 1000, 40)])
 def test_lm_wide_beam(torch_mod, arpa, labels, K, T):
