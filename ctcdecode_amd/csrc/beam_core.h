@@ -1289,6 +1289,11 @@ struct Decoder {
           const int c = IDENT ? r : w.cch[r];
           const float lp = w.clp[r];
           const uint32_t childinfo = mk_info(c, T_CHILD, 0);
+          // (word models: the lane's label picks ONE of the two gate words of a parent, once -- and the gate is folded into
+          //  `live` with plain bit operations, so that the compiler requests the word together with the parent's other
+          //  fields instead of behind the cutoff test: one LDS round trip per parent instead of two)
+          const int *gate_w = LM && WORDLM ? (c < 32 ? b.dmlo : b.dmhi) : nullptr;
+          const int gate_sh = c & 31;
           for (int i = t2 >> sh; i < n; i += ng) {
             // everything this candidate needs from its parent, requested in one go (one LDS round trip), no branches
             const int cs = w.cstart[i];
@@ -1299,7 +1304,12 @@ struct Decoder {
             const float ext = lp + psc, rep = pbp > CTC_NEG_MAX ? lp + pbp : CTC_NEG_MAX;  // :110-118
             float logp = c == pch ? rep : ext;
             if (LM) {
-              if (cut(lp, psc) || !lm_allows(b, i, c)) live = 0u;            // :93-95, path_trie.cpp:59-70
+              if (WORDLM) {
+                const uint32_t gate = ((uint32_t)gate_w[i] >> gate_sh) & 1u;
+                live &= 0u - (gate & (uint32_t)!cut(lp, psc));                    // :93-95, path_trie.cpp:59-70
+              } else if (cut(lp, psc) || !lm_allows(b, i, c)) {
+                live = 0u;
+              }
               if (live && lm_scores(c)) logp = lm_apply(logp, lm_window(b, i, c));  // :120-137
               ncand += live ? 1 : 0;
             }
