@@ -1361,7 +1361,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (big || !fixed || pruned_mode || !scorer || occ2 || threads != 1024 || (d->profile && !d->tl_armed))
     return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD=2: only the fixed-layout, no-prune, 1024-thread kernel of the LM tier was compiled");
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
-  if (!d->profile && !scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel) fn = (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>;
+  if (!scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel)
+    fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, 2> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>;
 #elif defined(CTC_QUICK_BUILD)
   // Experiment builds (tools/build_variants.sh, seconds instead of minutes): only the north-star class kernel and its
   // barrier-timeline twin exist; everything else is refused.
@@ -1407,6 +1408,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if (d->profile && d->tl_armed) {  // (shape conditions checked above)
       if (!fixed) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels");
       fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true>;
+      if (!scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel) fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, 2>;
     }
   }
 #endif

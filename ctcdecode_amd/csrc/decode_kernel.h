@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 // decode_kernels.hip instantiates the ones of its group (-DCTC_KERNEL_GROUP=g); ctcdecode_amd.hip declares them all extern.
 #define CTC_KERNEL_GROUPS 12
 #if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2  // experiment builds of the LM tier: its north-star class kernel and the timeline twin
-#define CTC_KERNEL_LIST(X) X(0, 0, 1, false, 1024, 2, false, 0) X(2, 0, 1, false, 1024, true, false, 1) X(0, 0, 1, false, 1024, true, false, 1)
+#define CTC_KERNEL_LIST(X) X(0, 0, 1, false, 1024, 2, false, 0) X(2, 0, 1, false, 1024, 2, false, 1) X(0, 0, 1, false, 1024, true, false, 1) X(2, 0, 1, false, 1024, true, false, 0)
 #elif defined(CTC_QUICK_BUILD)  // experiment builds: the north-star class kernels and the barrier-timeline twin only
 #define CTC_KERNEL_LIST(X) \
   X(0, 0, 1, false, 1024, false, false, 0) X(2, 0, 1, false, 1024, false, false, 1) X(0, 0, 1, false, 1024, false, true, 1)
@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(1, 0, 0, false, 0, false, false, 10) X(1, 0, 0, true, 0, false, false, 10)                                                       \
   X(0, 0, 0, false, 0, true, false, 11) X(0, 0, 0, true, 0, true, false, 11) X(0, 0, 1, false, 1024, true, false, 2)                     \
   X(0, 0, 1, true, 1024, true, false, 3) X(2, 0, 1, false, 1024, true, false, 4)                                                       \
-  X(0, 0, 1, false, 1024, 2, false, 0) X(0, 0, 1, true, 1024, 2, false, 1) X(0, 0, 1, false, 1024, 2, true, 2) X(0, 0, 1, true, 1024, 2, true, 3) \
+  X(0, 0, 1, false, 1024, 2, false, 0) X(0, 0, 1, true, 1024, 2, false, 1) X(0, 0, 1, false, 1024, 2, true, 2) X(0, 0, 1, true, 1024, 2, true, 3) X(2, 0, 1, false, 1024, 2, false, 5) \
   X(0, 0, 1, false, 1024, false, true, 0) X(0, 0, 1, true, 1024, false, true, 1) X(0, 0, 1, false, 1024, true, true, 10) X(0, 0, 1, true, 1024, true, true, 11) \
   X(0, 1, 0, false, 0, true, false, 6) X(0, 1, 0, true, 0, true, false, 7) X(0, 2, 0, false, 0, true, false, 8) X(0, 2, 0, true, 0, true, false, 9) \
   X(0, 3, 0, false, 0, false, false, 5) X(0, 3, 0, true, 0, false, false, 4) X(0, 3, 0, false, 0, true, false, 6) X(0, 3, 0, true, 0, true, false, 7)
