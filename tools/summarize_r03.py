@@ -65,7 +65,7 @@ def main():
         total = int((h.get("FETCH_SIZE_KiB", 0) + h.get("WRITE_SIZE_KiB", 0)) * 1024)
         pmc["hbm_bytes_per_launch"] = total
         lat = {"hbm_bytes_per_launch": total, "source": tag + "_pmc.json"}
-        comp = [v for k, v in pmc["kernels"].items() if k.startswith("extras: ") and "ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, false>" in k]
+        comp = [v for k, v in pmc["kernels"].items() if k.startswith("extras: ") and ("ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, false>" in k or "ctc_beam_decode_kernel<0, 0, 1, false, 1024, 0, false>" in k)]
         if comp:  # the same kernel handing its results over in compact form (tools/profile_extras.py "expand")
             lat["compact_hbm_bytes_per_launch"] = int((comp[0].get("FETCH_SIZE_KiB", 0) + comp[0].get("WRITE_SIZE_KiB", 0)) * 1024)
             pmc["compact_hbm_bytes_per_launch"] = lat["compact_hbm_bytes_per_launch"]
