@@ -55,7 +55,10 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
     os.makedirs(LIB_DIR, exist_ok=True)
     stem = os.path.splitext(lib_path)[0] if out else os.path.join(LIB_DIR, "obj")
     base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-            "-Wno-unused-result"] + ["-D" + d for d in defines] + os.environ.get("CTCD_EXTRA_HIPCC_FLAGS", "").split()
+            "-Wno-unused-result",
+            # (lane-0 atomics on per-workgroup counters are already one per wave: the atomic optimizer's wave reduction
+            #  around them is ~10 instructions of dead weight per site on every wave)
+            "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + ["-D" + d for d in defines] + os.environ.get("CTCD_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
     quick = any(d.split("=")[0] == "CTC_QUICK_BUILD" for d in defines)

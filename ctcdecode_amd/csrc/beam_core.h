@@ -98,6 +98,13 @@ CTC_HD uint32_t ord_f32(float f) {
   const uint32_t u = ctcmath::f32_to_bits(f + 0.0f);  // -0 + +0 = +0: both zeros get the same key; nothing else changes
   return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
+// ... without the zero canonicalisation: for sums that cannot be -0.  (x + y is -0 only when both are -0; without a scorer a
+// prefix score starts at +0 and is from then on a sum with at least one term that is not -0, or logf(.) + max(.), which
+// gives -0 only from two -0 terms as well -- so score + log-probability is never -0, whatever the rows hold.)
+CTC_HD uint32_t ord_f32_raw(float f) {
+  const uint32_t u = ctcmath::f32_to_bits(f);
+  return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
 CTC_HD float unord_f32(uint32_t k) {  // inverse of ord_f32 (the key of either zero gives +0)
   return ctcmath::bits_to_f32((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
@@ -429,6 +436,17 @@ struct Decoder {
 
   CTC_HD float lse(float a, float b) const { return ctcmath::lse(a, b, tbl); }
 
+  // "The tail is zero": in identity mode without a scorer the number of slots S = n (1 + V) never shrinks while an utterance
+  // is decoded (n only grows, the blank is always a candidate), and a frame writes every slot below S.  The fixed-layout
+  // kernels therefore keep the slot keys from S to the end of their block at zero -- cleared once (init / load_state), and
+  // again after an exact replay that used the block as its staging area -- and the select's listing pass reads its keys
+  // without bounds tests (decode_kernel.h list_bucket).  Only where the execution policy asks for it (the GPU).
+  static constexpr bool kTailZero = IDENT && SMALLV && !LM && !LAZY && X::kZeroKeyTail;
+  CTC_HD void zero_key_tail(int from) {
+    if (!kTailZero) return;
+    for (int i = from + x.tid(); i < kSmallK * (2 + kSmallV); i += x.nt()) w.skey[i] = 0u;  // (the fixed layout's block: carve)
+  }
+
   // Step-to-step state, identical in every thread (kept in registers, not LDS)
   int st_n = 1, st_pool = 1, st_wlog = 32;
   uint32_t st_maxkey = 0;
@@ -668,6 +686,7 @@ struct Decoder {
     for (int i = x.tid(); i < 2 * d.K; i += x.nt()) { w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
     if (d.use_rank_table)
       for (int c = x.tid(); c < d.V; c += x.nt()) w.rank_of[c] = -1;
+    zero_key_tail(0);
     x.sync_full();
   }
 
@@ -704,6 +723,7 @@ struct Decoder {
     for (int i = tid; i < 2 * K; i += nt) { w.hit[i] = 0; w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
     if (d.use_rank_table)
       for (int c = tid; c < d.V; c += nt) w.rank_of[c] = -1;
+    zero_key_tail(0);
     x.sync_full();
   }
   CTC_HD void save_state(const StreamState &ss, int frames) {
@@ -799,6 +819,11 @@ struct Decoder {
     x.sync();
   }
 
+  // which word of w.hit holds bit `bit` (non-blank candidate number) of entry i's existing-children mask: two words per
+  // entry; the fixed-layout class (at most 31 non-blank candidates) uses ONE word per entry, indexed like every other
+  // per-entry array (the scoring loop then advances one address for all of them)
+  CTC_HD static int hit_word(int i, int bit) { return SMALLV ? i : 2 * i + (bit >> 5); }
+
   // log_p of extending beam entry P with character c (ctc_beam_search_decoder.cpp:110-118)
   CTC_HD float child_logp(int P, int c, float lp) const {
     const Beam &b = w.cur;
@@ -846,7 +871,7 @@ struct Decoder {
     const int tid = x.tid(), nt = x.nt();
     CTC_ASSUME(inb >= 1 && inb <= kListCap);
     // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
-    x.list_bucket(S, w.skey, b32, bspan, direct, w.bitmap, w.list, w.lslot, &pv[P_LCOUNT]);
+    x.template list_bucket<kTailZero>(S, w.skey, b32, bspan, direct, w.bitmap, w.list, w.lslot, &pv[P_LCOUNT]);
     for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
     x.sync();
     x.mark(14);
@@ -1182,7 +1207,7 @@ struct Decoder {
         const int r = pr >= 0 ? pr : rr;
         if (r >= 0 && small_vocab) {
           const int bit = r - ((brank >= 0 && r > brank) ? 1 : 0);
-          x.atomic_or(&w.hit[2 * P + (bit >> 5)], 1u << (bit & 31));
+          x.atomic_or(&w.hit[hit_word(P, bit)], 1u << (bit & 31));
         }
       }
       w.pinr[j] = pr;
@@ -1294,10 +1319,13 @@ struct Decoder {
           //  fields instead of behind the cutoff test: one LDS round trip per parent instead of two)
           const int *gate_w = LM && WORDLM ? (c < 32 ? b.dmlo : b.dmhi) : nullptr;
           const int gate_sh = c & 31;
-          for (int i = t2 >> sh; i < n; i += ng) {
+          // (the info word of (label, parent i) is childinfo + i: it is the loop's induction variable)
+          uint32_t ci = childinfo + (uint32_t)(t2 >> sh);
+          const uint32_t ci_end = childinfo + (uint32_t)n;
+          for (int i = t2 >> sh; ci < ci_end; i += ng, ci += (uint32_t)ng) {
             // everything this candidate needs from its parent, requested in one go (one LDS round trip), no branches
             const int cs = w.cstart[i];
-            const uint32_t hw = w.hit[2 * i + (rn >> 5)];
+            const uint32_t hw = w.hit[hit_word(i, rn)];
             const int pch = b.ch[i];
             const float psc = b.score[i], pbp = b.bprev[i];
             uint32_t live = 0u - (((hw >> (rn & 31)) & 1u) ^ 1u);  // all ones unless the child already exists
@@ -1313,10 +1341,10 @@ struct Decoder {
               if (live && lm_scores(c)) logp = lm_apply(logp, lm_window(b, i, c));  // :120-137
               ncand += live ? 1 : 0;
             }
-            const uint32_t k = ord_f32(logp) & live;
+            const uint32_t k = (LM ? ord_f32(logp) : ord_f32_raw(logp)) & live;
             const int s = cs + rn;
             w.skey[s] = k;
-            if (!LAZY) w.sinfo[s] = ((childinfo | (uint32_t)i) & live) | (kHoleInfo & ~live);
+            if (!LAZY) w.sinfo[s] = x.bitsel(live, ci, kHoleInfo);
             hist_add(wd, k);
           }
         }
@@ -1326,7 +1354,7 @@ struct Decoder {
           const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
           const int c = IDENT ? r : w.cch[r];
           const int s = w.cstart[i] + rn;
-          bool exists = small_vocab && ((w.hit[2 * i + (rn >> 5)] >> (rn & 31)) & 1u);
+          bool exists = small_vocab && ((w.hit[hit_word(i, rn)] >> (rn & 31)) & 1u);
           float logp = CTC_NEG_MAX;
           if (LM) {
             // (with more than 64 candidate labels the children that already exist are punched out afterwards; they are
@@ -1410,6 +1438,7 @@ struct Decoder {
       x.sync();
       if (keys_in_ord) {
         for (int q = tid; q < K; q += nt) ord[rk[q]] = (int)(uint32_t)(EO::key(ekp()[q]) >> 16);
+        zero_key_tail(S);  // (the replay staged its ranges in the block of the slot keys; the frames to come rewrite [0, S))
         x.sync();
       }
       x.mark(6);
@@ -1462,7 +1491,7 @@ struct Decoder {
         if (!spare || tid >= nroles * ne) {
           const int t0 = spare ? tid - nroles * ne : tid, tstep = spare ? nt - nroles * ne : nt;
           for (int i = t0; i < kBins; i += tstep) w.bins[i] = 0;
-          for (int i = t0; i < 2 * n; i += tstep) w.hit[i] = 0;
+          for (int i = t0; i < (SMALLV ? n : 2 * n); i += tstep) w.hit[i] = 0;
           int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;
           for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }
           if (t0 == 0) {

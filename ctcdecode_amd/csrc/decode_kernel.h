@@ -17,6 +17,10 @@ using namespace ctcbeam;
 // ------------------------------------------------------------------------------------------------ device policy
 // Cross-lane data movement uses DPP (row shifts + row broadcasts, a few cycles each) instead of ds_bpermute-based
 // shuffles (~100 cycles each on the critical path): every block primitive below is a wave-level scan.
+// lane mask of a predicate.  (HIP's __ballot(int) compares an integer with zero: the compiler then materialises the
+// predicate as 0 / 1 in a vector register and compares it again -- two vector instructions per ballot; the builtin takes
+// the boolean and folds into the compare that produced it.)
+#define CTC_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 #define CTC_DPP(old, v, ctrl, rowmask) __builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rowmask), 0xf, false)
 
 // Inclusive scan over the 64 lanes of a wave; op(left, mine); `ident` is op's left identity.
@@ -48,6 +52,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // and the slot-to-wave assignment then fold to constants.
 template <int PROF, bool FAR, int NT = 0>
 struct DevX {
+  static constexpr bool kZeroKeyTail = true;  // beam_core.h Decoder::kTailZero
   int *red;  // 2 x 16 ints of LDS
   int parity;
   long long *prof;   // PROF: per-phase cycle accumulators (LDS), written by thread 0
@@ -135,12 +140,12 @@ struct DevX {
   __device__ __forceinline__ int ngroups() const { return (nt() + 63) >> 6; }
   __device__ __forceinline__ int lane() const { return (int)threadIdx.x & 63; }
   __device__ __forceinline__ int lanes() const { return 64; }
-  __device__ __forceinline__ unsigned long long ballot(bool p) const { return __ballot(p); }
+  __device__ __forceinline__ unsigned long long ballot(bool p) const { return CTC_BALLOT(p); }
   // first q in [from, n) with arr[q] < bound (n if none); arguments uniform across the wave
   __device__ __forceinline__ int first_below(const int *arr, int from, int n, int bound) const {
     for (int base = from; base < n; base += 64) {
       const int q = base + ((int)threadIdx.x & 63);
-      const unsigned long long m = __ballot(q < n && arr[q] < bound);
+      const unsigned long long m = CTC_BALLOT(q < n && arr[q] < bound);
       if (m) return base + __ffsll((long long)m) - 1;
     }
     return n;
@@ -170,13 +175,13 @@ struct DevX {
       bool done = !act;
       for (int base = jj + 2;; base += L) {
         const int p = base + sl;
-        const unsigned long long m = __ballot(!done && p < n && lcp[p] < dj);
+        const unsigned long long m = CTC_BALLOT(!done && p < n && lcp[p] < dj);
         const unsigned mine = (unsigned)(m >> (L * sub)) & ((1u << L) - 1u);
         if (!done) {
           if (mine) { q = base + __builtin_ctz(mine); done = true; }
           else if (base + L >= n) done = true;
         }
-        if (__ballot(!done) == 0) break;
+        if (CTC_BALLOT(!done) == 0) break;
       }
       if (act) {
         if (sl == 0) e[jj] = q;
@@ -189,6 +194,8 @@ struct DevX {
     return true;
   }
   __device__ __forceinline__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+  // (a & mask) | (b & ~mask): one v_bitop3_b32 (the compiler builds it from three instructions)
+  __device__ __forceinline__ uint32_t bitsel(uint32_t mask, uint32_t a, uint32_t b) const { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA); }
   // results mirrored into host memory: make this thread's stores visible system-wide / publish a flag there
   __device__ __forceinline__ void fence_system() const { __threadfence_system(); }
   // streamed input: a counter another agent (the copy stream) advances in uncached memory; a short pause between two looks
@@ -230,7 +237,7 @@ struct DevX {
       const bool f1 = rounds > 1 && s1 < S && pred(s1);
       const bool f2 = rounds > 2 && s2 < S && pred(s2);
       const bool f3 = rounds > 3 && s3 < S && pred(s3);
-      const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+      const unsigned long long m0 = CTC_BALLOT(f0), m1 = CTC_BALLOT(f1), m2 = CTC_BALLOT(f2), m3 = CTC_BALLOT(f3);
       if (lane < rounds) {
         const unsigned long long m = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : m3;
         bitmap[2 * (wave * rounds + lane)] = (uint32_t)m;
@@ -240,7 +247,7 @@ struct DevX {
     }
     for (int it = 0; it < rounds; ++it) {
       const int s = first + it * 64 + lane;
-      const unsigned long long m = __ballot(s < S && pred(s));
+      const unsigned long long m = CTC_BALLOT(s < S && pred(s));
       if (lane == 0) {
         bitmap[2 * (wave * rounds + it)] = (uint32_t)m;
         bitmap[2 * (wave * rounds + it) + 1] = (uint32_t)(m >> 32);
@@ -251,44 +258,76 @@ struct DevX {
   // (key offset + 1) / lslot[] (slot), and -- when `direct` -- bit s of the bitmap says "key above the bucket".
   // A wave reserves the list space of ALL its slots with ONE returning LDS atomic: a returning atomic costs a full LDS
   // round trip, and one per bucket member (in divergent code, once per round) was most of this pass.
+  // TZ ("tail is zero"): the caller keeps every key from slot S up to the next multiple of the workgroup's slots-per-pass
+  // at zero (beam_core.h: identity mode without a scorer -- S never shrinks there), so up to four rounds per wave read
+  // their keys without a bounds test: a guarded load is seven instructions on every wave, a plain one is one.
+  template <int R, bool TZ>
+  __device__ __forceinline__ void list_group(int S, const uint32_t *skey, int s0, uint32_t b32, uint32_t bspan, bool direct, uint32_t *bmw,
+                                             uint32_t *list, int *lslot, int *lcount) {
+    const int lane = (int)threadIdx.x & 63;
+#define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
+    // One compare per question (the lane mask of a single compare IS the ballot; a conjunction of two is first
+    // materialised as 0 / 1 per lane and compared again): b32 + bspan never exceeds 2^32 - 1 (the bucket lies inside the
+    // key range), so a key below the bucket wraps to an offset beyond bspan, and "above the bucket" is one compare with
+    // its top.  (b32 >= 1: holes, key 0, never pass.)
+    const uint32_t top = b32 + bspan;
+    const unsigned long long dm = direct ? ~0ull : 0ull;  // (uniform)
+    uint32_t k[R], d[R];
+    unsigned long long m[R], a[R];
+    int c[R], tot = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) k[r] = (TZ || s0 + 64 * r < S) ? skey[s0 + 64 * r] : 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      d[r] = k[r] - b32;
+      m[r] = CTC_BALLOT(d[r] <= bspan);
+      a[r] = CTC_BALLOT(k[r] > top) & dm;
+      c[r] = __popcll(m[r]);
+      tot += c[r];
+    }
+    if (tot) {  // (uniform)
+      int base = 0;
+      if (lane == 0) base = atomicAdd(lcount, tot);
+      base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (d[r] <= bspan) { const int p = base + CTC_BELOW(m[r]); list[p] = d[r] + 1u; lslot[p] = s0 + 64 * r; }
+        base += c[r];
+      }
+    }
+    // the R words of the bitmap, by one lane (the masks are scalars: no per-lane selection among them)
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) *reinterpret_cast<uint2 *>(bmw + 2 * r) = make_uint2((uint32_t)a[r], (uint32_t)(a[r] >> 32));
+    }
+#undef CTC_BELOW
+  }
+  template <bool TZ = false>
   __device__ __forceinline__ void list_bucket(int S, const uint32_t *skey, uint32_t b32, uint32_t bspan, bool direct, uint32_t *bitmap,
                                               uint32_t *list, int *lslot, int *lcount) {
     const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rounds = ctcbeam::ceil_div_p2(S, 64 * nw);
     const int first = wave * rounds * 64;
-#define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
     // four rounds at a time, straight-line: their keys are requested together (one LDS round trip), and one returning
     // atomic reserves the list space of all four.  (Wide beams take several such groups: 15 rounds at beam 500.)
+    if (TZ && rounds <= 4) {  // the usual shapes: one group, no bounds tests
+      uint32_t *bmw = bitmap + 2 * (wave * rounds);
+      if (rounds == 3) list_group<3, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
+      else if (rounds == 4) list_group<4, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
+      else if (rounds == 2) list_group<2, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
+      else list_group<1, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
+      return;
+    }
     for (int r0 = 0; r0 < rounds; r0 += 4) {
       const int nr = rounds - r0;  // rounds left (uniform)
-      const int s0 = first + r0 * 64 + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
-      const uint32_t k0 = s0 < S ? skey[s0] : 0u, k1 = (nr > 1 && s1 < S) ? skey[s1] : 0u;
-      const uint32_t k2 = (nr > 2 && s2 < S) ? skey[s2] : 0u, k3 = (nr > 3 && s3 < S) ? skey[s3] : 0u;
-      const uint32_t d0 = k0 - b32, d1 = k1 - b32, d2 = k2 - b32, d3 = k3 - b32;
-      const bool g0 = k0 >= b32, g1 = k1 >= b32, g2 = k2 >= b32, g3 = k3 >= b32;  // (b32 >= 1: holes, key 0, never pass)
-      const bool i0 = g0 && d0 <= bspan, i1 = g1 && d1 <= bspan, i2 = g2 && d2 <= bspan, i3 = g3 && d3 <= bspan;
-      const unsigned long long m0 = __ballot(i0), m1 = __ballot(i1), m2 = __ballot(i2), m3 = __ballot(i3);
-      const unsigned long long a0 = __ballot(direct && g0 && !i0), a1 = __ballot(direct && g1 && !i1), a2 = __ballot(direct && g2 && !i2),
-                               a3 = __ballot(direct && g3 && !i3);
-      const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
-      const int tot = c0 + c1 + c2 + c3;
-      if (tot) {  // (uniform)
-        int base = 0;
-        if (lane == 0) base = atomicAdd(lcount, tot);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (i0) { const int p = base + CTC_BELOW(m0); list[p] = d0 + 1u; lslot[p] = s0; }
-        if (i1) { const int p = base + c0 + CTC_BELOW(m1); list[p] = d1 + 1u; lslot[p] = s1; }
-        if (i2) { const int p = base + c0 + c1 + CTC_BELOW(m2); list[p] = d2 + 1u; lslot[p] = s2; }
-        if (i3) { const int p = base + c0 + c1 + c2 + CTC_BELOW(m3); list[p] = d3 + 1u; lslot[p] = s3; }
-      }
-      if (lane < 4 && lane < nr) {
-        const unsigned long long m = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a3;
-        bitmap[2 * (wave * rounds + r0 + lane)] = (uint32_t)m;
-        bitmap[2 * (wave * rounds + r0 + lane) + 1] = (uint32_t)(m >> 32);
-      }
+      uint32_t *bmw = bitmap + 2 * (wave * rounds + r0);
+      const int s0 = first + r0 * 64 + lane;
+      if (nr >= 4) list_group<4, false>(S, skey, s0, b32, bspan, direct, bmw, list, lslot, lcount);
+      else if (nr == 3) list_group<3, false>(S, skey, s0, b32, bspan, direct, bmw, list, lslot, lcount);
+      else if (nr == 2) list_group<2, false>(S, skey, s0, b32, bspan, direct, bmw, list, lslot, lcount);
+      else list_group<1, false>(S, skey, s0, b32, bspan, direct, bmw, list, lslot, lcount);
     }
-#undef CTC_BELOW
   }
   // out[r] = s for the r-th set bit s of the bitmap (ascending); one wave, the others wait at the closing barrier.
   // CLUSTERED: the set bits come in long runs (the LM tier: a dictionary-constrained beam keeps the children of few
@@ -389,7 +428,7 @@ struct DevX {
       const bool f1 = rounds > 1 && s1 < S && pred(s1);
       const bool f2 = rounds > 2 && s2 < S && pred(s2);
       const bool f3 = rounds > 3 && s3 < S && pred(s3);
-      const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+      const unsigned long long m0 = CTC_BALLOT(f0), m1 = CTC_BALLOT(f1), m2 = CTC_BALLOT(f2), m3 = CTC_BALLOT(f3);
       const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
       if (lane == 0) row[wave] = c0 + c1 + c2 + c3;
       sync();
@@ -410,7 +449,7 @@ struct DevX {
     for (int it = 0; it < rounds; ++it) {
       const int s = first + it * 64 + lane;
       const bool f = s < S && pred(s);
-      cnt += __popcll(__ballot(f));
+      cnt += __popcll(CTC_BALLOT(f));
       if (f && it < 64) flags |= 1ull << it;
     }
     if (lane == 0) row[wave] = cnt;
@@ -423,7 +462,7 @@ struct DevX {
     for (int it = 0; it < rounds; ++it) {
       const int s = first + it * 64 + lane;
       const bool f = it < 64 ? ((flags >> it) & 1ull) != 0ull : (s < S && pred(s));
-      const unsigned long long m = __ballot(f);
+      const unsigned long long m = CTC_BALLOT(f);
       if (f) emit(base + CTC_BELOW(m), s);
       base += __popcll(m);
     }
@@ -447,7 +486,7 @@ struct DevX {
       const int cv = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) + ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));
       const int incl = wave_scan(cv, 0, [](int a, int b) { return a + b; });
       const int total = __builtin_amdgcn_readlane(incl, 63);
-      const unsigned long long m = __ballot(incl >= need);
+      const unsigned long long m = CTC_BALLOT(incl >= need);
       if (m == 0ull) {
         if (lane == 0) { out[0] = -1; out[1] = 0; out[2] = total; out[3] = 0; }
       } else {
@@ -456,7 +495,7 @@ struct DevX {
         const int above_c = __builtin_amdgcn_readlane(incl, l1) - __builtin_amdgcn_readlane(cv, l1);
         const int fv = lane < 16 ? bins[cstar * 16 + (15 - lane)] : 0;  // its 16 fine buckets, top one in lane 0
         const int fincl = wave_scan(fv, 0, [](int a, int b) { return a + b; }) + above_c;
-        const unsigned long long mf = __ballot(lane < 16 && fincl >= need);
+        const unsigned long long mf = CTC_BALLOT(lane < 16 && fincl >= need);
         const int l2 = __ffsll((long long)mf) - 1;
         if (lane == l2) { out[0] = cstar * 16 + (15 - lane); out[1] = fincl - fv; out[2] = total; out[3] = fv; }
       }

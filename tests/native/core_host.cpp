@@ -19,6 +19,7 @@
 namespace {
 
 struct HostX {
+  static constexpr bool kZeroKeyTail = false;  // (the listing pass below tests its bounds)
   bool far_ = false;  // the workspace layout under test keeps the exact-replay arrays "far" (CTC_HOST_BIG)
   bool far() const { return far_; }
   int tid() const { return 0; }
@@ -61,6 +62,7 @@ struct HostX {
   }
   int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
   void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
+  uint32_t bitsel(uint32_t mask, uint32_t a, uint32_t b) const { return (a & mask) | (b & ~mask); }
   int sum8(int v) const { return v; }
   void fence_system() const {}
   int load_system(const int *p) const { return *p; }
@@ -84,6 +86,7 @@ struct HostX {
     for (int s = 0; s < S; ++s)
       if (pred(s)) bitmap[s >> 5] |= 1u << (s & 31);
   }
+  template <bool TZ = false>
   void list_bucket(int S, const uint32_t *skey, uint32_t b32, uint32_t bspan, bool direct, uint32_t *bitmap, uint32_t *list, int *lslot,
                    int *lcount) {
     for (int wd = 0; wd < 2 * ((S + 63) / 64); ++wd) bitmap[wd] = 0;
