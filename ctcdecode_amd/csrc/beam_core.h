@@ -436,12 +436,14 @@ struct Decoder {
 
   CTC_HD float lse(float a, float b) const { return ctcmath::lse(a, b, tbl); }
 
-  // "The tail is zero": in identity mode without a scorer the number of slots S = n (1 + V) never shrinks while an utterance
-  // is decoded (n only grows, the blank is always a candidate), and a frame writes every slot below S.  The fixed-layout
+  // "The tail is zero": in identity mode the blank is always a candidate, so the number of slots is S = n (1 + V), and
+  // without a scorer n only grows while an utterance is decoded; a frame writes every slot below S.  The fixed-layout
   // kernels therefore keep the slot keys from S to the end of their block at zero -- cleared once (init / load_state), and
   // again after an exact replay that used the block as its staging area -- and the select's listing pass reads its keys
   // without bounds tests (decode_kernel.h list_bucket).  Only where the execution policy asks for it (the GPU).
-  static constexpr bool kTailZero = IDENT && SMALLV && !LM && !LAZY && X::kZeroKeyTail;
+  // With a scorer S can shrink (candidates are cut, the beam may not fill): the keys between the next frame's S and this
+  // frame's are then cleared after the frame's closing barrier (step()).
+  static constexpr bool kTailZero = IDENT && SMALLV && !LAZY && X::kZeroKeyTail;
   CTC_HD void zero_key_tail(int from) {
     if (!kTailZero) return;
     for (int i = from + x.tid(); i < kSmallK * (2 + kSmallV); i += x.nt()) w.skey[i] = 0u;  // (the fixed layout's block: carve)
@@ -1609,6 +1611,11 @@ struct Decoder {
     x.mark(7);
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
     x.mark(9);
+    if (kTailZero && LM) {  // (the emission has read its survivors' keys: nothing looks at this frame's slots any more)
+      const int S_next = n_new * (2 + Vnb);
+      if (CTC_RARE(S_next < S))
+        for (int i = S_next + tid; i < S; i += nt) w.skey[i] = 0u;
+    }
     // every thread advances its copy of the step state
     {
       // next select window.  It is anchored at this step's best key (an upper bound for the next step's keys when
