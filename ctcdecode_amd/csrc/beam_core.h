@@ -1134,7 +1134,7 @@ struct Decoder {
     //  n-gram look-up here -- the look-up's cost in phase A2 is its arithmetic and its later levels, not the first round
     //  trip; and spreading the pending entries over all idle waves -- every wave then pays the set-up.)
     const bool lm_job = LM && !lm_char_();
-    const int lm_joff = nt >= 2 * ((n + 63) & ~63) ? ((n + 63) & ~63) : 0;
+    const int lm_joff = (SMALLV && x.nt_is(1024)) ? kSmallK : nt >= 2 * ((n + 63) & ~63) ? ((n + 63) & ~63) : 0;
     int lm_jk = -1;
     ctclm::DictNode lm_jinfo;
     if (lm_job) {
@@ -1229,7 +1229,7 @@ struct Decoder {
     // ---- B: score every candidate, lay it out in DFS (Euler-tour) slot order and count it into the select histogram.
     // B1 (beam entries themselves + revived children) and B2 (brand-new children) are independent: with enough
     // waves they run side by side on disjoint threads.
-    const int n1 = (n + 63) & ~63;
+    const int n1 = (SMALLV && x.nt_is(1024)) ? kSmallK : (n + 63) & ~63;  // (fixed-layout class: two entry waves, a compile-time split)
     const bool split = nt - n1 >= 128;
     if (!split || tid < n1) {
       const float lp_blank = brank >= 0 ? w.clp[brank] : CTC_NEG_MAX;
@@ -1474,7 +1474,10 @@ struct Decoder {
       x.sync();
     }
     {
-      const int ne = (n_new + 63) & ~63;
+      // (fixed-layout class at its usual 1024 threads: at most 128 survivors -- two waves per role, whatever their number:
+      //  the role of a thread, the number of roles and the threads left for the resets are then compile-time facts instead
+      //  of two dozen scalar instructions every wave executes before its first load)
+      const int ne = (SMALLV && x.nt_is(1024)) ? kSmallK : (n_new + 63) & ~63;
       // (wide beams: the workgroup has two sets of waves per survivor, not three: LCP + structure || probabilities [+ scorer state])
       const bool two = !SMALLV && nt < 3 * ne && nt >= 2 * ne;
       const bool roles = nt >= 3 * ne || two;

@@ -77,6 +77,7 @@ struct DevX {
   }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
   __device__ __forceinline__ int nt() const { return NT ? NT : (int)blockDim.x; }
+  __device__ __forceinline__ constexpr bool nt_is(int v) const { return NT == v; }  // the workgroup size is this compile-time value
   __device__ __forceinline__ constexpr bool far() const { return FAR; }  // part of the workspace lives in HBM
   // LDS-only barrier: waits for this wave's LDS traffic, not for outstanding global loads/stores (the row prefetch
   // and the pool appends stay in flight across phases).  sync_full() is the fence that also drains global memory.

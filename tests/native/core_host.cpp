@@ -24,6 +24,7 @@ struct HostX {
   bool far() const { return far_; }
   int tid() const { return 0; }
   int nt() const { return 1; }
+  constexpr bool nt_is(int) const { return false; }
   void sync() {}
   void sync_full() {}
   int uni(int v) const { return v; }
