@@ -869,11 +869,12 @@ struct Decoder {
   // of them (VAR_TAU), G = gsum + #bucket keys above tau, E = #keys equal to tau.  `direct` (first round only): the
   // listing pass also records, one bit per slot, every key ABOVE the bucket, and the ranking threads add the bucket's
   // own survivors, so the caller only has to expand the bitmap.  inb = #keys in the bucket (<= kListCap).
+  template <bool COMPACT = false>
   CTC_HD void rank_bucket(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb) {
     const int tid = x.tid(), nt = x.nt();
     CTC_ASSUME(inb >= 1 && inb <= kListCap);
     // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
-    x.template list_bucket<kTailZero>(S, w.skey, b32, bspan, direct, w.bitmap, w.list, w.lslot, &pv[P_LCOUNT]);
+    x.template list_bucket<kTailZero, COMPACT>(S, w.skey, b32, bspan, direct, w.bitmap, w.list, w.lslot, &pv[P_LCOUNT]);
     for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
     x.sync();
     x.mark(14);
@@ -946,7 +947,7 @@ struct Decoder {
         else { gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
       }
       if (!again) {  // exact rank inside the bucket, on offsets from its base
-        rank_bucket(S, pv, (uint32_t)blo, (uint32_t)(bhi - blo - 1), first, need - above, gbase + above, inb);
+        rank_bucket<true>(S, pv, (uint32_t)blo, (uint32_t)(bhi - blo - 1), first, need - above, gbase + above, inb);
         return first;
       }
       // another histogram round over [lo, hi)

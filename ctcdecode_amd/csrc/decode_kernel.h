@@ -303,7 +303,9 @@ struct DevX {
     }
 #undef CTC_BELOW
   }
-  template <bool TZ = false>
+  // COMPACT: the rare callers (the select's fallback rounds) take one round at a time -- one small copy of the code
+  // instead of another set of straight-line instantiations in a kernel that lives in a 64 KB instruction cache.
+  template <bool TZ = false, bool COMPACT = false>
   __device__ __forceinline__ void list_bucket(int S, const uint32_t *skey, uint32_t b32, uint32_t bspan, bool direct, uint32_t *bitmap,
                                               uint32_t *list, int *lslot, int *lcount) {
     const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
@@ -312,12 +314,15 @@ struct DevX {
     const int first = wave * rounds * 64;
     // four rounds at a time, straight-line: their keys are requested together (one LDS round trip), and one returning
     // atomic reserves the list space of all four.  (Wide beams take several such groups: 15 rounds at beam 500.)
-    if (TZ && rounds <= 4) {  // the usual shapes: one group, no bounds tests
+    if (!COMPACT && TZ && (rounds == 3 || rounds == 4)) {  // the usual shapes: one group, no bounds tests
       uint32_t *bmw = bitmap + 2 * (wave * rounds);
       if (rounds == 3) list_group<3, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
-      else if (rounds == 4) list_group<4, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
-      else if (rounds == 2) list_group<2, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
-      else list_group<1, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
+      else list_group<4, true>(S, skey, first + lane, b32, bspan, direct, bmw, list, lslot, lcount);
+      return;
+    }
+    if (COMPACT || TZ) {
+      for (int r0 = 0; r0 < rounds; ++r0)
+        list_group<1, false>(S, skey, first + r0 * 64 + lane, b32, bspan, direct, bitmap + 2 * (wave * rounds + r0), list, lslot, lcount);
       return;
     }
     for (int r0 = 0; r0 < rounds; r0 += 4) {

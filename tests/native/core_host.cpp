@@ -87,7 +87,7 @@ struct HostX {
     for (int s = 0; s < S; ++s)
       if (pred(s)) bitmap[s >> 5] |= 1u << (s & 31);
   }
-  template <bool TZ = false>
+  template <bool TZ = false, bool COMPACT = false>
   void list_bucket(int S, const uint32_t *skey, uint32_t b32, uint32_t bspan, bool direct, uint32_t *bitmap, uint32_t *list, int *lslot,
                    int *lcount) {
     for (int wd = 0; wd < 2 * ((S + 63) / 64); ++wd) bitmap[wd] = 0;
