@@ -428,28 +428,10 @@ struct DevX {
     const int first = wave * rounds * 64;
     int *row = red + parity * 16;
     parity ^= 1;
-    if (rounds <= 4) {  // common case: straight-line code, the four slots' predicates evaluated together
-      const int s0 = first + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
-      const bool f0 = s0 < S && pred(s0);
-      const bool f1 = rounds > 1 && s1 < S && pred(s1);
-      const bool f2 = rounds > 2 && s2 < S && pred(s2);
-      const bool f3 = rounds > 3 && s3 < S && pred(s3);
-      const unsigned long long m0 = CTC_BALLOT(f0), m1 = CTC_BALLOT(f1), m2 = CTC_BALLOT(f2), m3 = CTC_BALLOT(f3);
-      const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
-      if (lane == 0) row[wave] = c0 + c1 + c2 + c3;
-      sync();
-      int tot = lane < nw ? row[lane] : 0;
-      tot += CTC_DPP(0, tot, 0x111, 0xf); tot += CTC_DPP(0, tot, 0x112, 0xf);
-      tot += CTC_DPP(0, tot, 0x114, 0xf); tot += CTC_DPP(0, tot, 0x118, 0xf);
-      const int base = wave > 0 ? __builtin_amdgcn_readlane(tot, wave - 1) : 0;
+    // (one general form: since the select hands over a bitmap this compaction only runs on the rare paths -- ties resolved by
+    //  character, the exact replay's candidate list -- and a straight-line special case for few rounds was 2 KB of code
+    //  in the frame loop of every kernel)
 #define CTC_BELOW(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
-      if (f0) emit(base + CTC_BELOW(m0), s0);
-      if (f1) emit(base + c0 + CTC_BELOW(m1), s1);
-      if (f2) emit(base + c0 + c1 + CTC_BELOW(m2), s2);
-      if (f3) emit(base + c0 + c1 + c2 + CTC_BELOW(m3), s3);
-      sync();
-      return;
-    }
     unsigned long long flags = 0ull;
     int cnt = 0;
     for (int it = 0; it < rounds; ++it) {
