@@ -1381,6 +1381,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if (d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the widest-beam layout");
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false>;
   }
+  if (!d->profile && big && far_level == 1 && threads == 1024)  // wide beams at the usual workgroup size: folded into the code as well
+    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 1, 0, true, 1024> : (const void *)ctc_beam_decode_kernel<0, 1, 0, false, 1024>;
   if (!d->profile && fixed && !big && threads == 1024)  // the usual case: workgroup size folded into the code
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
   if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, false, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
