@@ -166,7 +166,7 @@ constexpr int kExpress = 32;
 // how often a frame takes the paths that are rare on random input and common on beams shaped by a dictionary or by
 // peaky acoustic posteriors.
 enum Event { EV_FRAMES, EV_CANDIDATES, EV_EXACT, EV_INTERNAL, EV_PINNED, EV_LPC_UPDATE, EV_DEAD_PARENT, EV_REVIVE_CAND, EV_REVIVED, EV_WALK,
-             EV_WALK_HOPS, EV_COUNT };
+             EV_WALK_HOPS, EV_FAST_SELECT, EV_SINGLE_KEY, EV_BUCKET_KEYS, EV_COUNT };
 
 struct Work {
   // The beam is double-buffered: step t reads the copy of parity p and writes the other one.  cur / nxt are re-derived
@@ -920,6 +920,7 @@ struct Decoder {
     if (CTC_USUAL(fb[0] >= 0 && fb[3] <= kListCap && (wd.shift != 0 || fb[0] == kBins - 1))) {
       const uint32_t b32 = wd.lo + ((uint32_t)fb[0] << wd.shift);
       const uint32_t bspan = fb[0] == kBins - 1 ? 0xFFFFFFFFu - b32 : (1u << wd.shift) - 1u;
+      if (tid == 0) { x.count(EV_FAST_SELECT, 1); x.count(EV_BUCKET_KEYS, fb[3]); if (fb[3] == 1) x.count(EV_SINGLE_KEY, 1); }
       rank_bucket(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3]);
       return true;
     }

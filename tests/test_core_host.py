@@ -67,6 +67,9 @@ def _edge_cases():
     lp[:, 1::3, 3] = -1e-40
     lp[1, :, 0] = -0.0
     yield "signed_zeros_and_positive_values", lp, dict(beam=16)
+    # every log-probability -0.0: sums of a prefix score and a log-probability are then never -0 (the score is not), which
+    # is what lets the child-scoring loop skip the zero canonicalisation of its keys (beam_core.h ord_f32_raw)
+    yield "all_negative_zero", np.full((2, 25, 7), np.float32(-0.0), np.float32), dict(beam=24)
 
 
 EDGE = list(_edge_cases())

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 NAMES = ["frames", "candidates", "exact replays", "entries with in-beam descendants", "entries whose parent is in the beam",
          "pool updates of a label probability", "entries below a dead interior node", "revival candidates", "revived nodes that survive",
-         "pool walks", "hops of those walks"]
+         "pool walks", "hops of those walks", "selects on the fast path", "... whose bucket holds a single key", "keys in the K-th key's bucket"]
 
 
 def main():
