@@ -881,8 +881,12 @@ struct Decoder {
     // a long list (wide beams: up to kListCap keys share the bucket) is ranked by eight lanes per key, each comparing an
     // eighth of the list; a short one by one lane per key
     const bool wide_rank = !SMALLV && inb > 32 && nt >= 8 * kListCap;
-    for (int q0 = tid; q0 < (wide_rank ? 8 * kListCap : inb); q0 += nt) {
-      const int q = wide_rank ? q0 >> 3 : q0, part = wide_rank ? q0 & 7 : 0, stride = wide_rank ? 32 : 4;
+    // (fixed-layout class at 1024 threads: four lanes per key, each comparing a quarter of the list -- some twenty keys share
+    //  the bucket on ordinary input, and the ranking is a single-wave stage: five rounds of loads and compares become two)
+    const bool quad_rank = SMALLV && !COMPACT && x.nt_is(1024);
+    const int psh = wide_rank ? 3 : quad_rank ? 2 : 0;
+    for (int q0 = tid; q0 < (wide_rank ? 8 * kListCap : inb << psh); q0 += nt) {
+      const int q = q0 >> psh, part = q0 & ((1 << psh) - 1), stride = 4 << psh;
       const uint32_t mine = q < inb ? w.list[q] : 0u;
       int g = 0, e = 0;
       for (int r = 4 * part; r < inb; r += stride) {
@@ -893,6 +897,9 @@ struct Decoder {
       if (wide_rank) {
         g = x.sum8(g); e = x.sum8(e);
         if (part != 0 || q >= inb) continue;
+      } else if (quad_rank) {
+        g = x.sum4(g); e = x.sum4(e);
+        if (part != 0) continue;
       }
       if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
         w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gsum + g; w.vars[VAR_E] = e;
@@ -1218,7 +1225,15 @@ struct Decoder {
       w.revr[j] = rr;
       npin += pr >= 0;
     }
-    if (x.group() * x.lanes() < n) x.wave_add(&pv[P_NPIN], npin);  // (the other waves had no entry: skip the reduction)
+    // (the other waves had no entry: skip the reduction; with at most one entry per thread the count is a ballot's population)
+#if defined(CTC_EXP_NO_FLAGCOUNT)
+    if (x.group() * x.lanes() < n) x.wave_add(&pv[P_NPIN], npin);
+#else
+    if (x.group() * x.lanes() < n) {
+      if (SMALLV && x.nt_is(1024)) x.wave_add_flag(&pv[P_NPIN], npin != 0);
+      else x.wave_add(&pv[P_NPIN], npin);
+    }
+#endif
     if (lm_job && tid >= lm_joff) {
       if (lm_jk >= 0) lm_resolve_entry(b, lm_jk, lm_jinfo);
       for (int k = tid - lm_joff + (nt - lm_joff); k < n; k += nt - lm_joff)  // (workgroups with fewer threads than entries)

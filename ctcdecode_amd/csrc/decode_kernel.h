@@ -208,6 +208,17 @@ struct DevX {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
     return v;
   }
+  // sum over the aligned group of four lanes this lane belongs to (two quad permutes; the whole quad must be active)
+  __device__ __forceinline__ int sum4(int v) const {
+    v += CTC_DPP(0, v, 0xB1, 0xf);  // quad_perm:[1,0,3,2]
+    v += CTC_DPP(0, v, 0x4E, 0xf);  // quad_perm:[2,3,0,1]
+    return v;
+  }
+  // *p += number of lanes of this wave whose flag is set: a ballot's population, one LDS atomic
+  __device__ __forceinline__ void wave_add_flag(int *p, bool f) {
+    const int c = __popcll(CTC_BALLOT(f));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(p, c);
+  }
   // one LDS atomic per wave
   __device__ __forceinline__ void wave_add(int *p, int v) {
     v = wave_sum(v);

@@ -65,6 +65,8 @@ struct HostX {
   void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
   uint32_t bitsel(uint32_t mask, uint32_t a, uint32_t b) const { return (a & mask) | (b & ~mask); }
   int sum8(int v) const { return v; }
+  int sum4(int v) const { return v; }
+  void wave_add_flag(int *p, bool f) { *p += f ? 1 : 0; }
   void fence_system() const {}
   int load_system(const int *p) const { return *p; }
   void nap() const {}
