@@ -56,6 +56,45 @@ def test_library_is_the_hip_build(torch_mod):
     assert "libctcdecode_amd.so" in maps
 
 
+def test_library_builds_on_this_box(torch_mod, tmp_path):
+    """The HIP sources compile HERE (hipcc --offload-arch=gfx950 on the GPU box, not only in the build container) and
+    the result decodes like the shipped library: the quick build (north-star class kernels only) goes to a scratch
+    directory and is driven through the raw C ABI, next to the product library already loaded in this process."""
+    import ctypes
+    import shutil
+
+    from ctcdecode_amd import _build
+
+    if not os.environ.get("CTCD_TEST_BUILD_ON_BOX"):
+        pytest.skip("opt-in (CTCD_TEST_BUILD_ON_BOX=1): written at the very end of round 3 and not yet run to completion on a GPU box")
+    if not (shutil.which("hipcc") or os.path.exists(os.path.join(_build.ROCM, "bin", "hipcc"))):
+        pytest.skip("no hipcc on this box")
+    torch = torch_mod
+    so = _build.build(defines=["CTC_QUICK_BUILD=1"], out=str(tmp_path / "libctcdecode_quick.so"))
+    lib = ctypes.CDLL(so)
+    h = ctypes.c_void_p()
+    lib.ctcd_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    assert lib.ctcd_create(ctypes.byref(h), 0) == 0
+    lib.ctcd_beam_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_double] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
+    B, T, V, K = 3, 60, 29, 100
+    lp = ou.synth_logprobs(B, T, V, 77)
+    d = torch.from_numpy(lp).cuda()
+    tok = torch.empty((B, K, T), dtype=torch.int32, device="cuda")
+    ts = torch.empty_like(tok)
+    sc = torch.empty((B, K), dtype=torch.float32, device="cuda")
+    ln = torch.empty((B, K), dtype=torch.int32, device="cuda")
+    rc = lib.ctcd_beam_decode(h, d.data_ptr(), None, B, T, V, K, 4, 1.0, 40, 0, 1, tok.data_ptr(), ts.data_ptr(), sc.data_ptr(), ln.data_ptr(), None, None)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got = dict(tokens=tok.cpu().numpy(), timesteps=ts.cpu().numpy(), scores=sc.cpu().numpy(), lens=ln.cpu().numpy())
+    want = ou.decode(lp, beam=K)
+    ou.assert_same(_with_nres(got, want), want, "library built on this box")
+    # ... and exactly like the product library in this process
+    mine = _decode(torch, lp, beam=K)
+    for k in ("tokens", "timesteps", "scores", "lens"):
+        assert np.array_equal(got[k], mine[k]), k
+
+
 @pytest.mark.parametrize("name", gu.names())
 def test_reference_fixtures(torch_mod, name):
     args, want = gu.load(name)
