@@ -4,7 +4,7 @@
 REPS=$1; shift
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/v
 L=""; for v in "$@"; do L="$L ctcdecode_amd/_lib/var_$v.so"; done
-python tools/raw_multi.py 256 1000 29 100 $REPS $L
+python tools/raw_multi.py ${SHAPE:-256 1000 29 100} $REPS $L $EXTRA   # SHAPE="B T V beam"; EXTRA="--lm tests/data/test.arpa" / "--cu-sharing 1"
 if [ -n "$TIMELINE" ]; then
 for v in $TIMELINE; do
 CTCDECODE_AMD_LIB=$GRAFT_REPO_ROOT/ctcdecode_amd/_lib/var_$v.so python tools/barrier_timeline.py --repeat 3 --frames 4 --out gpurun_out/v/tl_$v.json > gpurun_out/v/tl_$v.log 2>&1
