@@ -152,11 +152,20 @@ enum {
                // select's result so that phase C reads it for free.
   VAR_PAR0 = 12,  // first per-parity set
   P_NPIN = 0, P_LCOUNT, P_NMAXKEY, P_NMINKEY, P_NCAND, P_SIZE = 8,
-  VAR_COUNT = VAR_PAR0 + 2 * P_SIZE
+  // speculative select (Decoder::kSpec), kept by ONE thread (X::spec_thread) -- every instruction all sixteen waves execute
+  // costs sixteen clocks of the frame: the frame's threshold key, the estimate of the best candidate score it was derived
+  // from, the safety margin, the observed distance best -> K-th (float bits), the largest log-probability of the staged row,
+  // "the prediction is valid"
+  // "the prediction is valid", and the histogram window of the frames that fall back (its log2 width, the key it is anchored at)
+  VAR_SPEC = VAR_PAR0 + 2 * P_SIZE, SP_THR = 0, SP_BEST, SP_MARGIN, SP_GAP, SP_ROWMAX, SP_PRED, SP_WLOG, SP_ANCHOR,
+  VAR_ROWMAX = VAR_SPEC + SP_ROWMAX,
+  VAR_COUNT = VAR_SPEC + 8
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
 constexpr int kBinsLog = 10;
 constexpr int kListCap = 128;   // exact-rank list (one bucket's keys)
+constexpr int kSmallK = 128, kSmallV = 32;  // the class of shapes of the fixed workspace layout (SMALLV below)
+constexpr int kHotCap = 256;    // speculative select (Decoder::kSpec): capacity of the frame's hot list (keys at or above the predicted threshold)
 constexpr int kSerialCut = 24;  // introselect ranges at most this long are finished by one lane
 // Express pointers for the final back-trace: every pool node X (depth d >= 1) also records up(X) = its ancestor at
 // depth ((d - 1) / kExpress) * kExpress, so a label sequence of length d is read back as d / kExpress + 1 independent
@@ -166,7 +175,7 @@ constexpr int kExpress = 32;
 // how often a frame takes the paths that are rare on random input and common on beams shaped by a dictionary or by
 // peaky acoustic posteriors.
 enum Event { EV_FRAMES, EV_CANDIDATES, EV_EXACT, EV_INTERNAL, EV_PINNED, EV_LPC_UPDATE, EV_DEAD_PARENT, EV_REVIVE_CAND, EV_REVIVED, EV_WALK,
-             EV_WALK_HOPS, EV_FAST_SELECT, EV_SINGLE_KEY, EV_BUCKET_KEYS, EV_COUNT };
+             EV_WALK_HOPS, EV_FAST_SELECT, EV_SINGLE_KEY, EV_BUCKET_KEYS, EV_SPEC_OK, EV_SPEC_UNDER, EV_SPEC_OVER, EV_SPEC_OTHER, EV_SPEC_HOT, EV_COUNT };
 
 struct Work {
   // The beam is double-buffered: step t reads the copy of parity p and writes the other one.  cur / nxt are re-derived
@@ -265,8 +274,10 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.rank_of = carve_ptr<int16_t>(p, d.use_rank_table ? (size_t)d.V : 0);
   w.skey = carve_ptr<uint32_t>(deep ? q : p, S);
   w.surv = carve_ptr<int>(p, 3 * K + 4);
-  w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, kListCap + 4);
-  w.lslot = carve_ptr<int>(p, kListCap + 4); w.bitmap = carve_ptr<uint32_t>(huge ? q : p, 2 * ((S + 63) / 64 + 17));
+  // (the fixed-layout class also uses the two lists as the hot list of the speculative select: kHotCap entries + padding)
+  const size_t lcap = (d.K <= kSmallK && d.Vc_max <= kSmallV) ? (size_t)kHotCap + 64 : (size_t)kListCap + 4;
+  w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, lcap);
+  w.lslot = carve_ptr<int>(p, lcap); w.bitmap = carve_ptr<uint32_t>(huge ? q : p, 2 * ((S + 63) / 64 + 17));
   w.wpre = huge ? carve_ptr<uint32_t>(q, (S + 63) / 64 + 2) : reinterpret_cast<uint32_t *>(w.bins);
   w.fin = carve_ptr<int>(BIG ? q : p, K);  // (last / exact / danger frames and finish() only: HBM scratch in the wide-beam layouts)
   w.apos = carve_ptr<int>(BIG ? q : p, K);  // (read in danger mode only: HBM scratch in the wide-beam layouts)
@@ -380,7 +391,6 @@ struct FullSyncView {
 // them in one instantiation makes the compiler wait for the prefetch where the other mode's registers are written.
 // SMALLV: the caller guarantees beam <= kSmallK and at most kSmallV labels (the class of shapes of the fixed workspace
 // layout): the paths for larger candidate sets are compiled out and the bounds are told to the optimiser.
-constexpr int kSmallK = 128, kSmallV = 32;
 #if defined(CTC_ASSUME_CHECKED)  // the host build of the tests verifies every assumption instead of exploiting it
 #define CTC_ASSUME(c) do { if (!(c)) { std::fprintf(stderr, "beam_core.h:%d: assumption violated: %s\n", __LINE__, #c); std::abort(); } } while (0)
 #elif defined(__clang__)
@@ -447,6 +457,57 @@ struct Decoder {
   CTC_HD void zero_key_tail(int from) {
     if (!kTailZero) return;
     for (int i = from + x.tid(); i < kSmallK * (2 + kSmallV); i += x.nt()) w.skey[i] = 0u;  // (the fixed layout's block: carve)
+  }
+
+  // ---- speculative select (round 4) -----------------------------------------------------------------------------------
+  // The K-th best key moves with the best key from frame to frame, so the frame PREDICTS it: threshold = (best score of the
+  // beam + the row's largest log-probability) - (that same quantity minus the K-th best score, as observed in the previous
+  // frame) - margin.  While the candidates are scored (phase B) every key at or above the threshold is appended to a short
+  // "hot list" (one wave-aggregated LDS atomic per pass) INSTEAD of being counted into the 1024-bucket histogram.  If the
+  // list then holds H keys with K <= H <= kHotCap, the K best candidates are all in it -- whatever the threshold was: a key
+  // outside the list is below every key inside -- and one all-pairs ranking of the list by the whole workgroup gives the
+  // exact K-th key, says whether equal keys straddle the boundary, and marks the survivors; a prefix count over the
+  // survivor bitmap puts them in slot (= DFS) order.  The histogram, the bucket search, the re-scan of all S slots, the
+  // single-wave ranking and the single-wave bitmap expansion of the histogram select (five barriers, three single-wave
+  // stages) become two all-wave stages and two barriers.  Everything else -- too few or too many hot keys, ties at the
+  // boundary, the last frame, danger mode -- falls back to the histogram select, which first has to build its histogram
+  // (rehistogram()): same survivors either way, by construction.
+  static constexpr bool kSpec = IDENT && SMALLV && !LM && !LAZY && X::kSpecSelect;
+  // ONE thread (X::spec_thread), between the barriers of phases A1 and A2 (where its wave has nothing else to do): what the
+  // previous frame observed -- its K-th key st_tau, the size of its hot list st_hot -- becomes this frame's threshold
+  // SP_THR, which everyone reads behind phase A2's barrier.  The best key of the previous frame's survivors is still in that
+  // frame's per-parity counters (P_NMAXKEY: they are reset during THIS frame's emission).
+  bool st_sel = false;       // the previous frame selected (N > K): st_tau / st_hot are valid
+  uint32_t st_tau = 0;
+  int st_hot = 0;
+  CTC_HD void spec_update(int t, int K) const {
+    int *sp = w.vars + VAR_SPEC;
+    const int pred = sp[SP_PRED];
+    const float best_prev = ctcmath::bits_to_f32((uint32_t)sp[SP_BEST]), rowmax = ctcmath::bits_to_f32((uint32_t)sp[SP_ROWMAX]);
+    float margin = ctcmath::bits_to_f32((uint32_t)sp[SP_MARGIN]), gap = ctcmath::bits_to_f32((uint32_t)sp[SP_GAP]);
+    const uint32_t anchor = (uint32_t)sp[SP_ANCHOR], mk = (uint32_t)pvars(t - 1)[P_NMAXKEY];
+    int wl = 32;
+    if (st_sel) {
+      gap = best_prev - unord_f32(st_tau);
+      // too few hot keys: widen the margin; many more than needed: narrow it (the ranking's cost grows with their square)
+      if (pred) {
+        if (st_hot < K) margin = margin < 32.f ? margin * 2.f : margin;
+        else if (st_hot > K + (K >> 1) + 10) margin = margin > 0.001f ? margin * 0.8125f : margin;
+      }
+      // the window of a frame that falls back to the histogram select: anchored at the best key, reaching twice as far down
+      // as the previous frame's K-th key lay below ITS anchor, rounded up to a power of two (as the histogram select keeps it)
+      const uint32_t kgap = anchor > st_tau ? anchor - st_tau : 0u;
+      wl = (kgap ? 32 - __builtin_clz(kgap) : 0) + 1;
+      wl = wl < kBinsLog ? kBinsLog : (wl > 32 ? 32 : wl);
+    }
+    const float best = unord_f32(mk) + rowmax;
+    uint32_t k = 0xFFFFFFFFu;  // no prediction: nothing is hot, the frame goes the histogram way
+    if (st_sel) {
+      k = ord_f32(best - gap - margin);
+      k = k ? k : 1u;  // (holes have key 0 and are never hot)
+    }
+    sp[SP_THR] = (int)k; sp[SP_BEST] = (int)ctcmath::f32_to_bits(best); sp[SP_MARGIN] = (int)ctcmath::f32_to_bits(margin);
+    sp[SP_GAP] = (int)ctcmath::f32_to_bits(gap); sp[SP_PRED] = st_sel ? 1 : 0; sp[SP_WLOG] = wl; sp[SP_ANCHOR] = (int)mk;
   }
 
   // Step-to-step state, identical in every thread (kept in registers, not LDS)
@@ -689,6 +750,8 @@ struct Decoder {
     if (d.use_rank_table)
       for (int c = x.tid(); c < d.V; c += x.nt()) w.rank_of[c] = -1;
     zero_key_tail(0);
+    if (kSpec) x.sync();  // (thread 0's resets above come before the ones spec_reset adds)
+    spec_reset(0);
     x.sync_full();
   }
 
@@ -726,6 +789,8 @@ struct Decoder {
     if (d.use_rank_table)
       for (int c = tid; c < d.V; c += nt) w.rank_of[c] = -1;
     zero_key_tail(0);
+    if (kSpec) x.sync();
+    spec_reset(x.uni(ss.hdr[SH_FRAMES]));
     x.sync_full();
   }
   CTC_HD void save_state(const StreamState &ss, int frames) {
@@ -744,6 +809,11 @@ struct Decoder {
       }
     }
     if (tid == 0) {
+      if (kSpec) {  // (the window state is kept in LDS by one thread: beam_core.h spec_update; one frame stale at most, which
+                    //  only ever costs time -- the select is exact for any window)
+        st_wlog = w.vars[VAR_SPEC + SP_WLOG];
+        st_maxkey = (uint32_t)pvars(frames - 1)[P_NMAXKEY];
+      }
       ss.hdr[SH_FRAMES] = frames; ss.hdr[SH_N] = st_n; ss.hdr[SH_POOL] = st_pool; ss.hdr[SH_WLOG] = st_wlog;
       ss.hdr[SH_MAXKEY] = (int)st_maxkey; ss.hdr[SH_MINKEY] = (int)st_minkey;
       ss.hdr[SH_DANGER] = w.vars[VAR_DANGER];
@@ -857,6 +927,34 @@ struct Decoder {
       x.atomic_add(&w.bins[bb], 1);  // (one LDS atomic per candidate: a second, coarse level of counters kept by atomics as
                                      //  well cost 2.5 % of the frame -- many lanes hit the same few coarse words)
     }
+  }
+
+  // start of an utterance / of a stream's chunk: no prediction yet, empty hot list, clear survivor bitmap
+  CTC_HD void spec_reset(int t0) {
+    if (!kSpec) return;
+    st_sel = false; st_tau = 0; st_hot = 0;
+    if (x.tid() == 0) {
+      int *sp = w.vars + VAR_SPEC;
+      sp[SP_THR] = -1; sp[SP_BEST] = 0; sp[SP_MARGIN] = (int)ctcmath::f32_to_bits(0.125f); sp[SP_GAP] = 0; sp[SP_PRED] = 0;
+      sp[SP_WLOG] = st_wlog; sp[SP_ANCHOR] = (int)st_maxkey;
+      w.vars[VAR_G] = 0;  // (the hot list's length is counted in the select's result group: one read gives it and the danger flag)
+      // (the first frame finds "the previous frame's best key" where every later one does: in the counters of the other parity)
+      pvars(t0 - 1)[P_NMAXKEY] = (int)st_maxkey;
+    }
+    for (int i = x.tid(); i < kHotCap + 64; i += x.nt()) w.list[i] = 0u;
+    for (int i = x.tid(); i < 2 * ((kSmallK * (2 + kSmallV) + 63) / 64); i += x.nt()) w.bitmap[i] = 0u;
+  }
+  // The histogram of the frame's keys, for the frames the speculative select hands back: what phase B would have counted.
+  CTC_HD void rehistogram(int S, int *pv, Window &wd) {
+    const int tid = x.tid(), nt = x.nt();
+    st_wlog = x.uni(w.vars[VAR_SPEC + SP_WLOG]);
+    st_maxkey = (uint32_t)x.uni(w.vars[VAR_SPEC + SP_ANCHOR]);
+    wd = first_window();
+    if (tid == 0) pv[P_LCOUNT] = 0;
+    for (int i = tid; i < kBins; i += nt) w.bins[i] = 0;
+    x.sync();
+    for (int s = tid; s < S; s += nt) hist_add(wd, w.skey[s]);
+    x.sync();
   }
 
   // K-th largest SCORE key (32 bit) among the S slots (holes have key 0).  The first-round histogram (window
@@ -1115,7 +1213,8 @@ struct Decoder {
     const bool small_vocab = SMALLV || Vnb <= 64;  // existing children fit a 64-bit mask per parent
     int *pv = pvars(in.t);
     int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
-    const Window wd = first_window();
+    Window wd{1u, 0};
+    if (!kSpec) wd = first_window();
     // LM tier: candidates whose (prefix score + label log-prob) falls below the worst prefix's score plus the blank's
     // log-prob (minus beta) are skipped once the beam is full (ctc_beam_search_decoder.cpp:74-82,93-95).  The prefixes
     // are visited best first there and the loop breaks at the first miss; scores only fall from there on and float
@@ -1191,6 +1290,7 @@ struct Decoder {
     }
     x.tick();
     x.sync();
+    if (kSpec && tid == x.spec_thread()) spec_update(in.t, K);
     // ---- A2: Euler-tour slot offsets; which children of in-beam parents already exist
     int npin = 0;
     for (int j = tid; j < n; j += nt) {
@@ -1242,6 +1342,7 @@ struct Decoder {
     x.sync();
     x.mark(0);
     const int npin_total = pv[P_NPIN];  // final since the barrier above; requested here so that phase C does not wait for it
+    const uint32_t thr = kSpec ? (uint32_t)x.uni(w.vars[VAR_SPEC + SP_THR]) : 0xFFFFFFFFu;  // (written before phase A's barriers)
 
     // ---- B: score every candidate, lay it out in DFS (Euler-tour) slot order and count it into the select histogram.
     // B1 (beam entries themselves + revived children) and B2 (brand-new children) are independent: with enough
@@ -1313,7 +1414,10 @@ struct Decoder {
         w.skey[s0] = k0;
         w.skey[s0 + 1] = k1;
         if (!LAZY) { w.sinfo[s0] = i0; w.sinfo[s0 + 1] = mk_info(c, T_SELF, j); }
-        if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
+        if (kSpec) {
+          x.hot_append(k0 >= thr, k0, s0, w.list, w.lslot, &w.vars[VAR_G]);
+          x.hot_append(k1 >= thr, k1, s0 + 1, w.list, w.lslot, &w.vars[VAR_G]);
+        } else if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
         if (LM && upd_node >= 0) set_node_time(upd_node, c, in.t, upd_lp);
         if (LM && CTC_RARE(upd_xn >= 0)) set_node_time(upd_xn, upd_xc, in.t, upd_xlp);
       }
@@ -1364,7 +1468,8 @@ struct Decoder {
             const int s = cs + rn;
             w.skey[s] = k;
             if (!LAZY) w.sinfo[s] = x.bitsel(live, ci, kHoleInfo);
-            hist_add(wd, k);
+            if (kSpec) x.hot_append(k >= thr, k, s, w.list, w.lslot, &w.vars[VAR_G]);
+            else hist_add(wd, k);
           }
         }
       } else {
@@ -1390,11 +1495,15 @@ struct Decoder {
           const uint32_t k = exists ? 0u : ord_f32(logp);
           w.skey[s] = k;
           if (!LAZY) w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
-          if (small_vocab) hist_add(wd, k);
+          if (kSpec) x.hot_append(k >= thr, k, s, w.list, w.lslot, &w.vars[VAR_G]);
+          else if (small_vocab) hist_add(wd, k);
         }
       }
       if (LM) x.wave_add(&pv[P_NCAND], ncand);
     }
+    // (speculative select: the look at the next frame's row -- see below -- comes before the phase's barrier, because the
+    //  select reads the flag right behind it)
+    if (kSpec && tid < next_cnt) note_lp(next_val);
     x.sync();
     if (!small_vocab) {  // children that already exist leave a hole in their parent's group; then the histogram
       for (int j = tid; j < n; j += nt) {
@@ -1412,8 +1521,9 @@ struct Decoder {
     }
     // the next frame's row (in the caller's prefetch registers since before this frame started: long arrived): a bad value
     // puts the utterance into danger mode from THIS frame's selection on (the barriers of phase C order the store)
-    if (tid < next_cnt) note_lp(next_val);
+    if (!kSpec && tid < next_cnt) note_lp(next_val);
     x.mark(2);
+    x.probe_keys(in.t, S, w.skey, K, kSpec ? (uint32_t)w.vars[VAR_SPEC + SP_ANCHOR] : st_maxkey, w.clp, Vc);  // (host build: statistics of a frame's keys; nothing on the GPU)
 
     // ---- C: the K-th best key.  #candidates = beam entries + new children - children that already exist as entries
     const int N = LM ? x.uni(pv[P_NCAND]) : n * (1 + Vnb) - x.uni(npin_total);
@@ -1422,7 +1532,26 @@ struct Decoder {
     SlotCtx lz;  // LAZY: no info words are stored; whoever needs one derives it from the layout
     if (LAZY) lz = slot_ctx(b, n, Vnb, brank);
     bool keys_in_ord = false;  // the exact replay overwrote w.skey[]: the survivors' keys are in ord[] (by beam position)
-    if (CTC_USUAL(N > K)) {  // ctc_beam_search_decoder.cpp:150
+    bool spec_done = false;    // the speculative select settled the frame: surv[] holds the K survivors in slot order
+    int hot = 0;
+    if (kSpec && CTC_USUAL(N > K)) {
+      int tv0[4];
+      x.uni4(&w.vars[VAR_TAU], tv0);  // [1]: the hot list's length, [3]: the danger flag
+      hot = tv0[1];
+      if (CTC_USUAL(!last && hot >= K && hot <= kHotCap && x.spec_fits(hot) && tv0[3] == 0)) {
+        // -> VAR_TAU = the K-th key, VAR_E = number of keys that rank within the first K (fewer than K: equal keys straddle
+        //    the boundary and nothing was written to surv[]); w.bins[0, kHotCap) is the ranking's scratch (zero on entry)
+        x.spec_select(hot, K, w.list, w.lslot, w.bitmap, w.bins, S, surv, &w.vars[VAR_TAU]);
+        int tv[4];
+        x.uni4(&w.vars[VAR_TAU], tv);
+        spec_done = tv[2] == K;
+        if (CTC_USUAL(spec_done)) tau = (uint32_t)tv[0];
+      }
+      if (CTC_RARE(!spec_done)) rehistogram(S, pv, wd);
+      if (spec_done) x.count(EV_SPEC_HOT, hot);
+      x.count(spec_done ? EV_SPEC_OK : hot < K ? EV_SPEC_UNDER : hot > kHotCap ? EV_SPEC_OVER : EV_SPEC_OTHER, 1);
+    }
+    if (CTC_USUAL(N > K) && !spec_done) {  // ctc_beam_search_decoder.cpp:150
       have_bitmap = select_kth(S, K, pv, wd);
       int tv[4];
       x.uni4(&w.vars[VAR_TAU], tv);
@@ -1445,7 +1574,9 @@ struct Decoder {
     // threshold; when the outcome depends on it, an exact replay of std::nth_element followed by a ranking by slot.
     const int n_new = N < K ? N : K;
     if (tid == 0) { x.count(EV_FRAMES, 1); x.count(EV_CANDIDATES, N); if (exact) x.count(EV_EXACT, 1); }
-    if (CTC_RARE(exact)) {
+    if (CTC_USUAL(kSpec && spec_done)) {
+      x.mark(3);
+    } else if (CTC_RARE(exact)) {
       keys_in_ord = nth_element_order(S, N, K, &lz);
       for (int q = tid; q < K; q += nt) {  // rank by slot
         const int mine = ord[q];
@@ -1512,12 +1643,21 @@ struct Decoder {
         const bool spare = roles && nt > nroles * ne;
         if (!spare || tid >= nroles * ne) {
           const int t0 = spare ? tid - nroles * ne : tid, tstep = spare ? nt - nroles * ne : nt;
-          for (int i = t0; i < kBins; i += tstep) w.bins[i] = 0;
+          if (kSpec) {  // the hot list's keys (its unused tail must read as zero), the ranking's counters (the head of the
+                        // histogram's block; the histogram itself is cleared by the frames that build one: rehistogram) and
+                        // the survivor bitmap
+            for (int i = t0; i < kHotCap + 64; i += tstep) w.list[i] = 0u;
+            for (int i = t0; i < kHotCap; i += tstep) w.bins[i] = 0;
+            for (int i = t0; i < 2 * ((kSmallK * (2 + kSmallV) + 63) / 64); i += tstep) w.bitmap[i] = 0u;
+          } else {
+            for (int i = t0; i < kBins; i += tstep) w.bins[i] = 0;
+          }
           for (int i = t0; i < (SMALLV ? n : 2 * n); i += tstep) w.hit[i] = 0;
           int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;
           for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }
           if (t0 == 0) {
             reset_pvars(pvars(in.t + 1));
+            if (kSpec) w.vars[VAR_G] = 0;
           }
         }
       }
@@ -1628,6 +1768,7 @@ struct Decoder {
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
     }
     if (stage && tid < d.V) w.clpbuf[((in.t + 1) & 1) * d.Vc_max + tid] = stage_val;
+    if (kSpec && stage) x.row_max_store(&w.vars[VAR_ROWMAX], stage_val, d.V);
     x.mark(7);
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
     x.mark(9);
@@ -1641,14 +1782,18 @@ struct Decoder {
       // next select window.  It is anchored at this step's best key (an upper bound for the next step's keys when
       // log-probabilities are <= 0) and must reach down to the next K-th key: twice the distance from THIS step's
       // anchor (the previous best key) to this step's K-th key, rounded up to a power of two.
-      int wl = 32;
-      if (N > K) {
-        const uint32_t gap = st_maxkey > tau ? st_maxkey - tau : 0;
-        wl = (gap ? 32 - __builtin_clz(gap) : 0) + 1;  // = ceil(log2(gap + 1)) + 1
-        wl = wl < 10 ? 10 : (wl > 32 ? 32 : wl);
+      if (kSpec) {  // (one thread keeps the window and the prediction: spec_update)
+        st_sel = N > K; st_tau = tau; st_hot = hot;
+      } else {
+        int wl = 32;
+        if (N > K) {
+          const uint32_t gap = st_maxkey > tau ? st_maxkey - tau : 0;
+          wl = (gap ? 32 - __builtin_clz(gap) : 0) + 1;  // = ceil(log2(gap + 1)) + 1
+          wl = wl < 10 ? 10 : (wl > 32 ? 32 : wl);
+        }
+        st_wlog = wl;
+        st_maxkey = (uint32_t)x.uni(pv[P_NMAXKEY]);
       }
-      st_wlog = wl;
-      st_maxkey = (uint32_t)x.uni(pv[P_NMAXKEY]);
       if (LM) st_minkey = (uint32_t)x.uni(pv[P_NMINKEY]);
       st_n = n_new;
       st_pool = pool_count + n_new;
@@ -1909,7 +2054,8 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
                             const StreamState *ss = nullptr, const ctclm::LmView *lm = nullptr, const float *raw = nullptr,
                             int raw_log = 1, const int *frames_ready = nullptr) {
   if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
-  Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE, WORDLM> dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
+  using Dec0 = Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE, WORDLM>;
+  Dec0 dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   dec.long_t = (long long)t0 + len > 65536;  // (frame numbers 0 .. 65535 fit the node's 16 bits)
@@ -1946,6 +2092,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   }
   if (IDENT && prefetch && len > 0) {  // frame 0 goes straight to LDS; from then on step() stages frame t+1
     if (tid < d.V) { w.clpbuf[(t0 & 1) * d.Vc_max + tid] = pre_lp; dec.note_lp(pre_lp); }  // (the launch's first row: checked here)
+    if (Dec0::kSpec) x.row_max_store(&w.vars[VAR_ROWMAX], pre_lp, d.V);
     x.sync();
   }
   for (int t = 0; t < len; ++t) {
@@ -1983,6 +2130,14 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
           if (t + 1 < len && Dec::lp_bad(rows[(size_t)(t + 1) * d.V + r])) { next_cnt = tid + 1; next_val = -__builtin_huge_valf(); }
         }
         x.sync();
+        if (Dec0::kSpec) {  // (rows that are not prefetched -- workgroups narrower than the vocabulary: the host build of the tests)
+          if (tid == 0) {
+            float mx = w.clp[0];
+            for (int r = 1; r < d.V; ++r) mx = w.clp[r] > mx ? w.clp[r] : mx;
+            w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(mx);
+          }
+          x.sync();
+        }
       }
     } else {
       in.identity = 0;

@@ -126,6 +126,7 @@ struct DevX {
   template <int P>
   __device__ __forceinline__ void prio() const { __builtin_amdgcn_s_setprio(P); }
   __device__ __forceinline__ void count(int, int) const {}  // (event statistics of the host build)
+  __device__ __forceinline__ void probe_keys(int, int, const uint32_t *, int, uint32_t, const float *, int) const {}
   // a pointer the compiler must treat as new: what it points to is (re)loaded after this point, not kept live before it
   template <class P>
   __device__ __forceinline__ const P *fresh(const P *p) const {
@@ -195,6 +196,122 @@ struct DevX {
     return true;
   }
   __device__ __forceinline__ void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+
+  // ---- speculative select (beam_core.h Decoder::kSpec) -------------------------------------------------------------------
+#if defined(CTC_NO_SPEC_SELECT)
+  static constexpr bool kSpecSelect = false;
+#else
+  static constexpr bool kSpecSelect = true;
+#endif
+  // (the ranking gives every hot key one lane of the first 128 or 256 threads)
+  __device__ __forceinline__ bool spec_fits(int hot) const { return (hot <= 128 ? 128 : 256) <= nt(); }
+  __device__ __forceinline__ int spec_thread() const { return nt() - 64; }  // lane 0 of the last wave keeps the prediction
+  // Append (key, slot) of every lane whose candidate is hot: the wave reserves its places with ONE returning LDS atomic,
+  // issued by the first hot lane (the calls sit in loops whose trip count differs from lane to lane: no fixed lane is
+  // guaranteed to be active).  Keys beyond the list's capacity are counted but not stored (the select then falls back).
+  __device__ __forceinline__ void hot_append(bool hot, uint32_t key, int slot, uint32_t *hk, int *hs, int *cnt) {
+    const unsigned long long m = CTC_BALLOT(hot);
+    if (m) {  // (uniform)
+      const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      int base = 0;
+      if (hot && below == 0) base = atomicAdd(cnt, __popcll(m));
+      base = __builtin_amdgcn_readlane(base, __builtin_ctzll(m));
+      const int p = base + below;
+      if (hot && p < ctcbeam::kHotCap) { hk[p] = key; hs[p] = slot; }
+    }
+  }
+  // the largest of the V (<= 64) values the first lanes of wave 0 hold -> *dst (float bits), by wave 0
+  __device__ __forceinline__ void row_max_store(int *dst, float v, int V) const {
+    if (threadIdx.x < 64) {
+      const float mine = (int)threadIdx.x < V ? v : -__builtin_huge_valf();
+      // (an order-preserving integer image: the DPP scan works on ints)
+      const int key = (int)ctcbeam::ord_f32(mine);
+      const uint32_t mx = wave_max_u32((uint32_t)key);
+      if (threadIdx.x == 0) *dst = (int)ctcmath::f32_to_bits(ctcbeam::unord_f32(mx));
+    }
+  }
+  // acc + the number of the four keys that are >= mine.  Hand-scheduled: a compare into a scalar register pair, then an
+  // add-with-carry that takes that pair as its carry-in -- two instructions per key.  (The compiler's form is compare,
+  // wait states for the VCC hazard, select / add: three to four issue slots per key, and this runs on all sixteen waves.)
+  __device__ __forceinline__ int count_ge4(const uint4 o, const uint32_t mine, int acc) const {
+    int r;
+    unsigned long long m0, m1, m2;
+    asm volatile(
+        "v_cmp_ge_u32_e64 %1, %4, %8\n\t"
+        "v_cmp_ge_u32_e64 %2, %5, %8\n\t"
+        "v_cmp_ge_u32_e64 %3, %6, %8\n\t"
+        "v_cmp_ge_u32_e64 vcc, %7, %8\n\t"
+        "v_addc_co_u32_e64 %0, %1, %9, 0, %1\n\t"
+        "v_addc_co_u32_e64 %0, %2, %0, 0, %2\n\t"
+        "v_addc_co_u32_e64 %0, %3, %0, 0, %3\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, 0, vcc"
+        : "=&v"(r), "=&s"(m0), "=&s"(m1), "=&s"(m2)
+        : "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(mine), "v"(acc)
+        : "vcc");
+    return r;
+  }
+  // The hot list hk[0, H) / hs[0, H) (K <= H <= kHotCap; hk zero beyond H up to kHotCap + 64) holds every candidate key at or
+  // above the frame's threshold.
+  //   Stage 1, all waves: thread t stands for key q = t mod L (L = 128 or 256 lanes of keys) and compares it with its
+  //   share of the list (part t / L: 16 keys at 1024 threads and H <= 128 -- four 128-bit reads, the same addresses in every
+  //   lane of a wave); the partial counts of "keys >= mine" meet in gearr[q] (LDS atomics, zero on entry).
+  //   Stage 2, the first L threads only (two or four waves; the others go straight to the barrier -- an instruction that all
+  //   sixteen waves execute costs sixteen clocks, one that two execute costs four or five): a key survives iff its count is
+  //   <= K, the K-th key is the one whose count is K; survivors set their bit in the (zeroed) bitmap.
+  //   Stage 3, the same threads: a prefix count over the bitmap's 128-bit groups (one per lane, redundantly per wave) gives
+  //   each survivor its rank in slot (= DFS) order: surv[rank] = slot.
+  // tau_out[0] = the K-th key, tau_out[2] = the number of survivors: fewer than K when equal keys straddle the boundary, and
+  // then nothing is written to surv[].  Three barriers; everything is visible when it returns.
+  __device__ __forceinline__ void spec_select(int H, int K, const uint32_t *hk, const int *hs, uint32_t *bitmap, int *gearr, int S, int *surv, int *tau_out) {
+    const int t = (int)threadIdx.x, n = nt();
+    const int lsh = H <= 128 ? 7 : 8, L = 1 << lsh;
+    const int q = t & (L - 1), part = t >> lsh;
+    const int per = ctcbeam::div_p2(L << lsh, n);  // keys per part: 16 (1024 threads, H <= 128) ... a multiple of 8 when n <= 1024
+    const uint32_t mine = hk[q];
+    const uint4 *src = reinterpret_cast<const uint4 *>(hk + part * per);
+    int ge = 0;
+    if (per == 16) {
+      const uint4 o0 = src[0], o1 = src[1], o2 = src[2], o3 = src[3];
+      ge = count_ge4(o3, mine, count_ge4(o2, mine, count_ge4(o1, mine, count_ge4(o0, mine, 0))));
+    } else {
+      for (int i = 0; i < (per >> 2); i += 2) {
+        const uint4 o0 = src[i], o1 = src[i + 1];
+        ge = count_ge4(o1, mine, count_ge4(o0, mine, ge));
+      }
+    }
+    atomicAdd(&gearr[q], ge);
+    sync();
+    const bool lead = t < L;  // (whole waves)
+    bool keep = false;
+    int slot = 0;
+    if (lead) {
+      const int g = gearr[t];
+      const bool valid = t < H;
+      slot = valid ? hs[t] : 0;
+      keep = valid && g <= K;
+      if (valid && g == K) tau_out[0] = (int)mine;
+      if (keep) atomicOr(&bitmap[slot >> 5], 1u << (slot & 31));
+    }
+    sync();
+    if (lead) {
+      const int lane = t & 63;
+      const int ngr = (S + 127) >> 7;  // 128-bit groups of the bitmap (at most 64: S <= 8192)
+      uint4 g4 = make_uint4(0u, 0u, 0u, 0u);
+      if (lane < ngr) g4 = *reinterpret_cast<const uint4 *>(bitmap + 4 * lane);
+      const uint4 m4 = *reinterpret_cast<const uint4 *>(bitmap + 4 * (slot >> 7));  // my own group (group 0 for lanes without a key)
+      const int cnt = __popc(g4.x) + __popc(g4.y) + __popc(g4.z) + __popc(g4.w);
+      const int incl = wave_scan(cnt, 0, [](int a, int b) { return a + b; });
+      const int ns = __builtin_amdgcn_readlane(incl, 63);
+      if (t == 0) tau_out[2] = ns;
+      const int pre = __shfl(incl - cnt, slot >> 7, 64);  // survivors in the groups below mine
+      const int wi = (slot >> 5) & 3;
+      const uint32_t wsel = wi == 0 ? m4.x : wi == 1 ? m4.y : wi == 2 ? m4.z : m4.w;
+      const int inner = (wi > 0 ? __popc(m4.x) : 0) + (wi > 1 ? __popc(m4.y) : 0) + (wi > 2 ? __popc(m4.z) : 0) + __popc(wsel & ((1u << (slot & 31)) - 1u));
+      if (ns == K && keep) surv[pre + inner] = slot;
+    }
+    sync();
+  }
+
   // (a & mask) | (b & ~mask): one v_bitop3_b32 (the compiler builds it from three instructions)
   __device__ __forceinline__ uint32_t bitsel(uint32_t mask, uint32_t a, uint32_t b) const { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA); }
   // results mirrored into host memory: make this thread's stores visible system-wide / publish a flag there

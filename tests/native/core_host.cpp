@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <limits>
@@ -51,6 +52,44 @@ struct HostX {
   static long long *counters() { static long long c[ctcbeam::EV_COUNT]; return c; }
   void count(int k, int v) const { counters()[k] += v; }
   void tick() {}
+  // speculative select (beam_core.h Decoder::kSpec), sequentially: the same contract as the device policy's
+  static constexpr bool kSpecSelect = true;
+  bool spec_fits(int) const { return true; }
+  void hot_append(bool hot, uint32_t key, int slot, uint32_t *hk, int *hs, int *cnt) {
+    if (!hot) return;
+    const int p = (*cnt)++;
+    if (p < ctcbeam::kHotCap) { hk[p] = key; hs[p] = slot; }
+  }
+  void row_max_store(int *dst, float v, int V) const { if (V >= 1) memcpy(dst, &v, 4); }  // (one lane: a one-label row)
+  int spec_thread() const { return 0; }
+  void spec_select(int H, int K, const uint32_t *hk, const int *hs, uint32_t *bitmap, int *scratch, int S, int *surv, int *tau_out) {
+    (void)scratch; (void)S;
+    tau_out[2] = -1;
+    if (getenv("CTC_HOST_NO_SPEC")) return;
+    std::vector<int> keep;
+    for (int q = 0; q < H; ++q) {
+      int ge = 0;
+      for (int r = 0; r < H; ++r) ge += hk[r] >= hk[q];
+      if (ge <= K) { keep.push_back(hs[q]); bitmap[hs[q] >> 5] |= 1u << (hs[q] & 31); }
+      if (ge == K) tau_out[0] = (int)hk[q];
+    }
+    tau_out[2] = (int)keep.size();
+    if ((int)keep.size() != K) return;  // equal keys straddle the boundary
+    std::sort(keep.begin(), keep.end());
+    for (int k = 0; k < K; ++k) surv[k] = keep[k];
+  }
+  // CTC_DUMP_KEYS=<file>: every frame's slot keys, for offline studies of the select
+  void probe_keys(int t, int S, const uint32_t *skey, int K, uint32_t maxkey, const float *clp, int Vc) const {
+    static FILE *f = getenv("CTC_DUMP_KEYS") ? fopen(getenv("CTC_DUMP_KEYS"), "wb") : nullptr;
+    if (!f) return;
+    float mx = clp[0];
+    for (int i = 1; i < Vc; ++i) mx = std::max(mx, clp[i]);
+    uint32_t hdr[5] = {(uint32_t)t, (uint32_t)S, (uint32_t)K, maxkey, 0u};
+    memcpy(&hdr[4], &mx, 4);
+    fwrite(hdr, 4, 5, f);
+    fwrite(skey, 4, (size_t)S, f);
+    fflush(f);
+  }
   void dump(int, int, const int *, const int *, const int *, const float *) {}
   uint32_t scan_excl(uint32_t *a, int n) {
     uint32_t run = 0;

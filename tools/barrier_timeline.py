@@ -20,6 +20,9 @@ LABELS = ["loop top (row prefetch issued) -> step prologue", "A1 subtree ends + 
           "C1 find bucket (wave 0)", "wait: C1 barrier", "C2 list bucket + survivor bitmap", "wait: C2 barrier",
           "C3 rank in bucket (wave 0)", "wait: C3 barrier", "D expand bitmap (wave 0)", "wait: D barrier",
           "E emit next beam (+ resets on idle waves)", "wait: end-of-frame barrier", "state update", "loop back-edge"]
+# ... on the path of the speculative select (round 4): the histogram select's four stages are two
+LABELS_SPEC = LABELS[:6] + ["B score candidates + hot list", "wait: B barrier", "R1 rank the hot list (all waves)", "wait: R1 barrier",
+                            "R2 survivors in slot order (all waves)", "wait: R2 barrier"] + LABELS[16:]
 
 
 def main():
@@ -34,6 +37,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--repeat", type=int, default=1, help="launches to average over (frame0 moves by 37 each)")
     ap.add_argument("--lm", default="", help="ARPA model: time the LM tier's kernel (labels _ ' space a..z)")
+    ap.add_argument("--kind", default="randn", help="randn | blank (+6 on the blank logit: nearly every frame takes the speculative select)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -42,7 +46,10 @@ def main():
     from ctcdecode_amd import _native
 
     g = torch.Generator(device="cpu").manual_seed(1234)
-    lp = torch.randn((a.batch, a.T, a.V), generator=g).log_softmax(-1).cuda()
+    lg = torch.randn((a.batch, a.T, a.V), generator=g)
+    if a.kind == "blank":
+        lg[:, :, 0] += 6.0
+    lp = lg.log_softmax(-1).cuda()
     labels = [str(i) for i in range(a.V)]
     kw = {}
     if a.lm:
@@ -86,11 +93,12 @@ def main():
     clocks_per_frame = cpf_sum / a.repeat
     print("timeline build: kernel %.3f ms; %d waves, %d stamps per frame, %.0f clocks per frame (%.2f GHz if every frame takes kernel/T)"
           % (kernel_ms, nw, per, clocks_per_frame, clocks_per_frame / (kernel_ms * 1e3 / a.T) / 1e3))
-    overhead = float(acc[:, 2].mean()) if per == len(LABELS) else 0.0
+    labels = LABELS if per == len(LABELS) else LABELS_SPEC if per == len(LABELS_SPEC) else None
+    overhead = float(acc[:, 2].mean()) if labels else 0.0
     print("one stamp costs about %.0f clocks (row 2 has nothing else in it)" % overhead)
     rows = []
     for i in range(per):
-        lab = LABELS[i] if per == len(LABELS) else "stamp %d" % i
+        lab = labels[i] if labels else "stamp %d" % i
         rows.append({"stamp": i, "what": lab, "max": float(acc[:, i].max()), "median": float(np.median(acc[:, i])), "min": float(acc[:, i].min()),
                      "per_wave": [float(v) for v in acc[:, i]]})
         print("%2d %-52s max %5.0f  med %5.0f  min %5.0f | %s" % (i, lab[:52], acc[:, i].max(), np.median(acc[:, i]), acc[:, i].min(),

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 NAMES = ["frames", "candidates", "exact replays", "entries with in-beam descendants", "entries whose parent is in the beam",
          "pool updates of a label probability", "entries below a dead interior node", "revival candidates", "revived nodes that survive",
-         "pool walks", "hops of those walks", "selects on the fast path", "... whose bucket holds a single key", "keys in the K-th key's bucket"]
+         "pool walks", "hops of those walks", "selects on the fast path", "... whose bucket holds a single key", "keys in the K-th key's bucket",
+         "speculative select: settled the frame", "... too few hot keys", "... too many hot keys", "... handed back (ties, last frame, danger mode)", "hot keys"]
 
 
 def main():
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--beam", type=int, default=100)
     ap.add_argument("--lm", default="")
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--blank-bias", type=float, default=0.0)
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -34,7 +36,9 @@ def main():
 
     labels = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
     torch.manual_seed(a.seed)
-    lp = torch.randn((1, a.T, 29)).log_softmax(-1).numpy()
+    lg = torch.randn((1, a.T, 29))
+    lg[:, :, 0] += a.blank_bias
+    lp = lg.log_softmax(-1).numpy()
     lib = ctypes.CDLL(ou.build_core_host())
     cnt = (ctypes.c_longlong * 32)()
     lib.ctccore_event_counts(cnt, 1)

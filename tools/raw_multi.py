@@ -2,7 +2,7 @@
 """Kernel time of one shape through the C ABI of SEVERAL builds of the library in one process, launches interleaved (A B C A B
 C ...) so that clock / box drift hits them alike; the outputs of every build must agree bit for bit with the first one's.
     python tools/raw_multi.py B T V beam reps lib1.so lib2.so ... [--lm tests/data/test.arpa] [--cu-sharing 1]
-(tools/build_variants.sh makes the builds; --lm times the LM tier -- labels blank, ', space, a..z, alpha 0.5, beta 1.0 -- and
+(--kind blank / peaky: other input distributions.  tools/build_variants.sh makes the builds; --lm times the LM tier -- labels blank, ', space, a..z, alpha 0.5, beta 1.0 -- and
 needs builds that contain its kernels: CTC_QUICK_BUILD=2 or full builds; --cu-sharing 1 asks for the two-workgroups-per-CU
 instantiations.)  The --lm / --cu-sharing forms were written without a GPU at the end of round 3: check them on first use."""
 import ctypes
@@ -17,10 +17,23 @@ if "--lm" in args:
     i = args.index("--lm"); lm_path = args[i + 1]; del args[i:i + 2]
 if "--cu-sharing" in args:
     i = args.index("--cu-sharing"); cu_sharing = int(args[i + 1]); del args[i:i + 2]
+kind = "randn"  # --kind randn | blank (+6 on the blank logit) | peaky (one label +8 per frame, in runs of 5-15 frames)
+if "--kind" in args:
+    i = args.index("--kind"); kind = args[i + 1]; del args[i:i + 2]
 B, T, V, K, reps = (int(a) for a in args[:5])
 paths = args[5:]
 g = torch.Generator(device="cpu").manual_seed(7)
-lp = torch.randn((B, T, V), generator=g).log_softmax(-1).cuda()
+lg = torch.randn((B, T, V), generator=g)
+if kind == "blank":
+    lg[:, :, 0] += 6.0
+elif kind == "peaky":
+    for b in range(B):
+        t = 0
+        while t < T:
+            run = int(torch.randint(5, 16, (1,), generator=g)); c = int(torch.randint(0, V, (1,), generator=g))
+            lg[b, t:t + run, c] += 8.0
+            t += run
+lp = lg.log_softmax(-1).cuda()
 labels = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
 I, D, P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 libs = []
