@@ -157,7 +157,8 @@ enum {
   // from, the safety margin, the observed distance best -> K-th (float bits), the largest log-probability of the staged row,
   // "the prediction is valid"
   // "the prediction is valid", and the histogram window of the frames that fall back (its log2 width, the key it is anchored at)
-  VAR_SPEC = VAR_PAR0 + 2 * P_SIZE, SP_THR = 0, SP_BEST, SP_MARGIN, SP_GAP, SP_ROWMAX, SP_PRED, SP_WLOG, SP_ANCHOR,
+  // (the first four are what every thread reads before phase B: one 16-byte group)
+  VAR_SPEC = VAR_PAR0 + 2 * P_SIZE, SP_THR = 0, SP_WLOG, SP_ANCHOR, SP_PRED, SP_BEST, SP_MARGIN, SP_GAP, SP_ROWMAX,
   VAR_ROWMAX = VAR_SPEC + SP_ROWMAX,
   VAR_COUNT = VAR_SPEC + 8
 };
@@ -199,6 +200,7 @@ struct Work {
   uint16_t *lr;    // 2 * S_max: stop positions of the parallel Hoare partition (widest layout: 32 bit each)
   uint32_t *wpre;  // build_ek_lazy's prefix over the bitmap's words (the histogram's block; widest layout: HBM scratch)
   int *bins;       // kBins buckets of the select histogram (+ kBins/16 more words: with them, the task lists of the final sorts)
+  int *hotge;      // kHotCap counters of the speculative select's ranking (fixed-layout class only; zero between frames)
   uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
   int *lslot;      // kListCap: their slots
   uint32_t *bitmap;  // one bit per slot: survives (select fast path)
@@ -277,7 +279,8 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   // (the fixed-layout class also uses the two lists as the hot list of the speculative select: kHotCap entries + padding)
   const size_t lcap = (d.K <= kSmallK && d.Vc_max <= kSmallV) ? (size_t)kHotCap + 64 : (size_t)kListCap + 4;
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, lcap);
-  w.lslot = carve_ptr<int>(p, lcap); w.bitmap = carve_ptr<uint32_t>(huge ? q : p, 2 * ((S + 63) / 64 + 17));
+  w.lslot = carve_ptr<int>(p, lcap);
+  w.hotge = carve_ptr<int>(p, lcap > (size_t)kListCap + 4 ? (size_t)kHotCap : 0); w.bitmap = carve_ptr<uint32_t>(huge ? q : p, 2 * ((S + 63) / 64 + 17));
   w.wpre = huge ? carve_ptr<uint32_t>(q, (S + 63) / 64 + 2) : reinterpret_cast<uint32_t *>(w.bins);
   w.fin = carve_ptr<int>(BIG ? q : p, K);  // (last / exact / danger frames and finish() only: HBM scratch in the wide-beam layouts)
   w.apos = carve_ptr<int>(BIG ? q : p, K);  // (read in danger mode only: HBM scratch in the wide-beam layouts)
@@ -473,41 +476,46 @@ struct Decoder {
   // boundary, the last frame, danger mode -- falls back to the histogram select, which first has to build its histogram
   // (rehistogram()): same survivors either way, by construction.
   static constexpr bool kSpec = IDENT && SMALLV && !LM && !LAZY && X::kSpecSelect;
-  // ONE thread (X::spec_thread), between the barriers of phases A1 and A2 (where its wave has nothing else to do): what the
-  // previous frame observed -- its K-th key st_tau, the size of its hot list st_hot -- becomes this frame's threshold
-  // SP_THR, which everyone reads behind phase A2's barrier.  The best key of the previous frame's survivors is still in that
-  // frame's per-parity counters (P_NMAXKEY: they are reset during THIS frame's emission).
-  bool st_sel = false;       // the previous frame selected (N > K): st_tau / st_hot are valid
-  uint32_t st_tau = 0;
-  int st_hot = 0;
-  CTC_HD void spec_update(int t, int K) const {
+  // ONE thread (X::spec_thread) turns what a frame observed -- its K-th key, the size of its hot list -- into the next frame's
+  // threshold SP_THR, which everyone reads behind phase A2's barrier.  The best key of the previous frame's survivors is
+  // still in that frame's per-parity counters (P_NMAXKEY: they are reset during THIS frame's emission).
+  // ... in two parts, each where its wave has time to spare.  spec_learn: during the emission (the thread's wave is one of
+  // those without a role there), from this frame's K-th key and hot-list length.  spec_predict: between the barriers of
+  // phases A1 and A2 of the next frame, once that frame's anchor (the best key the emission found) is final.
+  CTC_HD void spec_learn(bool selected, uint32_t tau, int hot, int K) const {
     int *sp = w.vars + VAR_SPEC;
     const int pred = sp[SP_PRED];
-    const float best_prev = ctcmath::bits_to_f32((uint32_t)sp[SP_BEST]), rowmax = ctcmath::bits_to_f32((uint32_t)sp[SP_ROWMAX]);
-    float margin = ctcmath::bits_to_f32((uint32_t)sp[SP_MARGIN]), gap = ctcmath::bits_to_f32((uint32_t)sp[SP_GAP]);
-    const uint32_t anchor = (uint32_t)sp[SP_ANCHOR], mk = (uint32_t)pvars(t - 1)[P_NMAXKEY];
+    const float best = ctcmath::bits_to_f32((uint32_t)sp[SP_BEST]);
+    float margin = ctcmath::bits_to_f32((uint32_t)sp[SP_MARGIN]);
+    const uint32_t anchor = (uint32_t)sp[SP_ANCHOR];
     int wl = 32;
-    if (st_sel) {
-      gap = best_prev - unord_f32(st_tau);
+    float cut = 0.f;
+    if (selected) {
       // too few hot keys: widen the margin; many more than needed: narrow it (the ranking's cost grows with their square)
       if (pred) {
-        if (st_hot < K) margin = margin < 32.f ? margin * 2.f : margin;
-        else if (st_hot > K + (K >> 1) + 10) margin = margin > 0.001f ? margin * 0.8125f : margin;
+        if (hot < K) margin = margin < 32.f ? margin * 2.f : margin;
+        else if (hot > K + (K >> 1) + 10) margin = margin > 0.001f ? margin * 0.8125f : margin;
       }
+      cut = (best - unord_f32(tau)) + margin;  // the next threshold lies this far below the next frame's best estimate
       // the window of a frame that falls back to the histogram select: anchored at the best key, reaching twice as far down
-      // as the previous frame's K-th key lay below ITS anchor, rounded up to a power of two (as the histogram select keeps it)
-      const uint32_t kgap = anchor > st_tau ? anchor - st_tau : 0u;
+      // as this frame's K-th key lay below ITS anchor, rounded up to a power of two (as the histogram select keeps it)
+      const uint32_t kgap = anchor > tau ? anchor - tau : 0u;
       wl = (kgap ? 32 - __builtin_clz(kgap) : 0) + 1;
       wl = wl < kBinsLog ? kBinsLog : (wl > 32 ? 32 : wl);
     }
+    sp[SP_MARGIN] = (int)ctcmath::f32_to_bits(margin); sp[SP_GAP] = (int)ctcmath::f32_to_bits(cut);
+    sp[SP_PRED] = selected ? 1 : 0; sp[SP_WLOG] = wl;
+  }
+  CTC_HD void spec_predict(int t) const {
+    int *sp = w.vars + VAR_SPEC;
+    const int pred = sp[SP_PRED];
+    const float rowmax = ctcmath::bits_to_f32((uint32_t)sp[SP_ROWMAX]), cut = ctcmath::bits_to_f32((uint32_t)sp[SP_GAP]);
+    const uint32_t mk = (uint32_t)pvars(t - 1)[P_NMAXKEY];
     const float best = unord_f32(mk) + rowmax;
-    uint32_t k = 0xFFFFFFFFu;  // no prediction: nothing is hot, the frame goes the histogram way
-    if (st_sel) {
-      k = ord_f32(best - gap - margin);
-      k = k ? k : 1u;  // (holes have key 0 and are never hot)
-    }
-    sp[SP_THR] = (int)k; sp[SP_BEST] = (int)ctcmath::f32_to_bits(best); sp[SP_MARGIN] = (int)ctcmath::f32_to_bits(margin);
-    sp[SP_GAP] = (int)ctcmath::f32_to_bits(gap); sp[SP_PRED] = st_sel ? 1 : 0; sp[SP_WLOG] = wl; sp[SP_ANCHOR] = (int)mk;
+    uint32_t k = ord_f32(best - cut);
+    k = k ? k : 1u;               // (holes have key 0 and are never hot)
+    k = pred ? k : 0xFFFFFFFFu;   // no prediction: nothing is hot, the frame goes the histogram way
+    sp[SP_THR] = (int)k; sp[SP_BEST] = (int)ctcmath::f32_to_bits(best); sp[SP_ANCHOR] = (int)mk;
   }
 
   // Step-to-step state, identical in every thread (kept in registers, not LDS)
@@ -809,7 +817,7 @@ struct Decoder {
       }
     }
     if (tid == 0) {
-      if (kSpec) {  // (the window state is kept in LDS by one thread: beam_core.h spec_update; one frame stale at most, which
+      if (kSpec) {  // (the window state is kept in LDS by one thread: spec_learn; one frame stale at most, which
                     //  only ever costs time -- the select is exact for any window)
         st_wlog = w.vars[VAR_SPEC + SP_WLOG];
         st_maxkey = (uint32_t)pvars(frames - 1)[P_NMAXKEY];
@@ -932,25 +940,27 @@ struct Decoder {
   // start of an utterance / of a stream's chunk: no prediction yet, empty hot list, clear survivor bitmap
   CTC_HD void spec_reset(int t0) {
     if (!kSpec) return;
-    st_sel = false; st_tau = 0; st_hot = 0;
     if (x.tid() == 0) {
       int *sp = w.vars + VAR_SPEC;
       sp[SP_THR] = -1; sp[SP_BEST] = 0; sp[SP_MARGIN] = (int)ctcmath::f32_to_bits(0.125f); sp[SP_GAP] = 0; sp[SP_PRED] = 0;
       sp[SP_WLOG] = st_wlog; sp[SP_ANCHOR] = (int)st_maxkey;
       w.vars[VAR_G] = 0;  // (the hot list's length is counted in the select's result group: one read gives it and the danger flag)
+      w.vars[VAR_E] = 0;
       // (the first frame finds "the previous frame's best key" where every later one does: in the counters of the other parity)
       pvars(t0 - 1)[P_NMAXKEY] = (int)st_maxkey;
     }
     for (int i = x.tid(); i < kHotCap + 64; i += x.nt()) w.list[i] = 0u;
+    for (int i = x.tid(); i < kHotCap; i += x.nt()) w.hotge[i] = 0;
     for (int i = x.tid(); i < 2 * ((kSmallK * (2 + kSmallV) + 63) / 64); i += x.nt()) w.bitmap[i] = 0u;
   }
-  // The histogram of the frame's keys, for the frames the speculative select hands back: what phase B would have counted.
-  CTC_HD void rehistogram(int S, int *pv, Window &wd) {
+  // The histogram of the frame's keys, for the frames the speculative select hands back: what phase B would have counted
+  // (the window is kept in LDS by the thread that keeps the prediction: spec_learn).
+  CTC_HD void rehistogram(int S, Window &wd) {
     const int tid = x.tid(), nt = x.nt();
-    st_wlog = x.uni(w.vars[VAR_SPEC + SP_WLOG]);
-    st_maxkey = (uint32_t)x.uni(w.vars[VAR_SPEC + SP_ANCHOR]);
+    int sv[4];
+    x.uni4(&w.vars[VAR_SPEC], sv);
+    st_wlog = sv[SP_WLOG]; st_maxkey = (uint32_t)sv[SP_ANCHOR];
     wd = first_window();
-    if (tid == 0) pv[P_LCOUNT] = 0;
     for (int i = tid; i < kBins; i += nt) w.bins[i] = 0;
     x.sync();
     for (int s = tid; s < S; s += nt) hist_add(wd, w.skey[s]);
@@ -1290,7 +1300,7 @@ struct Decoder {
     }
     x.tick();
     x.sync();
-    if (kSpec && tid == x.spec_thread()) spec_update(in.t, K);
+    if (kSpec && tid == x.spec_thread()) spec_predict(in.t);
     // ---- A2: Euler-tour slot offsets; which children of in-beam parents already exist
     int npin = 0;
     for (int j = tid; j < n; j += nt) {
@@ -1342,7 +1352,7 @@ struct Decoder {
     x.sync();
     x.mark(0);
     const int npin_total = pv[P_NPIN];  // final since the barrier above; requested here so that phase C does not wait for it
-    const uint32_t thr = kSpec ? (uint32_t)x.uni(w.vars[VAR_SPEC + SP_THR]) : 0xFFFFFFFFu;  // (written before phase A's barriers)
+    const uint32_t thr = kSpec ? (uint32_t)x.uni(w.vars[VAR_SPEC + SP_THR]) : 0xFFFFFFFFu;  // (written between the barriers of phase A: spec_predict)
 
     // ---- B: score every candidate, lay it out in DFS (Euler-tour) slot order and count it into the select histogram.
     // B1 (beam entries themselves + revived children) and B2 (brand-new children) are independent: with enough
@@ -1350,6 +1360,9 @@ struct Decoder {
     const int n1 = (SMALLV && x.nt_is(1024)) ? kSmallK : (n + 63) & ~63;  // (fixed-layout class: two entry waves, a compile-time split)
     const bool split = nt - n1 >= 128;
     if (!split || tid < n1) {
+#if defined(CTC_EXP_B1_PRIO)
+      x.template prio<CTC_EXP_B1_PRIO>();
+#endif
       const float lp_blank = brank >= 0 ? w.clp[brank] : CTC_NEG_MAX;
       int ncand = 0;
       for (int j = tid; j < n; j += (split ? n1 : nt)) {
@@ -1415,13 +1428,16 @@ struct Decoder {
         w.skey[s0 + 1] = k1;
         if (!LAZY) { w.sinfo[s0] = i0; w.sinfo[s0 + 1] = mk_info(c, T_SELF, j); }
         if (kSpec) {
-          x.hot_append(k0 >= thr, k0, s0, w.list, w.lslot, &w.vars[VAR_G]);
-          x.hot_append(k1 >= thr, k1, s0 + 1, w.list, w.lslot, &w.vars[VAR_G]);
+          x.hot_append(k0 >= thr, k0, s0, w.list, w.lslot, &w.vars[VAR_G]);  // (a revived node: rare)
+          x.hot_append_wave(k1 >= thr, k1, s0 + 1, w.list, w.lslot, &w.vars[VAR_G]);
         } else if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
         if (LM && upd_node >= 0) set_node_time(upd_node, c, in.t, upd_lp);
         if (LM && CTC_RARE(upd_xn >= 0)) set_node_time(upd_xn, upd_xc, in.t, upd_xlp);
       }
       if (LM) x.wave_add(&pv[P_NCAND], ncand);
+#if defined(CTC_EXP_B1_PRIO)
+      x.template prio<0>();
+#endif
     }
     x.mark(1);
     if (!split || tid >= n1) {
@@ -1445,18 +1461,32 @@ struct Decoder {
           // (the info word of (label, parent i) is childinfo + i: it is the loop's induction variable)
           uint32_t ci = childinfo + (uint32_t)(t2 >> sh);
           const uint32_t ci_end = childinfo + (uint32_t)n;
-          for (int i = t2 >> sh; ci < ci_end; i += ng, ci += (uint32_t)ng) {
+          // (speculative select: the list space of a pass is reserved with a returning LDS atomic -- a full round trip.  The
+          //  loop is pipelined by hand: the atomic is issued, then the NEXT pass's parent fields are requested, and only then
+          //  is the atomic's result used -- LDS answers in order, so the append never waits on its own)
+          struct Par { int cs; uint32_t hw; int pch; float psc, pbp; uint32_t gw; };
+          auto fetch = [&](int i) {
+            Par p;
             // everything this candidate needs from its parent, requested in one go (one LDS round trip), no branches
-            const int cs = w.cstart[i];
-            const uint32_t hw = w.hit[hit_word(i, rn)];
-            const int pch = b.ch[i];
-            const float psc = b.score[i], pbp = b.bprev[i];
+            p.cs = w.cstart[i]; p.hw = w.hit[hit_word(i, rn)]; p.pch = b.ch[i]; p.psc = b.score[i]; p.pbp = b.bprev[i];
+            p.gw = (LM && WORDLM) ? (uint32_t)gate_w[i] : 0u;
+            return p;
+          };
+          int i = t2 >> sh;
+          bool act = ci < ci_end;
+          Par cur{};
+          if (act) cur = fetch(i);
+          while (act) {
+            const int cs = cur.cs;
+            const uint32_t hw = cur.hw;
+            const int pch = cur.pch;
+            const float psc = cur.psc, pbp = cur.pbp;
             uint32_t live = 0u - (((hw >> (rn & 31)) & 1u) ^ 1u);  // all ones unless the child already exists
             const float ext = lp + psc, rep = pbp > CTC_NEG_MAX ? lp + pbp : CTC_NEG_MAX;  // :110-118
             float logp = c == pch ? rep : ext;
             if (LM) {
               if (WORDLM) {
-                const uint32_t gate = ((uint32_t)gate_w[i] >> gate_sh) & 1u;
+                const uint32_t gate = (cur.gw >> gate_sh) & 1u;
                 live &= 0u - (gate & (uint32_t)!cut(lp, psc));                    // :93-95, path_trie.cpp:59-70
               } else if (cut(lp, psc) || !lm_allows(b, i, c)) {
                 live = 0u;
@@ -1468,8 +1498,13 @@ struct Decoder {
             const int s = cs + rn;
             w.skey[s] = k;
             if (!LAZY) w.sinfo[s] = x.bitsel(live, ci, kHoleInfo);
-            if (kSpec) x.hot_append(k >= thr, k, s, w.list, w.lslot, &w.vars[VAR_G]);
-            else hist_add(wd, k);
+            const bool hotk = kSpec && k >= thr;
+            const auto tk = x.hot_issue(hotk, &w.vars[VAR_G]);
+            if (!kSpec) hist_add(wd, k);
+            i += ng; ci += (uint32_t)ng;
+            act = ci < ci_end;
+            if (act) cur = fetch(i);
+            if (kSpec) x.hot_commit(tk, hotk, k, s, w.list, w.lslot);
           }
         }
       } else {
@@ -1535,19 +1570,17 @@ struct Decoder {
     bool spec_done = false;    // the speculative select settled the frame: surv[] holds the K survivors in slot order
     int hot = 0;
     if (kSpec && CTC_USUAL(N > K)) {
+      const auto pre = x.spec_pre(w.list, w.lslot);  // (the ranking's first reads, in flight with the one below)
       int tv0[4];
-      x.uni4(&w.vars[VAR_TAU], tv0);  // [1]: the hot list's length, [3]: the danger flag
+      x.uni4(&w.vars[VAR_TAU], tv0);  // [1]: the hot list's length, [2]: zero (reset with it), [3]: the danger flag
       hot = tv0[1];
       if (CTC_USUAL(!last && hot >= K && hot <= kHotCap && x.spec_fits(hot) && tv0[3] == 0)) {
-        // -> VAR_TAU = the K-th key, VAR_E = number of keys that rank within the first K (fewer than K: equal keys straddle
-        //    the boundary and nothing was written to surv[]); w.bins[0, kHotCap) is the ranking's scratch (zero on entry)
-        x.spec_select(hot, K, w.list, w.lslot, w.bitmap, w.bins, S, surv, &w.vars[VAR_TAU]);
-        int tv[4];
-        x.uni4(&w.vars[VAR_TAU], tv);
-        spec_done = tv[2] == K;
-        if (CTC_USUAL(spec_done)) tau = (uint32_t)tv[0];
+        // (w.hotge[]: the ranking's scratch, zero between frames; the VAR_TAU group takes the report of the K-th key's lane)
+        const auto r = x.spec_select(pre, hot, K, w.list, w.lslot, w.bitmap, w.hotge, S, surv, &w.vars[VAR_TAU]);
+        spec_done = r.ok != 0;
+        if (CTC_USUAL(spec_done)) tau = r.tau;
       }
-      if (CTC_RARE(!spec_done)) rehistogram(S, pv, wd);
+      if (CTC_RARE(!spec_done)) rehistogram(S, wd);
       if (spec_done) x.count(EV_SPEC_HOT, hot);
       x.count(spec_done ? EV_SPEC_OK : hot < K ? EV_SPEC_UNDER : hot > kHotCap ? EV_SPEC_OVER : EV_SPEC_OTHER, 1);
     }
@@ -1643,11 +1676,9 @@ struct Decoder {
         const bool spare = roles && nt > nroles * ne;
         if (!spare || tid >= nroles * ne) {
           const int t0 = spare ? tid - nroles * ne : tid, tstep = spare ? nt - nroles * ne : nt;
-          if (kSpec) {  // the hot list's keys (its unused tail must read as zero), the ranking's counters (the head of the
-                        // histogram's block; the histogram itself is cleared by the frames that build one: rehistogram) and
-                        // the survivor bitmap
+          if (kSpec) {  // the hot list's keys (its unused tail must read as zero) and the survivor bitmap; the histogram is
+                        // cleared by the frames that build one (rehistogram)
             for (int i = t0; i < kHotCap + 64; i += tstep) w.list[i] = 0u;
-            for (int i = t0; i < kHotCap; i += tstep) w.bins[i] = 0;
             for (int i = t0; i < 2 * ((kSmallK * (2 + kSmallV) + 63) / 64); i += tstep) w.bitmap[i] = 0u;
           } else {
             for (int i = t0; i < kBins; i += tstep) w.bins[i] = 0;
@@ -1657,8 +1688,9 @@ struct Decoder {
           for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }
           if (t0 == 0) {
             reset_pvars(pvars(in.t + 1));
-            if (kSpec) w.vars[VAR_G] = 0;
+            if (kSpec) { w.vars[VAR_G] = 0; w.vars[VAR_E] = 0; }
           }
+          if (kSpec && tid == x.spec_thread()) spec_learn(N > K, tau, hot, K);
         }
       }
       for (int k = roles ? tid - role * ne : tid; k < n_new && role < nroles; k += roles ? ne : nt) {
@@ -1782,9 +1814,7 @@ struct Decoder {
       // next select window.  It is anchored at this step's best key (an upper bound for the next step's keys when
       // log-probabilities are <= 0) and must reach down to the next K-th key: twice the distance from THIS step's
       // anchor (the previous best key) to this step's K-th key, rounded up to a power of two.
-      if (kSpec) {  // (one thread keeps the window and the prediction: spec_update)
-        st_sel = N > K; st_tau = tau; st_hot = hot;
-      } else {
+      if (!kSpec) {  // (speculative select: one thread keeps the window and the prediction in LDS -- spec_learn / spec_predict)
         int wl = 32;
         if (N > K) {
           const uint32_t gap = st_maxkey > tau ? st_maxkey - tau : 0;

@@ -110,6 +110,10 @@ struct DevX {
     if (PROF == 2 && tl && (threadIdx.x & 63) == 0) {
       if (t == tl_f0) tlcnt[threadIdx.x >> 6] = 0;
       if (t == tl_f0 + tl_nf) tlcnt[threadIdx.x >> 6] = tl_cap;
+      // a frame marker (bit 62 set): frames take different paths with different numbers of stamps (speculative select /
+      // histogram select / exact replay); tools/barrier_timeline.py groups the recorded frames by their stamp count
+      const int i = atomicAdd(&tlcnt[threadIdx.x >> 6], 1);
+      if (i < tl_cap) tl[(threadIdx.x >> 6) * tl_cap + i] = (long long)clock64() | (1ll << 62);
     }
   }
   // a value every thread of the workgroup holds identically -> scalar register (branches/loops on it become scalar)
@@ -206,18 +210,30 @@ struct DevX {
   // (the ranking gives every hot key one lane of the first 128 or 256 threads)
   __device__ __forceinline__ bool spec_fits(int hot) const { return (hot <= 128 ? 128 : 256) <= nt(); }
   __device__ __forceinline__ int spec_thread() const { return nt() - 64; }  // lane 0 of the last wave keeps the prediction
-  // Append (key, slot) of every lane whose candidate is hot: the wave reserves its places with ONE returning LDS atomic,
-  // issued by the first hot lane (the calls sit in loops whose trip count differs from lane to lane: no fixed lane is
-  // guaranteed to be active).  Keys beyond the list's capacity are counted but not stored (the select then falls back).
+  // Append (key, slot) of every lane whose candidate is hot: each hot lane takes its own place with a returning LDS atomic.
+  // (A few percent of the candidates are hot -- two or three lanes of a wave per pass -- so the same-address atomics barely
+  //  serialise, and the wave-aggregated form (ballot, lane count, leader election, one atomic, readlane) measured 18
+  //  instructions longer per pass on every scoring wave.)  Keys beyond the list's capacity are counted but land in a dummy
+  //  place behind it (the select then falls back).
   __device__ __forceinline__ void hot_append(bool hot, uint32_t key, int slot, uint32_t *hk, int *hs, int *cnt) {
-    const unsigned long long m = CTC_BALLOT(hot);
-    if (m) {  // (uniform)
-      const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-      int base = 0;
-      if (hot && below == 0) base = atomicAdd(cnt, __popcll(m));
-      base = __builtin_amdgcn_readlane(base, __builtin_ctzll(m));
-      const int p = base + below;
-      if (hot && p < ctcbeam::kHotCap) { hk[p] = key; hs[p] = slot; }
+    if (hot) {
+      int p = atomicAdd(cnt, 1);
+      p = p < ctcbeam::kHotCap ? p : ctcbeam::kHotCap;
+      hk[p] = key; hs[p] = slot;
+    }
+  }
+  // ... in two halves, for loops that have something to request between them (beam_core.h phase B): the place is requested,
+  // and only waited for when the append is committed.
+  using HotTicket = int;
+  __device__ __forceinline__ HotTicket hot_issue(bool hot, int *cnt) {
+    int p = 0;
+    if (hot) p = atomicAdd(cnt, 1);
+    return p;
+  }
+  __device__ __forceinline__ void hot_commit(HotTicket p, bool hot, uint32_t key, int slot, uint32_t *hk, int *hs) {
+    if (hot) {
+      p = p < ctcbeam::kHotCap ? p : ctcbeam::kHotCap;
+      hk[p] = key; hs[p] = slot;
     }
   }
   // the largest of the V (<= 64) values the first lanes of wave 0 hold -> *dst (float bits), by wave 0
@@ -250,30 +266,66 @@ struct DevX {
         : "vcc");
     return r;
   }
-  // The hot list hk[0, H) / hs[0, H) (K <= H <= kHotCap; hk zero beyond H up to kHotCap + 64) holds every candidate key at or
+  // ... the same through the wave: every lane of a B1 wave may be hot (an entry's own new score usually is), and sixty-four
+  // same-address atomics would serialise: ballot, one atomic by the first hot lane, places by lane count.
+  __device__ __forceinline__ void hot_append_wave(bool hot, uint32_t key, int slot, uint32_t *hk, int *hs, int *cnt) {
+    const unsigned long long m = CTC_BALLOT(hot);
+    if (m) {  // (uniform)
+      const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      int base = 0;
+      if (hot && below == 0) base = atomicAdd(cnt, __popcll(m));
+      base = __builtin_amdgcn_readlane(base, __builtin_ctzll(m));
+      int p = base + below;
+      p = p < ctcbeam::kHotCap ? p : ctcbeam::kHotCap;
+      if (hot) { hk[p] = key; hs[p] = slot; }
+    }
+  }
+  // The hot list hk[0, H) / hs[0, H) (K <= H <= kHotCap; hk zero beyond H up to kHotCap) holds every candidate key at or
   // above the frame's threshold.
   //   Stage 1, all waves: thread t stands for key q = t mod L (L = 128 or 256 lanes of keys) and compares it with its
   //   share of the list (part t / L: 16 keys at 1024 threads and H <= 128 -- four 128-bit reads, the same addresses in every
-  //   lane of a wave); the partial counts of "keys >= mine" meet in gearr[q] (LDS atomics, zero on entry).
+  //   lane of a wave); the partial counts of "keys >= mine" meet in gearr[q] (LDS atomics; zero on entry, and left zero).
   //   Stage 2, the first L threads only (two or four waves; the others go straight to the barrier -- an instruction that all
   //   sixteen waves execute costs sixteen clocks, one that two execute costs four or five): a key survives iff its count is
-  //   <= K, the K-th key is the one whose count is K; survivors set their bit in the (zeroed) bitmap.
+  //   <= K, the K-th key is the one whose count is K -- it exists iff no group of equal keys straddles the boundary, and its
+  //   lane reports it (res[0] = the key, res[2] = K); survivors set their bit in the (zeroed) bitmap.
   //   Stage 3, the same threads: a prefix count over the bitmap's 128-bit groups (one per lane, redundantly per wave) gives
-  //   each survivor its rank in slot (= DFS) order: surv[rank] = slot.
-  // tau_out[0] = the K-th key, tau_out[2] = the number of survivors: fewer than K when equal keys straddle the boundary, and
-  // then nothing is written to surv[].  Three barriers; everything is visible when it returns.
-  __device__ __forceinline__ void spec_select(int H, int K, const uint32_t *hk, const int *hs, uint32_t *bitmap, int *gearr, int S, int *surv, int *tau_out) {
+  //   each survivor its rank in slot (= DFS) order: surv[rank] = slot.  The other waves meanwhile fetch the report, so that
+  //   nobody reads LDS behind the closing barrier.
+  // res[2] must be zero on entry.  Returns {the K-th key, 1} or {-, 0}: then equal keys straddle the boundary and nothing
+  // was written to surv[].  Three barriers; everything is visible when it returns.
+  // (Measured and dropped: stages 1 and 2 as one stage without LDS traffic -- every wave holds the list in two registers and
+  //  ranks eight keys of its own through scalar registers: readlane, two compares, two population counts, writelane; one
+  //  barrier less, no atomics -- 3 % SLOWER: ~85 instructions on all sixteen waves against ~45 + a two-wave stage.)
+  struct SpecPre { uint32_t mine; uint4 o0, o1, o2, o3; };
+  // (the list reads of stage 1 in the usual configuration -- 1024 threads, at most 128 hot keys -- requested before the
+  //  list's length is known: they ride with the read of that length instead of behind it)
+  __device__ __forceinline__ SpecPre spec_pre(const uint32_t *hk, const int *) const {
+    SpecPre pre;
+    pre.mine = 0u; pre.o0 = pre.o1 = pre.o2 = pre.o3 = make_uint4(0u, 0u, 0u, 0u);
+    if (NT == 1024) {
+      const int t = (int)threadIdx.x;
+      pre.mine = hk[t & 127];
+      const uint4 *src = reinterpret_cast<const uint4 *>(hk + (t >> 7) * 16);
+      pre.o0 = src[0]; pre.o1 = src[1]; pre.o2 = src[2]; pre.o3 = src[3];
+    }
+    return pre;
+  }
+  struct SpecResult { uint32_t tau; int ok; };
+  __device__ __forceinline__ SpecResult spec_select(const SpecPre &pre, int H, int K, const uint32_t *hk, const int *hs, uint32_t *bitmap, int *gearr, int S, int *surv,
+                                                    int *res) {
     const int t = (int)threadIdx.x, n = nt();
     const int lsh = H <= 128 ? 7 : 8, L = 1 << lsh;
     const int q = t & (L - 1), part = t >> lsh;
-    const int per = ctcbeam::div_p2(L << lsh, n);  // keys per part: 16 (1024 threads, H <= 128) ... a multiple of 8 when n <= 1024
-    const uint32_t mine = hk[q];
-    const uint4 *src = reinterpret_cast<const uint4 *>(hk + part * per);
+    uint32_t mine;
     int ge = 0;
-    if (per == 16) {
-      const uint4 o0 = src[0], o1 = src[1], o2 = src[2], o3 = src[3];
-      ge = count_ge4(o3, mine, count_ge4(o2, mine, count_ge4(o1, mine, count_ge4(o0, mine, 0))));
+    if (NT == 1024 && H <= 128) {
+      mine = pre.mine;
+      ge = count_ge4(pre.o3, mine, count_ge4(pre.o2, mine, count_ge4(pre.o1, mine, count_ge4(pre.o0, mine, 0))));
     } else {
+      const int per = ctcbeam::div_p2(L << lsh, n);  // keys per part: a multiple of 8 when n <= 1024
+      mine = hk[q];
+      const uint4 *src = reinterpret_cast<const uint4 *>(hk + part * per);
       for (int i = 0; i < (per >> 2); i += 2) {
         const uint4 o0 = src[i], o1 = src[i + 1];
         ge = count_ge4(o1, mine, count_ge4(o0, mine, ge));
@@ -286,13 +338,15 @@ struct DevX {
     int slot = 0;
     if (lead) {
       const int g = gearr[t];
+      gearr[t] = 0;  // (for the next frame)
       const bool valid = t < H;
       slot = valid ? hs[t] : 0;
       keep = valid && g <= K;
-      if (valid && g == K) tau_out[0] = (int)mine;
+      if (valid && g == K) { res[0] = (int)mine; res[2] = K; }
       if (keep) atomicOr(&bitmap[slot >> 5], 1u << (slot & 31));
     }
     sync();
+    const int4 rv = *reinterpret_cast<const int4 *>(res);  // (consumed behind the closing barrier)
     if (lead) {
       const int lane = t & 63;
       const int ngr = (S + 127) >> 7;  // 128-bit groups of the bitmap (at most 64: S <= 8192)
@@ -301,15 +355,17 @@ struct DevX {
       const uint4 m4 = *reinterpret_cast<const uint4 *>(bitmap + 4 * (slot >> 7));  // my own group (group 0 for lanes without a key)
       const int cnt = __popc(g4.x) + __popc(g4.y) + __popc(g4.z) + __popc(g4.w);
       const int incl = wave_scan(cnt, 0, [](int a, int b) { return a + b; });
-      const int ns = __builtin_amdgcn_readlane(incl, 63);
-      if (t == 0) tau_out[2] = ns;
-      const int pre = __shfl(incl - cnt, slot >> 7, 64);  // survivors in the groups below mine
+      const int pre_g = __shfl(incl - cnt, slot >> 7, 64);  // survivors in the groups below mine
       const int wi = (slot >> 5) & 3;
       const uint32_t wsel = wi == 0 ? m4.x : wi == 1 ? m4.y : wi == 2 ? m4.z : m4.w;
       const int inner = (wi > 0 ? __popc(m4.x) : 0) + (wi > 1 ? __popc(m4.y) : 0) + (wi > 2 ? __popc(m4.z) : 0) + __popc(wsel & ((1u << (slot & 31)) - 1u));
-      if (ns == K && keep) surv[pre + inner] = slot;
+      if (__builtin_amdgcn_readfirstlane(rv.z) == K && keep) surv[pre_g + inner] = slot;
     }
     sync();
+    SpecResult r;
+    r.tau = (uint32_t)__builtin_amdgcn_readfirstlane(rv.x);
+    r.ok = __builtin_amdgcn_readfirstlane(rv.z) == K ? 1 : 0;
+    return r;
   }
 
   // (a & mask) | (b & ~mask): one v_bitop3_b32 (the compiler builds it from three instructions)

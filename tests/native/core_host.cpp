@@ -60,23 +60,30 @@ struct HostX {
     const int p = (*cnt)++;
     if (p < ctcbeam::kHotCap) { hk[p] = key; hs[p] = slot; }
   }
+  using HotTicket = int *;
+  HotTicket hot_issue(bool, int *cnt) { return cnt; }
+  void hot_commit(HotTicket cnt, bool hot, uint32_t key, int slot, uint32_t *hk, int *hs) { hot_append(hot, key, slot, hk, hs, cnt); }
   void row_max_store(int *dst, float v, int V) const { if (V >= 1) memcpy(dst, &v, 4); }  // (one lane: a one-label row)
   int spec_thread() const { return 0; }
-  void spec_select(int H, int K, const uint32_t *hk, const int *hs, uint32_t *bitmap, int *scratch, int S, int *surv, int *tau_out) {
-    (void)scratch; (void)S;
-    tau_out[2] = -1;
-    if (getenv("CTC_HOST_NO_SPEC")) return;
+  void hot_append_wave(bool hot, uint32_t key, int slot, uint32_t *hk, int *hs, int *cnt) { hot_append(hot, key, slot, hk, hs, cnt); }
+  struct SpecPre {};
+  SpecPre spec_pre(const uint32_t *, const int *) const { return SpecPre{}; }
+  struct SpecResult { uint32_t tau; int ok; };
+  SpecResult spec_select(const SpecPre &, int H, int K, const uint32_t *hk, const int *hs, uint32_t *bitmap, int *scratch, int S, int *surv, int *res) {
+    (void)scratch; (void)S; (void)res;
+    SpecResult r{0u, 0};
+    if (getenv("CTC_HOST_NO_SPEC")) return r;
     std::vector<int> keep;
     for (int q = 0; q < H; ++q) {
       int ge = 0;
-      for (int r = 0; r < H; ++r) ge += hk[r] >= hk[q];
+      for (int k = 0; k < H; ++k) ge += hk[k] >= hk[q];
       if (ge <= K) { keep.push_back(hs[q]); bitmap[hs[q] >> 5] |= 1u << (hs[q] & 31); }
-      if (ge == K) tau_out[0] = (int)hk[q];
+      if (ge == K) { r.tau = hk[q]; r.ok = 1; }
     }
-    tau_out[2] = (int)keep.size();
-    if ((int)keep.size() != K) return;  // equal keys straddle the boundary
+    if (!r.ok) return r;  // equal keys straddle the boundary
     std::sort(keep.begin(), keep.end());
     for (int k = 0; k < K; ++k) surv[k] = keep[k];
+    return r;
   }
   // CTC_DUMP_KEYS=<file>: every frame's slot keys, for offline studies of the select
   void probe_keys(int t, int S, const uint32_t *skey, int K, uint32_t maxkey, const float *clp, int Vc) const {

@@ -60,8 +60,11 @@ def main():
         dec.set_threads(a.threads)
     dec.set_timing(True)
     _native.check(_native.lib.ctcd_debug_set_profile(dec._handle, 1))
-    acc_sum, cpf_sum, cnt_sum = None, 0.0, 0
-    for rep in range(a.repeat):  # (the LM build keeps 64 stamps per wave = 3 frames per launch: average over several launches)
+    MARK = 1 << 62
+    groups = {}  # stamps per frame -> list of [waves, stamps] arrays of clock differences (marker -> stamp 0 -> ... -> next marker)
+    frame_clocks = []
+    kernel_ms = 0.0
+    for rep in range(a.repeat):  # (the LM build keeps 64 stamps per wave: average over several launches)
         _native.check(_native.lib.ctcd_debug_timeline(dec._handle, a.frame0 + 37 * rep, a.frames, None))
         dec.decode_device(lp)
         torch.cuda.synchronize()
@@ -77,35 +80,35 @@ def main():
         nw = int((buf[:, 0] != 0).sum())
         n = int((buf[0] != 0).sum())
         assert n < cap, "the recorded frames do not fit the timeline buffer: fewer --frames"
-        per = n // a.frames
-        t = buf[:nw, :n].astype(np.float64)
-        d = np.diff(t, axis=1)
-        acc = np.zeros((nw, per))
-        cnt = 0
-        for f in range(1, a.frames - 1):  # whole frames only
-            acc += d[:, f * per:(f + 1) * per]
-            cnt += 1
-        acc_sum = acc if acc_sum is None else acc_sum + acc
-        cnt_sum += cnt
-        cpf_sum += float((t[0, (a.frames - 1) * per] - t[0, per]) / max(a.frames - 2, 1))
-    acc = acc_sum / max(cnt_sum, 1)
-    cnt = cnt_sum
-    clocks_per_frame = cpf_sum / a.repeat
-    print("timeline build: kernel %.3f ms; %d waves, %d stamps per frame, %.0f clocks per frame (%.2f GHz if every frame takes kernel/T)"
-          % (kernel_ms, nw, per, clocks_per_frame, clocks_per_frame / (kernel_ms * 1e3 / a.T) / 1e3))
-    labels = LABELS if per == len(LABELS) else LABELS_SPEC if per == len(LABELS_SPEC) else None
-    overhead = float(acc[:, 2].mean()) if labels else 0.0
-    print("one stamp costs about %.0f clocks (row 2 has nothing else in it)" % overhead)
+        marks = [i for i in range(n) if buf[0, i] & MARK]
+        t = (buf[:nw, :n] & (MARK - 1)).astype(np.float64)
+        for m0, m1 in zip(marks[:-1], marks[1:]):  # whole frames: marker to marker (every wave records the same sequence)
+            d = np.diff(t[:, m0:m1 + 1], axis=1)
+            groups.setdefault(m1 - m0 - 1, []).append(d)
+            frame_clocks.append(float(t[0, m1] - t[0, m0]))
+    per = max(groups, key=lambda k: len(groups[k]))
+    acc = np.mean(groups[per], axis=0)
+    cnt = len(groups[per])
+    clocks_per_frame = float(np.mean([g.sum(axis=1)[0] for g in groups[per]]))
+    print("timeline build: kernel %.3f ms; %d waves; frames recorded by stamps per frame: %s; showing the %d-stamp frames (%d of them), %.0f clocks each"
+          % (kernel_ms, nw, {k: len(v) for k, v in sorted(groups.items())}, per, cnt, clocks_per_frame))
+    # (row 0 = marker -> first stamp: the loop top; the marker itself costs what a stamp costs)
+    labels = (["(frame marker -> loop top)"] + LABELS) if per == len(LABELS) else (["(frame marker -> loop top)"] + LABELS_SPEC) if per == len(LABELS_SPEC) else None
+    overhead = float(acc[:, 3].mean()) if labels else 0.0
+    print("one stamp costs about %.0f clocks (the row '(tick -> barrier)' has nothing else in it)" % overhead)
     rows = []
-    for i in range(per):
+    for i in range(acc.shape[1]):
         lab = labels[i] if labels else "stamp %d" % i
         rows.append({"stamp": i, "what": lab, "max": float(acc[:, i].max()), "median": float(np.median(acc[:, i])), "min": float(acc[:, i].min()),
                      "per_wave": [float(v) for v in acc[:, i]]})
         print("%2d %-52s max %5.0f  med %5.0f  min %5.0f | %s" % (i, lab[:52], acc[:, i].max(), np.median(acc[:, i]), acc[:, i].min(),
                                                                  " ".join("%4.0f" % v for v in acc[:, i])))
+    per_group = {str(k): float(np.mean([g.sum(axis=1)[0] for g in v])) for k, v in groups.items()}
+    print("clocks per frame by path (stamps per frame -> clocks, stamps included):", per_group)
     if a.out:
         json.dump({"kernel_ms_timeline_build": kernel_ms, "waves": nw, "stamps_per_frame": per, "clocks_per_frame": clocks_per_frame,
-                   "stamp_overhead_clocks": overhead, "frames_averaged": cnt, "frame0": a.frame0, "rows": rows}, open(a.out, "w"), indent=1)
+                   "stamp_overhead_clocks": overhead, "frames_averaged": cnt, "frame0": a.frame0, "rows": rows,
+                   "frames_by_stamps": {str(k): len(v) for k, v in groups.items()}, "clocks_per_frame_by_stamps": per_group}, open(a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":
