@@ -491,10 +491,12 @@ struct Decoder {
     int wl = 32;
     float cut = 0.f;
     if (selected) {
-      // too few hot keys: widen the margin; many more than needed: narrow it (the ranking's cost grows with their square)
+      // too few hot keys: widen the margin; more than a quarter above K: narrow it (beyond 128 keys the ranking costs two and
+      // a half times as much).  Factors and trigger from a cost model over recorded key sets (tools/select_stats.py): falling
+      // back 3.7 k clocks, a long list 1.5 k -- random rows 970 -> 710 clocks per frame against (x2, x0.81, K + K/2 + 10).
       if (pred) {
-        if (hot < K) margin = margin < 32.f ? margin * 2.f : margin;
-        else if (hot > K + (K >> 1) + 10) margin = margin > 0.001f ? margin * 0.8125f : margin;
+        if (hot < K) margin = margin < 32.f ? margin * 1.5f : margin;
+        else if (hot > K + (K >> 2) + 3) margin = margin > 0.001f ? margin * 0.7f : margin;
       }
       cut = (best - unord_f32(tau)) + margin;  // the next threshold lies this far below the next frame's best estimate
       // the window of a frame that falls back to the histogram select: anchored at the best key, reaching twice as far down
@@ -1574,6 +1576,10 @@ struct Decoder {
       int tv0[4];
       x.uni4(&w.vars[VAR_TAU], tv0);  // [1]: the hot list's length, [2]: zero (reset with it), [3]: the danger flag
       hot = tv0[1];
+      // (Measured and dropped: a second attempt with another threshold when the list comes up short or overflows -- a pass
+      //  over the slot keys that extends or rebuilds the list.  It settles 11 of the 17 % of frames that fall back on random
+      //  rows, but the pass and the longer list it leaves -- more than 128 keys: four times the compares -- cost 3 k clocks
+      //  against the 4.4 k of falling back, and the attempts that fail pay both: +2 % kernel time.)
       if (CTC_USUAL(!last && hot >= K && hot <= kHotCap && x.spec_fits(hot) && tv0[3] == 0)) {
         // (w.hotge[]: the ranking's scratch, zero between frames; the VAR_TAU group takes the report of the K-th key's lane)
         const auto r = x.spec_select(pre, hot, K, w.list, w.lslot, w.bitmap, w.hotge, S, surv, &w.vars[VAR_TAU]);
