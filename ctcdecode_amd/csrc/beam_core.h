@@ -59,6 +59,8 @@
 
 namespace ctcbeam {
 
+struct alignas(16) Int4v { int x, y, z, w; };  // four consecutive, 16-byte aligned words fetched with one access (X::load4)
+
 struct PoolNode {   // one alive-or-retired trie node in HBM: 12 bytes (round 3; 16 before: a quarter of the kernel's HBM writes)
   int32_t parent;   // pool index, -1 for the root
   float lpc;        // the best log_prob_c seen while the node lived (path_trie.cpp:42-45)
@@ -1572,9 +1574,12 @@ struct Decoder {
     bool spec_done = false;    // the speculative select settled the frame: surv[] holds the K survivors in slot order
     int hot = 0;
     if (kSpec && CTC_USUAL(N > K)) {
-      const auto pre = x.spec_pre(w.list, w.lslot);  // (the ranking's first reads, in flight with the one below)
+      // [1]: the hot list's length, [2]: zero (reset with it), [3]: the danger flag -- requested FIRST (LDS answers in order),
+      // the ranking's first reads behind it: they are in flight while the length is looked at
+      const Int4v tvv = x.load4(&w.vars[VAR_TAU]);
+      const auto pre = x.spec_pre(w.list, w.lslot);
       int tv0[4];
-      x.uni4(&w.vars[VAR_TAU], tv0);  // [1]: the hot list's length, [2]: zero (reset with it), [3]: the danger flag
+      x.uni4v(tvv, tv0);
       hot = tv0[1];
       // (Measured and dropped: a second attempt with another threshold when the list comes up short or overflows -- a pass
       //  over the slot keys that extends or rebuilds the list.  It settles 11 of the 17 % of frames that fall back on random

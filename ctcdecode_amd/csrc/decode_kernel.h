@@ -124,6 +124,12 @@ struct DevX {
     out[0] = __builtin_amdgcn_readfirstlane(v.x); out[1] = __builtin_amdgcn_readfirstlane(v.y);
     out[2] = __builtin_amdgcn_readfirstlane(v.z); out[3] = __builtin_amdgcn_readfirstlane(v.w);
   }
+  // ... in two halves: the request, and the move to scalar registers (whatever is requested in between rides behind it)
+  __device__ __forceinline__ ctcbeam::Int4v load4(const int *p) const { return *reinterpret_cast<const ctcbeam::Int4v *>(p); }
+  __device__ __forceinline__ void uni4v(const ctcbeam::Int4v &v, int *out) const {
+    out[0] = __builtin_amdgcn_readfirstlane(v.x); out[1] = __builtin_amdgcn_readfirstlane(v.y);
+    out[2] = __builtin_amdgcn_readfirstlane(v.z); out[3] = __builtin_amdgcn_readfirstlane(v.w);
+  }
   __device__ __forceinline__ float unif(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   // issue priority of this wave among the waves of its SIMD (0 = default .. 3).  (Raising it for the wave that works
   // alone in a phase, or for the child-scoring waves of phase B, was measured: neutral to 0.6 % slower -- not used.)
@@ -231,6 +237,7 @@ struct DevX {
     return p;
   }
   __device__ __forceinline__ void hot_commit(HotTicket p, bool hot, uint32_t key, int slot, uint32_t *hk, int *hs) {
+    asm volatile("" : "+v"(p));  // (the place is first LOOKED AT here: the compiler otherwise waits for it right behind the atomic)
     if (hot) {
       p = p < ctcbeam::kHotCap ? p : ctcbeam::kHotCap;
       hk[p] = key; hs[p] = slot;
@@ -294,7 +301,9 @@ struct DevX {
   //   nobody reads LDS behind the closing barrier.
   // res[2] must be zero on entry.  Returns {the K-th key, 1} or {-, 0}: then equal keys straddle the boundary and nothing
   // was written to surv[].  Three barriers; everything is visible when it returns.
-  // (Measured and dropped: stages 1 and 2 as one stage without LDS traffic -- every wave holds the list in two registers and
+  // (Measured and dropped: one key per lane + sixteen readlanes into scalar compare operands instead of four broadcast
+  //  128-bit reads -- sixteen times fewer LDS bytes, 1.5 % slower: the stage is bound by the instructions every wave issues
+  //  behind the barrier, not by LDS bandwidth.  Stages 1 and 2 as one stage without LDS traffic -- every wave holds the list in two registers and
   //  ranks eight keys of its own through scalar registers: readlane, two compares, two population counts, writelane; one
   //  barrier less, no atomics -- 3 % SLOWER: ~85 instructions on all sixteen waves against ~45 + a two-wave stage.)
   struct SpecPre { uint32_t mine; uint4 o0, o1, o2, o3; };
@@ -321,6 +330,11 @@ struct DevX {
     int ge = 0;
     if (NT == 1024 && H <= 128) {
       mine = pre.mine;
+#if defined(CTC_EXP_TICKS)
+      tick();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tick();
+#endif
       ge = count_ge4(pre.o3, mine, count_ge4(pre.o2, mine, count_ge4(pre.o1, mine, count_ge4(pre.o0, mine, 0))));
     } else {
       const int per = ctcbeam::div_p2(L << lsh, n);  // keys per part: a multiple of 8 when n <= 1024
@@ -331,6 +345,10 @@ struct DevX {
         ge = count_ge4(o1, mine, count_ge4(o0, mine, ge));
       }
     }
+#if defined(CTC_EXP_TICKS)
+    asm volatile("" : "+v"(ge));
+    tick();
+#endif
     atomicAdd(&gearr[q], ge);
     sync();
     const bool lead = t < L;  // (whole waves)

@@ -30,6 +30,8 @@ struct HostX {
   void sync_full() {}
   int uni(int v) const { return v; }
   void uni4(const int *p, int *out) const { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = p[3]; }
+  ctcbeam::Int4v load4(const int *p) const { return ctcbeam::Int4v{p[0], p[1], p[2], p[3]}; }
+  void uni4v(const ctcbeam::Int4v &v, int *out) const { out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
   int group() const { return 0; }
   int ngroups() const { return 1; }
   int lane() const { return 0; }
