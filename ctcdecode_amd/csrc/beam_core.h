@@ -45,6 +45,7 @@
 #include <stdint.h>
 
 #include "exact_math.h"
+#include "exact_math_f64.h"
 #include "lm_tables.h"
 #include "stl_emul.h"
 #if defined(CTC_ASSUME_CHECKED)
@@ -329,12 +330,8 @@ struct StepIn {
 CTC_HD int div_p2(int v, int d) { return v >> __builtin_ctz((unsigned)d); }
 CTC_HD int ceil_div_p2(int v, int d) { return div_p2(v + d - 1, d); }
 
-CTC_HD double ctc_log_f64(double v) {  // std::log on a double, host or device
-#if defined(__HIP_DEVICE_COMPILE__)
-  return log(v);
-#else
-  return __builtin_log(v);
-#endif
+CTC_HD double ctc_log_f64(double v) {  // std::log on a double as the reference's C library evaluates it, host or device (exact_math_f64.h)
+  return ctcmath::log_f64(v, ctcmath::tables64());
 }
 
 CTC_HD int ceil_log2_u32(uint32_t v) {  // smallest s with (1 << s) >= v, v >= 1

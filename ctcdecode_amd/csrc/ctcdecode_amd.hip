@@ -25,6 +25,7 @@
 #include "../../include/ctcdecode_amd.h"
 #define CTC_EXACT_MATH_HOST_TABLES
 #include "decode_kernel.h"
+#include "exact_math_f64.h"
 #include "lm_build.h"
 #include "compact_results.h"
 
@@ -39,11 +40,14 @@ using namespace ctcdk;
 #undef CTC_X_EXTERN
 
 
-// prob -> log-prob exactly as decoder_utils.cpp:42 : float(log(double(p) + FLT_MIN)).  The device log() is within
-// 1 ulp of the correctly rounded double; the element is flagged (and later recomputed with the host C library the
-// reference binds to) whenever that uncertainty could change the float it rounds to, so the result is bit-exact.
-__global__ void prob_to_log_kernel(const float *in, float *out, size_t n, const int32_t *seq_lens, int T, int V, unsigned *n_flag,
-                                   unsigned long long *flag_idx, unsigned flag_cap) {
+// The data of the bit-exact binary64 log / exp (exact_math_f64.h): the vocabulary pruning and the probability -> log
+// conversion evaluate exactly what the reference's C library evaluates (decoder_utils.cpp:16,29,42), on the device.
+#define g_t64 (ctcmath::tables64())
+
+// prob -> log-prob exactly as decoder_utils.cpp:42 : float(log(double(p) + FLT_MIN)), every element, bit for bit.
+// (Rounds 1-3 used the device library's log() and sent the elements whose float rounding it could not guarantee through
+//  the host's libm; the restated routine needs no second opinion.)
+__global__ void prob_to_log_kernel(const float *in, float *out, size_t n, const int32_t *seq_lens, int T, int V) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t tv = (size_t)T * V;
@@ -53,24 +57,8 @@ __global__ void prob_to_log_kernel(const float *in, float *out, size_t n, const 
       const int t = (int)((i - b * tv) / (size_t)V);
       if (t >= seq_lens[b]) continue;
     }
-    const double y = log((double)in[i] + (double)FLT_MIN);
-    const float f = (float)y;
-    const double eps = fabs(y) * 0x1p-50;
-    if ((float)(y - eps) != f || (float)(y + eps) != f || !(y == y)) {
-      unsigned k = atomicAdd(n_flag, 1u);
-      if (k < flag_cap) flag_idx[k] = (unsigned long long)i;
-    }
-    out[i] = f;
+    out[i] = (float)ctcmath::log_f64((double)in[i] + (double)FLT_MIN, g_t64);
   }
-}
-// flagged elements: values to a contiguous buffer, host-computed logs back (one transfer each way per chunk)
-__global__ void gather_elems_kernel(const float *in, const unsigned long long *idx, unsigned n, float *out) {
-  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) out[k] = in[idx[k]];
-}
-__global__ void scatter_elems_kernel(const float *vals, const unsigned long long *idx, unsigned n, float *out) {
-  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) out[idx[k]] = vals[k];
 }
 
 // Raw-logit input (log_input == 2, an extension: the reference's callers run log_softmax themselves): one wave per frame,
@@ -111,10 +99,13 @@ __global__ void __launch_bounds__(256) log_softmax_rows_kernel(const float *in, 
 // ------------------------------------------------------------------------------------------------ vocabulary prune
 // get_pruned_log_probs (decoder_utils.cpp:10-45) for every frame, one wave per frame, no barriers: the top
 // min(cutoff_top_n, V) values in descending order (and, with cutoff_prob < 1, the reference's cumulative cut).
-// The order std::sort gives EQUAL values, and double-precision libm roundings, are toolchain behaviour the reference
-// inherits; whenever a frame's result could depend on either (equal values at or above the cut, a cumulative sum
-// within rounding distance of cutoff_prob, a borderline float rounding of log) the frame is flagged and recomputed on
-// the host with the real std::sort / libm (host_prune_row below).  Everything else is decided here, exactly.
+// The order std::sort gives EQUAL values is toolchain behaviour the reference inherits, and its cumulative cut is a
+// sequential chain of binary64 log / exp: whenever a frame's result could depend on either (equal values at or above the
+// cut, a cumulative sum within rounding distance of cutoff_prob) the frame is flagged and settled by prune_resolve_kernel
+// -- on the device: a replay of libstdc++'s std::sort and the chain with the bit-exact log / exp of exact_math_f64.h.
+// Everything else is decided here, exactly (the kept probabilities' logs with the same bit-exact log).
+// NaN: the reference's comparator is not a strict weak order on rows that hold one (its std::sort call is undefined
+// behaviour there); here a NaN ranks below every number, -inf included, and is otherwise carried through.
 constexpr int kPruneCand = 256;  // capacity of the pre-filter candidate list per frame
 
 struct PruneArgs {
@@ -131,6 +122,7 @@ struct PruneArgs {
 
 __device__ __forceinline__ uint32_t prune_key(float v) {  // order of the doubles the reference compares; -0 == +0
   uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 1u;  // NaN: below every number (key 0 = no element)
   if (u == 0x80000000u) u = 0;
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
@@ -318,10 +310,7 @@ __global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
       const int idx = lidx[q];
       float v = x[idx];
       if (!a.log_input) {  // decoder_utils.cpp:42
-        const double y = log((double)v + (double)FLT_MIN);
-        v = (float)y;
-        const double eps = fabs(y) * 0x1p-50;
-        if ((float)(y - eps) != v || (float)(y + eps) != v || !(y == y)) flag = true;
+        v = (float)ctcmath::log_f64((double)v + (double)FLT_MIN, g_t64);
       }
       if (dup <= 1) { och[rank] = idx; olp[rank] = v; sidx[rank] = idx; }
     }
@@ -331,7 +320,7 @@ __global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
       // decoder_utils.cpp:25-32: cum = log_sum_exp(cum, log p_i) starting from cum = 0.0 (sic), i.e. after i+1 terms
       // cum = log(1 + p_0 + ... + p_i); keep going until cum >= cutoff_prob or cutoff_top_n entries.  Evaluated here
       // as a wave-parallel prefix sum (differs from the reference's sequential double chain by ~1e-14 relative); a
-      // frame where any partial sum comes within 1e-9 of the threshold is left to the host.
+      // frame where any partial sum comes within 1e-9 of the threshold is left to prune_resolve_kernel's exact chain.
       int stop = kept;  // number of entries kept
       double carry = 0.0;
       for (int i0 = 0; i0 < kept && stop == kept; i0 += 64) {
@@ -380,9 +369,9 @@ __global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
 // Requires V % 4 == 0 (16-byte aligned rows), V <= 1024 * F4, cutoff_top_n <= 64.
 // decoder_utils.cpp:25-32 for one frame, by one wave: the kept candidates (sidx[0, kept): their labels, best first) are cut
 // where the running sum of their probabilities reaches cutoff_prob (the reference accumulates log(1 + sum): its running
-// value starts at 0.0 in log space).  The device's exp()/log() may differ from the host C library's in the last place:
-// whenever the comparison with cutoff_prob could go either way before (or at) the stopping point, `flag` is raised and the
-// host decides the frame.
+// value starts at 0.0 in log space).  This is the fast form -- a wave-parallel prefix sum and the device library's
+// exp()/log(), not the reference's sequential chain: whenever the comparison with cutoff_prob could go either way before (or
+// at) the stopping point, `flag` is raised and prune_resolve_kernel walks the chain exactly (prune_exact_cut).
 __device__ __forceinline__ int prune_cumulative_cut(const PruneArgs &a, const float *x, const int *sidx, int kept, int lane, bool &flag) {
   int stop = kept;
   double carry = 0.0;
@@ -481,7 +470,7 @@ __global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
     __syncthreads();
     const int ns = s_cnt;
     if (wave == 0) {
-      bool flag = ns > kPruneCand;  // more values above the bound than the list holds: the host decides this frame
+      bool flag = ns > kPruneCand;  // more values above the bound than the list holds: prune_resolve_kernel decides this frame
       int kept = 0;
       int *och = a.ch + (size_t)r * a.stride;
       float *olp = a.lp + (size_t)r * a.stride;
@@ -508,10 +497,7 @@ __global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
             const int idx = cidx[q];
             float v = cval[q];
             if (!a.log_input) {  // decoder_utils.cpp:42
-              const double y = log((double)v + (double)FLT_MIN);
-              v = (float)y;
-              const double eps = fabs(y) * 0x1p-50;
-              if ((float)(y - eps) != v || (float)(y + eps) != v || !(y == y)) flag = true;
+              v = (float)ctcmath::log_f64((double)v + (double)FLT_MIN, g_t64);
             }
             och[gg] = idx; olp[gg] = v; sval[gg] = cval[q];  // (sval: the row's own value, before any prob -> log conversion)
           }
@@ -535,12 +521,14 @@ __global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
   }
 }
 
-// Flagged frames, second chance on the device.  Most flags are ties: equal values at or above the cut, whose order (and,
+// Flagged frames are settled here, on the device.  Most flags are ties: equal values at or above the cut, whose order (and,
 // at the cut, which of them are kept) is whatever std::sort leaves behind -- a function of the whole row.  One workgroup
 // per flagged frame replays that std::sort call (decoder_utils.cpp:19-20: (index, double) pairs in index order, compared
-// on the value alone) with stl_emul.h's workgroup-parallel introsort, takes the first min(top_n, V) pairs and applies the
-// cumulative cut.  What remains for the host (n_host / host_rows): frames with a NaN, borderline libm roundings (the
-// prob -> log conversion, the cumulative sum next to cutoff_prob), rows too long for the workgroup's LDS.
+// on the value alone) with stl_emul.h's workgroup-parallel introsort, takes the first min(top_n, V) pairs, converts them
+// with the bit-exact binary64 log and walks the cumulative cut as the reference does: a sequential chain of
+// log_sum_exp<double> (prune_exact_cut).  Nothing is left for the host (rounds 1-3 sent borderline libm roundings, NaN rows
+// and rows too long for the workgroup's LDS there: the first are exact now, the second defined -- prune_key --, the third
+// sort in a per-workgroup block of global memory, slowly).
 struct WgSortX {
   uint32_t *wsum;  // one word per wave (shared)
   // exclusive prefix (in thread order) and total of one word per thread; contains a barrier
@@ -575,10 +563,26 @@ __host__ __device__ inline size_t prune_resolve_lds_bytes(int V, int n) {
   return (size_t)V * 8 + (size_t)2 * (V + 2) * 2 + (size_t)6 * prune_resolve_task_cap(V) * 2 + (size_t)2 * (V / 2 + 1) * 2 + 3 * 64 * 4 + 64 +
          (size_t)n * 4 + 64;
 }
-__global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArgs a, unsigned *n_host, unsigned *host_rows) {
-  extern __shared__ __attribute__((aligned(16))) char rsm[];
-  __shared__ int s_bad;
+// decoder_utils.cpp:25-32 to the letter, by one thread: cum = log_sum_exp<double>(cum, log p_i) from cum = 0.0 over the sorted
+// candidates until cum >= cutoff_prob or cutoff_top_n of them are taken; every log / exp the bit-exact one.
+__device__ int prune_exact_cut(const PruneArgs &a, const float *row, const int *sidx, int n) {
+  double cum = 0.0;
+  int keep = 0;
+  for (int i = 0; i < n; ++i) {
+    const double v = (double)row[sidx[i]];
+    cum = ctcmath::lse_f64(cum, a.log_input ? v : ctcmath::log_f64(v, g_t64), g_t64);
+    ++keep;
+    if (cum >= a.cutoff_prob || keep >= a.top_n) break;
+  }
+  return keep;
+}
+
+// far != nullptr: the sort's arrays do not fit the workgroup's LDS (vocabularies beyond ~11 000 labels): they live in a block
+// of global memory per workgroup (far_stride bytes each; every barrier of the sort is a full fence already).
+__global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArgs a, char *far, size_t far_stride) {
+  extern __shared__ __attribute__((aligned(16))) char rsm_lds[];
   __shared__ uint32_t s_wsum[kResolveThreads / 64];
+  char *rsm = far ? far + (size_t)blockIdx.x * far_stride : rsm_lds;
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int V = a.V, n = a.top_n < V ? a.top_n : V;
   const int tcap = prune_resolve_task_cap(V);
@@ -591,67 +595,26 @@ __global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArg
   for (unsigned k = blockIdx.x; k < nf; k += gridDim.x) {
     const long long r = (long long)a.flag_rows[k];
     const float *row = a.in + (size_t)r * V;
-    if (tid == 0) s_bad = 0;
     __syncthreads();
-    bool nan = false;
-    for (int i = tid; i < V; i += kResolveThreads) {
-      const float f = row[i];
-      nan |= f != f;
-      v[i] = ((unsigned long long)prune_key(f) << 32) | (unsigned)i;
-    }
-    if (nan) s_bad = 1;
+    for (int i = tid; i < V; i += kResolveThreads) v[i] = ((unsigned long long)prune_key(row[i]) << 32) | (unsigned)i;
     __syncthreads();
-    if (!s_bad) {
-      // decoder_utils.cpp:19-20: (index, double) pairs in index order, std::sort on the value alone, descending
-      // (stl_emul.h: long ranges split by the whole workgroup, the rest by one thread per range; only the ranges that reach
-      //  the first n places -- the prune pass keeps the best top_n of a row)
-      stlemu::sort_prefix_parallel(x, v, V, n, kResolveBigCut, [](unsigned long long e) { return (uint32_t)(e >> 32); }, Lp, Rp, cur, nxt, small,
-                                   cnt, bstack);
-      if (tid < 64) {
-        bool flag = false;
-        int *och = a.ch + (size_t)r * a.stride;
-        float *olp = a.lp + (size_t)r * a.stride;
-        for (int q = lane; q < n; q += 64) {
-          const int idx = (int)(uint32_t)v[q];
-          float val = row[idx];
-          if (!a.log_input) {  // decoder_utils.cpp:42
-            const double y = log((double)val + (double)FLT_MIN);
-            val = (float)y;
-            const double eps = fabs(y) * 0x1p-50;
-            if ((float)(y - eps) != val || (float)(y + eps) != val || !(y == y)) flag = true;
-          }
-          och[q] = idx; olp[q] = val; sidx[q] = idx;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
-        flag = __ballot(flag) != 0ull;
-        int len = n;
-        if (a.cutoff_prob < 1.0 && !flag) len = prune_cumulative_cut(a, row, sidx, n, lane, flag);
-        if (lane == 0) {
-          if (flag) s_bad = 1;
-          else a.cnt[r] = len;
-        }
+    // decoder_utils.cpp:19-20: (index, double) pairs in index order, std::sort on the value alone, descending
+    // (stl_emul.h: long ranges split by the whole workgroup, the rest by one thread per range; only the ranges that reach
+    //  the first n places -- the prune pass keeps the best top_n of a row)
+    stlemu::sort_prefix_parallel(x, v, V, n, kResolveBigCut, [](unsigned long long e) { return (uint32_t)(e >> 32); }, Lp, Rp, cur, nxt, small,
+                                 cnt, bstack);
+    if (tid < 64) {
+      int *och = a.ch + (size_t)r * a.stride;
+      float *olp = a.lp + (size_t)r * a.stride;
+      for (int q = lane; q < n; q += 64) {
+        const int idx = (int)(uint32_t)v[q];
+        float val = row[idx];
+        if (!a.log_input) val = (float)ctcmath::log_f64((double)val + (double)FLT_MIN, g_t64);  // decoder_utils.cpp:42
+        och[q] = idx; olp[q] = val; sidx[q] = idx;
       }
-      __syncthreads();
+      __threadfence_block();  // the wave's own writes (LDS or global) are visible to its lane 0
+      if (lane == 0) a.cnt[r] = a.cutoff_prob < 1.0 ? prune_exact_cut(a, row, sidx, n) : n;
     }
-    if (tid == 0 && s_bad) host_rows[atomicAdd(n_host, 1u)] = (unsigned)r;
-    __syncthreads();
-  }
-}
-
-// Flagged frames: rows to a contiguous staging buffer, and host-resolved records back into the candidate lists.
-__global__ void gather_rows_kernel(const float *in, const unsigned *rows, int V, float *out) {
-  const float *src = in + (size_t)rows[blockIdx.x] * V;
-  float *dst = out + (size_t)blockIdx.x * V;
-  for (int i = threadIdx.x; i < V; i += blockDim.x) dst[i] = src[i];
-}
-__global__ void scatter_pruned_kernel(const int32_t *recs, const unsigned *rows, int stride, int *cnt, int *ch, float *lp) {
-  const int32_t *r = recs + (size_t)blockIdx.x * (1 + 2 * (size_t)stride);
-  const size_t row = rows[blockIdx.x];
-  const int n = r[0];
-  if (threadIdx.x == 0) cnt[row] = n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    ch[row * stride + i] = r[1 + i];
-    lp[row * stride + i] = __int_as_float(r[1 + stride + i]);
   }
 }
 
@@ -722,6 +685,20 @@ __global__ void debug_math_kernel(int mode, uint32_t start, uint32_t stride, con
     const float x = ctcmath::bits_to_f32(start + (uint32_t)i * stride);
     out[i] = mode == 0 ? ctcmath::expf_nonpos(x, tbl) : ctcmath::logf_normal(x, tbl);
   }
+}
+
+// binary64 log / exp / log_sum_exp of exact_math_f64.h on float images (modes 3..6 of ctcd_debug_math_check)
+__global__ void debug_math64_kernel(int mode, uint32_t start, uint32_t stride, const float *xs, const float *ys, uint64_t *out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r;
+  if (mode == 6) {
+    r = ctcmath::lse_f64((double)xs[i], (double)ys[i], g_t64);
+  } else {
+    const double x = (double)ctcmath::bits_to_f32(start + (uint32_t)i * stride);
+    r = mode == 3 ? ctcmath::log_f64(x, g_t64) : mode == 4 ? ctcmath::log_f64(x + (double)FLT_MIN, g_t64) : ctcmath::exp_f64(x, g_t64);
+  }
+  out[i] = ctcmath::f64_to_bits(r);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -835,9 +812,10 @@ struct ctcd_decoder {
   int cu_sharing = -1;       // ctcd_set_cu_sharing: 1 = always launch the two-workgroups-per-CU build, 0 = never, -1 = when B > #CUs
   Buf pool, status, tables, logp, lsm, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
   Buf prune_in, prune_out, st_lens;  // own staging: the host-pointer entry points keep their tensors in stage_in/out
-  long long prune_host_rows = 0;  // frames of the last call that were resolved on the host
-  long long prune_flagged_rows = 0;  // frames the prune pass could not settle itself (device tie replay + host)
-  bool no_prune_resolve = false;     // tests: send every flagged frame to the host
+  long long prune_flagged_rows = 0;  // frames of the last call the fast prune pass flagged (settled by prune_resolve_kernel)
+  unsigned *h_flagged = nullptr;     // page-locked: that count, copied behind the kernels
+  bool flagged_pending = false;
+  bool resolve_in_global = false;    // tests: the std::sort replay's arrays in global memory whatever the row length
   bool tables_ready = false;
   bool timing = false;
   bool profile = false, dbg_on = false;
@@ -924,44 +902,6 @@ Dims make_dims(int beam, int V, int cutoff_top_n, double cutoff_prob, bool lm = 
   return d;
 }
 
-// One frame of get_pruned_log_probs exactly as the reference computes it (decoder_utils.cpp:10-45): the same
-// std::sort call on (index, double) pairs, the same libm log/exp.  Used only for frames the GPU flagged (equal values
-// at the cut, borderline roundings), so that toolchain-defined behaviour is reproduced by the toolchain itself.
-template <class T>
-T host_log_add(T a, T b) {
-  const T neg = -std::numeric_limits<T>::max();
-  if (a <= neg) return b;
-  if (b <= neg) return a;
-  const T m = std::max(a, b);
-  return std::log(std::exp(a - m) + std::exp(b - m)) + m;
-}
-
-int host_prune_row(const float *row, int V, double cutoff_prob, int top_n, int log_input, int *ch, float *lp) {
-  std::vector<std::pair<int, double>> pv;
-  pv.reserve(V);
-  for (int i = 0; i < V; ++i) pv.emplace_back(i, (double)row[i]);
-  size_t keep = (size_t)V;
-  if (std::log(cutoff_prob) < 0.0 || (size_t)top_n < keep) {
-    std::sort(pv.begin(), pv.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.second > b.second; });
-    if (std::log(cutoff_prob) < 0.0) {
-      double cum = 0.0;
-      keep = 0;
-      for (size_t i = 0; i < pv.size(); ++i) {
-        cum = host_log_add(cum, log_input ? pv[i].second : std::log(pv[i].second));
-        ++keep;
-        if (cum >= cutoff_prob || keep >= (size_t)top_n) break;
-      }
-    } else {
-      keep = (size_t)top_n;
-    }
-  }
-  for (size_t i = 0; i < keep; ++i) {
-    ch[i] = pv[i].first;
-    lp[i] = (float)(log_input ? pv[i].second : std::log(pv[i].second + (double)FLT_MIN));
-  }
-  return (int)keep;
-}
-
 int check_args(int B, int T, int V, int beam, int cutoff_top_n, int blank_id, const void *probs, const void *tok,
                const void *ts, const void *sc, const void *ln) {
   if (B < 0 || T < 0 || V <= 0 || beam <= 0 || cutoff_top_n <= 0) return fail(CTCD_EINVAL, "B, T >= 0 and V, beam_width, cutoff_top_n > 0 required");
@@ -1012,6 +952,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   DeviceGuard guard_(d->device);
   if (d->fg_in) (void)hipFree(d->fg_in);
   if (d->h_cnt) (void)hipHostFree(d->h_cnt);
+  if (d->h_flagged) (void)hipHostFree(d->h_flagged);
   if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
   if (d->ev_in) (void)hipEventDestroy(d->ev_in);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->ev3); }
@@ -1161,13 +1102,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   }
 
   const float *logp = probs;
-  d->prune_host_rows = 0;
   d->prune_flagged_rows = 0;
+  d->flagged_pending = false;
   if (dims.use_rank_table && T > 0) {
     // vocabulary prune pass (also converts the kept probabilities to log space when log_input == 0)
     const long long rows = (long long)B * T;
     const int stride = dims.Vc_max;
-    unsigned cap = 1u << 16;
+
     if ((rc = d->pr_cnt.ensure((size_t)rows * 4))) return rc;
     if ((rc = d->pr_ch.ensure((size_t)rows * stride * 4))) return rc;
     if ((rc = d->pr_lp.ensure((size_t)rows * stride * 4))) return rc;
@@ -1190,122 +1131,44 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     // (measured: a persistent grid of 1280 or 2560 workgroups is slower, 16 k / 32 k the same)
     const int blocks_launch = wg_kernel ? (int)std::min<long long>(rows, 256 * 32) : blocks;
     HIP_TRY(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psm_launch));
-    unsigned nf = 0, nh = 0;
-    unsigned *n_flag = nullptr, *flag_rows = nullptr, *host_rows = nullptr;
+    // Frames the fast pass cannot settle (ties at the cut, a cumulative sum next to cutoff_prob) are flagged and settled by
+    // prune_resolve_kernel right behind it -- on the device, on the same stream: no read-back, no host arithmetic, no
+    // synchronisation before the decode kernel.  The flag list holds every frame of the call (rows words).
+    const unsigned cap = (unsigned)std::min<long long>(rows, 0x7fffffffLL);
+    if ((rc = d->flags.ensure(8 + (size_t)cap * 4))) return rc;
+    unsigned *n_flag = (unsigned *)d->flags.p, *flag_rows = (unsigned *)((char *)d->flags.p + 8);
     d->prune_timed = false;
-    const size_t rlds = prune_resolve_lds_bytes(V, std::min(cutoff_top_n, V));
-    const bool resolve_on_device = V <= kResolveMaxV && rlds + 1024 <= (size_t)d->max_lds && !d->no_prune_resolve;
-    if (resolve_on_device) HIP_TRY(hipFuncSetAttribute((const void *)prune_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-    for (int attempt = 0; attempt < 2; ++attempt) {  // (a second pass only when more frames were flagged than the list held)
-      if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
-      n_flag = (unsigned *)d->flags.p;
-      flag_rows = (unsigned *)((char *)d->flags.p + 8);
-      host_rows = flag_rows + cap;
-      HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));  // n_flag, n_host
-      HIP_TRY(hipMemsetAsync(d->pr_cnt.p, 0, (size_t)rows * 4, stream));
-      PruneArgs pa;
-      pa.in = probs; pa.seq_lens = seq_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
-      pa.stride = stride; pa.rows = rows; pa.cutoff_prob = cutoff_prob; pa.cnt = (int *)d->pr_cnt.p; pa.ch = (int *)d->pr_ch.p;
-      pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
-      void *pargs[] = {&pa};
-      if (d->timing) HIP_TRY(hipEventRecord(d->ev2, stream));
-      HIP_TRY(hipLaunchKernel(pfn, dim3(blocks_launch), dim3(wpb * 64), pargs, psm_launch, stream));
-      HIP_TRY(hipGetLastError());
-      if (d->timing) { HIP_TRY(hipEventRecord(d->ev3, stream)); d->prune_timed = true; }
-      // flagged frames whose outcome only depends on std::sort's treatment of equal values are settled on the device
-      if (resolve_on_device) {
-        hipLaunchKernelGGL(prune_resolve_kernel, dim3(256), dim3(kResolveThreads), rlds, stream, pa, n_flag + 1, host_rows);
-        HIP_TRY(hipGetLastError());
-      }
-      unsigned both[2] = {0, 0};
-      HIP_TRY(hipMemcpyAsync(both, n_flag, 8, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      nf = both[0];
-      nh = resolve_on_device ? both[1] : nf;
-      if (nf <= cap) break;
-      cap = nf;  // the set of flagged frames is a function of the input: the list now holds all of them
-    }
-    if (nf > cap) return fail(CTCD_EINTERNAL, "flagged-frame count changed between two passes over the same input");
-    d->prune_flagged_rows = nf;
-    if (!resolve_on_device) host_rows = flag_rows;
-    if (nh) {  // toolchain-defined cases: let the toolchain decide (real std::sort, real libm) -- batched transfers, in
-               // chunks so that the staging memory stays bounded however many frames are flagged
-      nf = nh;
-      flag_rows = host_rows;
-      std::vector<unsigned> fr(nf);
-      HIP_TRY(hipMemcpy(fr.data(), flag_rows, (size_t)nf * 4, hipMemcpyDeviceToHost));
-      const size_t rec = 1 + 2 * (size_t)stride;  // per frame: count, labels, log-probs
-      const unsigned chunk = (unsigned)std::max<size_t>(64, std::min<size_t>(nf, ((size_t)256 << 20) / ((size_t)V * 4)));
-      if ((rc = d->prune_in.ensure((size_t)chunk * V * 4))) return rc;
-      if ((rc = d->prune_out.ensure((size_t)chunk * rec * 4))) return rc;
-      std::vector<float> rowsh((size_t)chunk * V);
-      std::vector<int32_t> recs((size_t)chunk * rec);
-      for (unsigned c0 = 0; c0 < nf; c0 += chunk) {
-        const unsigned cn = std::min(chunk, nf - c0);
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(cn), dim3(256), 0, stream, probs, flag_rows + c0, V, (float *)d->prune_in.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(rowsh.data(), d->prune_in.p, (size_t)cn * V * 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        std::fill(recs.begin(), recs.begin() + (size_t)cn * rec, 0);
-        {  // the flagged frames are independent: one host thread each (up to the core count)
-          std::atomic<unsigned> next{0};
-          auto work = [&] {
-            for (;;) {
-              const unsigned k = next.fetch_add(1);
-              if (k >= cn) return;
-              int32_t *rr = recs.data() + (size_t)k * rec;
-              rr[0] = host_prune_row(rowsh.data() + (size_t)k * V, V, cutoff_prob, cutoff_top_n, log_input, rr + 1, (float *)(rr + 1 + stride));
-            }
-          };
-          const unsigned nth = std::min<unsigned>(cn, std::max(1u, std::thread::hardware_concurrency()));
-          std::vector<std::thread> pool;
-          for (unsigned i = 1; i < nth; ++i) pool.emplace_back(work);
-          work();
-          for (auto &t : pool) t.join();
-        }
-        HIP_TRY(hipMemcpyAsync(d->prune_out.p, recs.data(), (size_t)cn * rec * 4, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(scatter_pruned_kernel, dim3(cn), dim3(64), 0, stream, (const int32_t *)d->prune_out.p, flag_rows + c0, stride,
-                           (int *)d->pr_cnt.p, (int *)d->pr_ch.p, (float *)d->pr_lp.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(stream));  // recs (host memory) is reused by the next chunk
-      }
-      d->prune_host_rows = nf;
-    }
+    const size_t rbytes = prune_resolve_lds_bytes(V, std::min(cutoff_top_n, V));
+    const bool in_lds = rbytes + 1024 <= (size_t)d->max_lds && !d->resolve_in_global;
+    const int rblocks = in_lds ? 256 : 64;
+    if (in_lds) HIP_TRY(hipFuncSetAttribute((const void *)prune_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbytes));
+    const size_t rstride = (rbytes + 255) / 256 * 256;
+    if (!in_lds && (rc = d->prune_in.ensure(rstride * rblocks))) return rc;  // (rows too long for LDS: the sort's arrays in global memory)
+    HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
+    HIP_TRY(hipMemsetAsync(d->pr_cnt.p, 0, (size_t)rows * 4, stream));
+    PruneArgs pa;
+    pa.in = probs; pa.seq_lens = seq_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
+    pa.stride = stride; pa.rows = rows; pa.cutoff_prob = cutoff_prob; pa.cnt = (int *)d->pr_cnt.p; pa.ch = (int *)d->pr_ch.p;
+    pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
+    void *pargs[] = {&pa};
+    if (d->timing) HIP_TRY(hipEventRecord(d->ev2, stream));
+    HIP_TRY(hipLaunchKernel(pfn, dim3(blocks_launch), dim3(wpb * 64), pargs, psm_launch, stream));
+    HIP_TRY(hipGetLastError());
+    if (d->timing) { HIP_TRY(hipEventRecord(d->ev3, stream)); d->prune_timed = true; }
+    hipLaunchKernelGGL(prune_resolve_kernel, dim3(rblocks), dim3(kResolveThreads), in_lds ? rbytes : 0, stream, pa, in_lds ? (char *)nullptr : (char *)d->prune_in.p, rstride);
+    HIP_TRY(hipGetLastError());
+    // (statistics only: the number of flagged frames travels to page-locked memory behind the kernels; whoever asks for it
+    //  -- ctcd_last_prune_flagged_rows -- waits for the stream)
+    if (!d->h_flagged) HIP_TRY(hipHostMalloc((void **)&d->h_flagged, 8, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(d->h_flagged, n_flag, 4, hipMemcpyDeviceToHost, stream));
+    d->flagged_pending = true;
   } else if (!log_input && T > 0) {
     const size_t n = (size_t)B * T * V;
-    unsigned cap = 1u << 16;
     if ((rc = d->logp.ensure(n * 4))) return rc;
-    unsigned nf = 0;
-    unsigned *n_flag = nullptr;
-    unsigned long long *idx = nullptr;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      if ((rc = d->flags.ensure(8 + (size_t)cap * 8))) return rc;
-      n_flag = (unsigned *)d->flags.p;
-      idx = (unsigned long long *)((char *)d->flags.p + 8);
-      HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
-      if (seq_lens) HIP_TRY(hipMemsetAsync(d->logp.p, 0, n * 4, stream));  // frames past an utterance's end stay defined
-      hipLaunchKernelGGL(prob_to_log_kernel, dim3(blocks), dim3(256), 0, stream, probs, (float *)d->logp.p, n, seq_lens, T, V, n_flag, idx, cap);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      if (nf <= cap) break;
-      cap = nf;
-    }
-    if (nf > cap) return fail(CTCD_EINTERNAL, "flagged-element count changed between two passes over the same input");
-    if (nf) {  // borderline roundings (and non-finite values): recompute with the C library the reference binds to
-      if ((rc = d->prune_in.ensure((size_t)nf * 4))) return rc;
-      std::vector<float> vals(nf);
-      hipLaunchKernelGGL(gather_elems_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, probs, idx, nf, (float *)d->prune_in.p);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(vals.data(), d->prune_in.p, (size_t)nf * 4, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      for (unsigned k = 0; k < nf; ++k) vals[k] = (float)std::log((double)vals[k] + (double)FLT_MIN);
-      HIP_TRY(hipMemcpyAsync(d->prune_in.p, vals.data(), (size_t)nf * 4, hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(scatter_elems_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, (const float *)d->prune_in.p, idx, nf, (float *)d->logp.p);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipStreamSynchronize(stream));  // vals (host memory) must outlive the copy
-    }
+    if (seq_lens) HIP_TRY(hipMemsetAsync(d->logp.p, 0, n * 4, stream));  // frames past an utterance's end stay defined
+    hipLaunchKernelGGL(prob_to_log_kernel, dim3(blocks), dim3(256), 0, stream, probs, (float *)d->logp.p, n, seq_lens, T, V);
+    HIP_TRY(hipGetLastError());
     logp = (const float *)d->logp.p;
   }
 
@@ -1926,11 +1789,12 @@ int ctcd_debug_set_fixed_layout(ctcd_decoder *d, int on) {
   return CTCD_OK;
 }
 
-// Flagged prune frames: 1 (default) = the device replays std::sort for them, 0 = the host toolchain decides all of them
-// (the path that otherwise only sees libm-dependent frames).  Results are identical; the switch exists for the tests.
+// Flagged prune frames: 1 (default) = the std::sort replay keeps its arrays in LDS when the row fits, 0 = always in global
+// memory (the path of rows beyond ~11 000 labels).  Results are identical; the switch exists for the tests.  (Until round 3
+// "0" sent the flagged frames to the host toolchain; nothing goes there any more.)
 int ctcd_debug_set_prune_resolve(ctcd_decoder *d, int on) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
-  d->no_prune_resolve = on == 0;
+  d->resolve_in_global = on == 0;
   return CTCD_OK;
 }
 
@@ -1973,10 +1837,21 @@ int ctcd_debug_get_profile(ctcd_decoder *d, long long *out, int B) {
 int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,
                           const float *ys, long long n_pairs, long long *checked, long long *mismatches);
 
-// Number of frames of the last ctcd_beam_decode whose vocabulary prune was resolved on the host (ties / borderline).
-long long ctcd_last_prune_host_rows(ctcd_decoder *d) { return d ? d->prune_host_rows : -1; }
-// ... and the number the prune pass flagged in the first place (the rest were settled by the device's std::sort replay).
-long long ctcd_last_prune_flagged_rows(ctcd_decoder *d) { return d ? d->prune_flagged_rows : -1; }
+// Number of frames of the last ctcd_beam_decode whose vocabulary prune was resolved on the host: none, ever (kept for callers
+// of earlier rounds; the host path is gone).
+long long ctcd_last_prune_host_rows(ctcd_decoder *d) { return d ? 0 : -1; }
+// ... and the number the fast prune pass flagged (settled by the device's std::sort replay + exact cumulative chain).  The
+// count arrives behind the call's kernels: asking for it waits for the launch stream.
+long long ctcd_last_prune_flagged_rows(ctcd_decoder *d) {
+  if (!d) return -1;
+  if (d->flagged_pending) {
+    DeviceGuard g(d->device);
+    if (hipStreamSynchronize(d->last_stream) != hipSuccess) return -1;
+    d->prune_flagged_rows = d->h_flagged ? (long long)*d->h_flagged : 0;
+    d->flagged_pending = false;
+  }
+  return d->prune_flagged_rows;
+}
 
 // The same words, fetched without blocking: the copy into `host_status` (B words, page-locked memory for a truly
 // asynchronous copy) is enqueued on `stream` -- pass the stream the decode was launched on, before enqueuing anything else
@@ -2023,6 +1898,52 @@ int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, u
   *mismatches = 0;
   const size_t chunk = (size_t)1 << 24;
   Buf out, inx, iny;
+  if (mode >= 3 && mode <= 6) {  // binary64 log (3: log(p), 4: log(p + FLT_MIN)) / exp (5) on float images, log_sum_exp<double> on pairs (6)
+    if ((rc = out.ensure(chunk * 8))) return rc;
+    std::vector<uint64_t> h64(chunk);
+    auto same = [](double want, uint64_t got) { return (want != want && ctcmath::bits_to_f64(got) != ctcmath::bits_to_f64(got)) || ctcmath::f64_to_bits(want) == got; };
+    auto ref_lse64 = [](double x, double y) {  // decoder_utils.h:47-54, T = double
+      const double neg = -DBL_MAX;
+      if (x <= neg) return y;
+      if (y <= neg) return x;
+      const double m = x > y ? x : y;
+      return std::log(std::exp(x - m) + std::exp(y - m)) + m;
+    };
+    if (mode == 6) {
+      if (!xs || !ys || n_pairs < 0) return fail(CTCD_EINVAL, "pairs missing");
+      if ((rc = inx.ensure(chunk * 4)) || (rc = iny.ensure(chunk * 4))) return rc;
+      for (long long off = 0; off < n_pairs; off += (long long)chunk) {
+        const size_t cnt = (size_t)std::min<long long>((long long)chunk, n_pairs - off);
+        HIP_TRY(hipMemcpy(inx.p, xs + off, cnt * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(iny.p, ys + off, cnt * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(debug_math64_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, 6, 0u, 1u, (const float *)inx.p, (const float *)iny.p, (uint64_t *)out.p, cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(h64.data(), out.p, cnt * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; ++i)
+          if (!same(ref_lse64((double)xs[off + i], (double)ys[off + i]), h64[i])) ++*mismatches;
+        *checked += (long long)cnt;
+      }
+      inx.release();
+      iny.release();
+    } else {
+      for (uint64_t start = lo; start <= hi; start += (uint64_t)chunk * stride) {
+        const uint64_t cnt64 = ((uint64_t)hi - start) / stride + 1;
+        const size_t cnt = (size_t)std::min<uint64_t>(cnt64, chunk);
+        hipLaunchKernelGGL(debug_math64_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, mode, (uint32_t)start, stride, (const float *)nullptr,
+                           (const float *)nullptr, (uint64_t *)out.p, cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(h64.data(), out.p, cnt * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; ++i) {
+          const double x = (double)ctcmath::bits_to_f32((uint32_t)(start + i * stride));
+          const double want = mode == 3 ? std::log(x) : mode == 4 ? std::log(x + (double)FLT_MIN) : std::exp(x);
+          if (!same(want, h64[i])) ++*mismatches;
+        }
+        *checked += (long long)cnt;
+      }
+    }
+    out.release();
+    return CTCD_OK;
+  }
   if ((rc = out.ensure(chunk * 4))) return rc;
   std::vector<float> host(chunk);
   auto ref_lse = [](float x, float y) {  // decoder_utils.h:47-54

@@ -155,9 +155,11 @@ int ctcd_fetch_status_async(ctcd_decoder *dec, int B, int32_t *host_status, void
 
 /* Vocabulary prune bookkeeping of the last ctcd_beam_decode (0 for the no-prune configurations).  A frame in which equal
  * values sit at the cutoff_top_n boundary or among the kept ones is ordered by whatever std::sort does with the whole
- * row (decoder_utils.cpp:19-20): those frames are "flagged" by the prune pass and settled by a second device kernel that
- * replays libstdc++'s std::sort exactly.  What reaches the HOST toolchain is only what depends on its libm: a borderline
- * double rounding (prob -> log, the cumulative sum next to cutoff_prob), a NaN, or a row too long for the replay. */
+ * row (decoder_utils.cpp:19-20), and a cumulative sum next to cutoff_prob depends on the reference's sequential chain of
+ * binary64 log / exp (decoder_utils.cpp:25-32): those frames are "flagged" by the fast prune pass and settled by a second
+ * device kernel that replays libstdc++'s std::sort and walks the chain with bit-exact restatements of glibc's log / exp
+ * (exact_math_f64.h).  Nothing reaches the host toolchain since round 4: ctcd_last_prune_host_rows is always 0.
+ * ctcd_last_prune_flagged_rows waits for the call's stream (the count arrives behind the kernels). */
 long long ctcd_last_prune_flagged_rows(ctcd_decoder *dec);
 long long ctcd_last_prune_host_rows(ctcd_decoder *dec);
 
@@ -166,7 +168,8 @@ int ctcd_set_timing(ctcd_decoder *dec, int on);
 int ctcd_last_kernel_ms(ctcd_decoder *dec, float *ms);
 int ctcd_last_prune_ms(ctcd_decoder *dec, float *ms); /* the vocabulary-prune kernel of the same call (pruned configurations) */
 
-/* Test hook: device expf/logf/log_sum_exp (exact_math.h) vs the host C library over float bit patterns. */
+/* Test hook: device expf/logf/log_sum_exp (exact_math.h; modes 0..2) and binary64 log / exp / log_sum_exp<double>
+ * (exact_math_f64.h; modes 3: log(p), 4: log(p + FLT_MIN), 5: exp(x) over float bit patterns, 6: pairs) vs the host C library. */
 int ctcd_debug_math_check(ctcd_decoder *dec, int mode, uint32_t lo, uint32_t hi, uint32_t stride, const float *xs,
                           const float *ys, long long n_pairs, long long *checked, long long *mismatches);
 
@@ -176,8 +179,8 @@ int ctcd_debug_get_profile(ctcd_decoder *dec, long long *out, int B);
 /* Test hook: 1 (default) = beams <= 128 over <= 32 labels run the kernel variant with a compile-time workspace layout,
  * 0 = always the run-time layout (identical results). */
 int ctcd_debug_set_fixed_layout(ctcd_decoder *dec, int on);
-/* Test hook: 1 (default) = flagged prune frames are settled by the device's std::sort replay, 0 = all of them go to the
- * host toolchain (identical results). */
+/* Test hook: 1 (default) = the std::sort replay of flagged prune frames works in LDS when the row fits, 0 = always in
+ * global memory, the path of rows beyond ~11 000 labels (identical results). */
 int ctcd_debug_set_prune_resolve(ctcd_decoder *dec, int on);
 /* Tuning aid (instrumented build): per-wave shader-clock stamps at every workgroup barrier of batch item 0 during frames
  * [frame0, frame0 + nframes).  out == NULL arms the following decodes; out != NULL (int64 [16][ctcd_debug_timeline_cap()])

@@ -170,7 +170,7 @@ def build_core_host():
     import subprocess
 
     src = os.path.join(ROOT, "tests", "native", "core_host.cpp")
-    deps = [src] + [os.path.join(ROOT, "ctcdecode_amd", "csrc", f) for f in ("beam_core.h", "stl_emul.h", "exact_math.h", "lm_tables.h", "lm_build.h", "compact_results.h")]
+    deps = [src] + [os.path.join(ROOT, "ctcdecode_amd", "csrc", f) for f in ("beam_core.h", "stl_emul.h", "exact_math.h", "exact_math_f64.h", "exact_math_f64_tables.h", "lm_tables.h", "lm_build.h", "compact_results.h")]
     if os.path.exists(CORE_HOST_SO) and all(os.path.getmtime(CORE_HOST_SO) >= os.path.getmtime(p) for p in deps):
         return CORE_HOST_SO
     os.makedirs(os.path.dirname(CORE_HOST_SO), exist_ok=True)

@@ -172,21 +172,19 @@ def test_vocabulary_pruning_against_oracle(torch_mod, c):
     want = ou.decode(x, which="restated", **kw)
     dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(c["V"])], cutoff_top_n=c["top_n"], cutoff_prob=c.get("cutoff_prob", 1.0),
                                        beam_width=c["K"], log_probs_input=not c.get("prob_input"))
-    # frames whose order is std::sort's business (equal values at / above the cut) are flagged by the prune pass and then
-    # settled by the device's replay of std::sort; with the replay switched off the host toolchain decides them all
-    for device_replay in (True, False):
-        n.check(n.lib.ctcd_debug_set_prune_resolve(dec._handle, 1 if device_replay else 0))
+    # frames whose order is std::sort's business (equal values at / above the cut) or whose cumulative sum comes close to
+    # cutoff_prob are flagged by the fast prune pass and settled by the device's replay of std::sort + the exact chain of
+    # binary64 log / exp -- with its arrays in LDS, and (second round) in global memory, the path of very long rows.
+    # Nothing goes to the host toolchain (round 4: the host path is gone).
+    for in_lds in (True, False):
+        n.check(n.lib.ctcd_debug_set_prune_resolve(dec._handle, 1 if in_lds else 0))
         out, sc, ts, ln = dec.decode(torch_mod.from_numpy(np.ascontiguousarray(x)))
         got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
-        ou.assert_same(_with_nres(got, want), want, "device replay %s" % device_replay)
+        ou.assert_same(_with_nres(got, want), want, "replay in LDS %s" % in_lds)
         flagged, host_rows = n.lib.ctcd_last_prune_flagged_rows(dec._handle), n.lib.ctcd_last_prune_host_rows(dec._handle)
-        assert host_rows <= flagged
+        assert host_rows == 0
         if c.get("quant"):
             assert flagged > 0, "quantised inputs must exercise the tie resolution"
-        if not device_replay:
-            assert host_rows == flagged
-        elif not c.get("prob_input") and c.get("cutoff_prob", 1.0) == 1.0:
-            assert host_rows == 0, "ties alone never reach the host"
 
 
 @pytest.mark.parametrize("threads", [128, 256, 1024])
@@ -549,7 +547,7 @@ def test_host_pointer_entry_point(torch_mod):
     got = dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres)
     ou.assert_same(got, want, "host entry point")
     assert np.array_equal(nres, want["nres"])
-    # same entry point with vocabulary pruning and tied values (frames resolved on the host use their own staging buffers)
+    # same entry point with vocabulary pruning and tied values (the flagged frames' replay in LDS, then in global memory)
     lp = ou.synth_logprobs(3, 90, 64, 53, quant=0.5)
     want = ou.decode(lp, beam=24, cutoff_top_n=8, which="restated")
     B, T, V, K = 3, 90, 64, 24
@@ -561,10 +559,10 @@ def test_host_pointer_entry_point(torch_mod):
         n.check(n.lib.ctcd_beam_decode_host(h, lp.ctypes.data, None, B, T, V, K, 4, 1.0, 8, 0, 1,
                                             tok.ctypes.data, ts.ctypes.data, sc.ctypes.data, ln.ctypes.data, nres.ctypes.data))
         assert n.lib.ctcd_last_prune_flagged_rows(h) > 0 and n.lib.ctcd_last_prune_host_rows(h) == 0
-        n.check(n.lib.ctcd_debug_set_prune_resolve(h, 0))  # and with every flagged frame resolved on the host (own staging buffers)
+        n.check(n.lib.ctcd_debug_set_prune_resolve(h, 0))  # and with the replay's arrays in global memory (its own scratch buffer)
         n.check(n.lib.ctcd_beam_decode_host(h, lp.ctypes.data, None, B, T, V, K, 4, 1.0, 8, 0, 1,
                                             tok.ctypes.data, ts.ctypes.data, sc.ctypes.data, ln.ctypes.data, nres.ctypes.data))
-        assert n.lib.ctcd_last_prune_host_rows(h) > 0
+        assert n.lib.ctcd_last_prune_flagged_rows(h) > 0 and n.lib.ctcd_last_prune_host_rows(h) == 0
     finally:
         n.lib.ctcd_destroy(h)
     ou.assert_same(dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres), want, "host entry point, pruned")
@@ -687,6 +685,66 @@ def test_device_math_bit_exact_vs_host_libm(torch_mod):
     x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
     n.check(n.lib.ctcd_debug_math_check(dec._handle, 2, 0, 0, 1, x.ctypes.data, y.ctypes.data, N, ctypes.byref(chk), ctypes.byref(bad)))
     assert chk.value == N and bad.value == 0
+
+
+def test_device_math_f64_bit_exact_vs_host_libm(torch_mod):
+    """exact_math_f64.h on the GPU against the GPU box's own glibc log / exp in binary64 -- what the reference's pruning and its
+    probability -> log conversion call (decoder_utils.cpp:16,29,42; decoder_utils.h:47-54 with T = double)."""
+    import ctypes
+
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    dec = ctcdecode_amd.CTCBeamDecoder(["a", "b"], log_probs_input=True)
+    chk, bad = ctypes.c_longlong(), ctypes.c_longlong()
+    # log(p) and log(p + FLT_MIN) on every 16th positive float (subnormal .. +inf), plus the zeros, a negative and a NaN pattern
+    for mode in (3, 4):
+        n.check(n.lib.ctcd_debug_math_check(dec._handle, mode, 0x00000001, 0x7F800000, 16, None, None, 0, ctypes.byref(chk), ctypes.byref(bad)))
+        assert bad.value == 0 and chk.value > 1.3e8, (mode, chk.value, bad.value)
+        for lo in (0x00000000, 0x80000000, 0xBF800000, 0x7FC00000):
+            n.check(n.lib.ctcd_debug_math_check(dec._handle, mode, lo, lo, 1, None, None, 0, ctypes.byref(chk), ctypes.byref(bad)))
+            assert bad.value == 0, (mode, hex(lo))
+    # every float of [0.9, 1.1]: the branch around 1 of the binary64 log
+    n.check(n.lib.ctcd_debug_math_check(dec._handle, 3, 0x3F666666, 0x3F8CCCCD, 1, None, None, 0, ctypes.byref(chk), ctypes.byref(bad)))
+    assert bad.value == 0 and chk.value > 2.5e6
+    # exp on every 16th negative float (-0 .. -FLT_MAX, -inf) and on the positive ones up to 128
+    n.check(n.lib.ctcd_debug_math_check(dec._handle, 5, 0x80000000, 0xFF800000, 16, None, None, 0, ctypes.byref(chk), ctypes.byref(bad)))
+    assert bad.value == 0 and chk.value > 1.3e8
+    n.check(n.lib.ctcd_debug_math_check(dec._handle, 5, 0x00000000, 0x43000000, 16, None, None, 0, ctypes.byref(chk), ctypes.byref(bad)))
+    assert bad.value == 0
+    # log_sum_exp<double> on pairs as the cumulative cut sees them (a running value >= 0 against log-probabilities)
+    rng = np.random.default_rng(6)
+    N = 1 << 22
+    x = rng.uniform(0, 0.7, N).astype(np.float32)
+    y = (-rng.exponential(4.0, N)).astype(np.float32)
+    y[::5] = (-rng.uniform(0, 120, N)[::5]).astype(np.float32)
+    y[::1013] = -np.finfo(np.float32).max
+    y[::2027] = -np.inf
+    swap = rng.integers(0, 2, N).astype(bool)
+    x, y = np.where(swap, y, x), np.where(swap, x, y)
+    x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
+    n.check(n.lib.ctcd_debug_math_check(dec._handle, 6, 0, 0, 1, x.ctypes.data, y.ctypes.data, N, ctypes.byref(chk), ctypes.byref(bad)))
+    assert chk.value == N and bad.value == 0
+
+
+def test_prune_nan_rows_are_defined(torch_mod):
+    """A NaN among the values of a pruned frame: the reference's std::sort call is undefined behaviour there (its comparator is
+    not a strict weak order); here a NaN ranks below every number.  The call must neither hang nor touch the host, and a row
+    whose NaNs lie outside the kept top_n must decode exactly as the same row with -inf in their place."""
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    lp = ou.synth_logprobs(2, 40, 64, 71)
+    bad = lp.copy()
+    bad[:, ::3, 50:] = np.nan                  # the lowest ranks of every third frame
+    ref = lp.copy()
+    ref[:, ::3, 50:] = -np.inf
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(64)], cutoff_top_n=8, beam_width=16, log_probs_input=True)
+    a = dec.decode(torch_mod.from_numpy(bad))
+    b = dec.decode(torch_mod.from_numpy(ref))
+    for u, v in zip(a, b):
+        assert torch_mod.equal(u, v)
+    assert n.lib.ctcd_last_prune_host_rows(dec._handle) == 0
 
 
 @pytest.mark.parametrize("threads", [256, 1024])
