@@ -2108,13 +2108,17 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   // by frame block, while this kernel runs; *frames_ready (uncached memory, written by the copy stream behind every
   // block) says how many frames of every utterance have arrived.  The threads that fetch a row wait for it -- once per
   // block; a wait that lasts absurdly long gives up (status ST_INPUT_TIMEOUT) rather than hang the GPU.
+  // Giving up is sticky: the thread that gave up never spins again, and the workgroup leaves the frame loop at
+  // the next check (every sixteenth frame) -- a launch whose input never arrives costs about a second, not a second per
+  // frame.
   int ready_cached = 0;
+  bool gave_up = false;
   auto wait_frames = [&](int need) {
-    if (frames_ready != nullptr && need > ready_cached) {
+    if (frames_ready != nullptr && need > ready_cached && !gave_up) {
       for (int spins = 0;; ++spins) {
         ready_cached = x.load_system(frames_ready);
         if (ready_cached >= need) break;
-        if (spins > (1 << 20)) { w.vars[VAR_INTO] = 1; break; }  // (~1 s)
+        if (spins > (1 << 20)) { w.vars[VAR_INTO] = 1; gave_up = true; break; }  // (~1 s)
         x.nap();
       }
     }
@@ -2161,6 +2165,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
         next_cnt = stage ? d.V : 0;
         next_val = pre_lp;
       } else {
+        wait_frames(t + 2 < len ? t + 2 : len);  // (rows that are not prefetched are read here, this frame's and a look at the next)
         for (int r = tid; r < d.V; r += nt) {
           const float v = rows[(size_t)t * d.V + r];
           w.clp[r] = v;
@@ -2215,6 +2220,8 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     const int st = dec.step(in, t == len - 1, stage, pre_lp, next_cnt, next_val);
     x.mark(12);
     if (st != ST_OK) return st;
+    // (streamed input that stopped arriving: step() ended with a full fence, the flag is visible to every wave)
+    if (frames_ready != nullptr && (t & 15) == 15 && x.uni(w.vars[VAR_INTO]) != 0) return ST_INPUT_TIMEOUT;
   }
   if (LM) dec.lm_resolve_pending();
   if (ss) dec.save_state(*ss, t0 + len);

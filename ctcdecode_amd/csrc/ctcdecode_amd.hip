@@ -832,6 +832,7 @@ struct ctcd_decoder {
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_in = nullptr;
   bool no_input_streaming = false;
+  bool stall_input_test = false;
   bool general_lm_kernel = false;  // CTCD_GENERAL_LM_KERNEL=1: word models, too, run the scorer instantiations that serve every model
   bool input_timed_out = false;   // set by ctcd_check_status when an utterance reports ST_INPUT_TIMEOUT
   long long mirror_cap_override = -1;  // tests: labels the host mirror of the compact results holds (-1: a third of the worst case)
@@ -968,6 +969,7 @@ void ctcd_destroy(ctcd_decoder *d) {
 int ctcd_debug_set_host_path(ctcd_decoder *d, int input_streaming, long long mirror_cap_labels) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   if (input_streaming >= 0) d->no_input_streaming = input_streaming == 0;
+  d->stall_input_test = input_streaming == 2;  // tests: the rows are sent but "frames arrived" never advances -- the kernel must give up
   if (mirror_cap_labels >= -1) d->mirror_cap_override = mirror_cap_labels;
   return CTCD_OK;
 }
@@ -1544,8 +1546,10 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
   // block is a strided copy), each block followed by an update of the "frames arrived" counter the kernel's row fetch
   // waits on (beam_core.h decode_utterance).  Hides the 0.5 ms the 30 MB of a configs[1] batch take.
   const bool pruned_in = cutoff_prob < 1.0 || cutoff_top_n < V;
-  const bool stream_in = !probs_on_device && log_input == 1 && !pruned_in && T >= 128 && T <= 65536 && V <= 512 && nin >= ((size_t)1 << 20) &&
-                         !d->no_input_streaming && !d->profile;
+  // (V <= the workgroup size the launch will use -- decode_common: the caller's, or at least 512 -- so that the kernel
+  //  prefetches its rows: ADVICE r3; rows that are not prefetched wait as well since round 4, this keeps the fast form)
+  const bool stream_in = !probs_on_device && log_input == 1 && !pruned_in && T >= 128 && T <= 65536 && V <= (d->threads ? d->threads : 512) &&
+                         nin >= ((size_t)1 << 20) && !d->no_input_streaming && !d->profile;
   int nblk = 0;
   int blk[10];
   const int *frames_ready = nullptr;
@@ -1648,7 +1652,7 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
       HIP_TRY(hipMemcpy2DAsync(fg + 256 + (size_t)f0 * V * 4, pitch, (const char *)probs + (size_t)f0 * V * 4, pitch, (size_t)(f1 - f0) * V * 4, (size_t)B,
                                hipMemcpyHostToDevice, d->copy_stream));
       d->h_cnt[c] = f1;
-      HIP_TRY(hipMemcpyAsync(fg, &d->h_cnt[c], 4, hipMemcpyHostToDevice, d->copy_stream));
+      if (!d->stall_input_test) HIP_TRY(hipMemcpyAsync(fg, &d->h_cnt[c], 4, hipMemcpyHostToDevice, d->copy_stream));
     }
   }
   HIP_TRY(hipMemcpyAsync(out_sc, d->c_sc.p, kk * 4, hipMemcpyDeviceToHost, stream));

@@ -193,7 +193,8 @@ int ctcd_debug_beam_dump(ctcd_decoder *dec, int on, int *out, int T, int beam);
 
 /* Test hook for the host-tensor entry points (ctcd_beam_decode_to_host / _host / _lm_host): input_streaming = 0 / 1 turns
  * the streamed input off / on (-1: leave; on by default: the kernel is launched before its rows have crossed PCIe and
- * waits for them frame block by frame block); mirror_cap_labels >= 0 shrinks the page-locked mirror a finished utterance
+ * waits for them frame block by frame block; 2: on, but the "frames arrived" counter is never advanced -- the kernel must
+ * give up after about a second and the call repeat itself the plain way); mirror_cap_labels >= 0 shrinks the page-locked mirror a finished utterance
  * copies its compact results into (utterances beyond it are fetched from the device buffer afterwards; -1: default size,
  * -2: leave). */
 int ctcd_debug_set_host_path(ctcd_decoder *dec, int input_streaming, long long mirror_cap_labels);

@@ -471,6 +471,34 @@ def test_host_path_of_decode(torch_mod):
         ou.assert_same(_with_nres(got, want), want, "with scorer, streaming=%s" % streaming)
 
 
+def test_streamed_input_that_never_arrives_gives_up_quickly(torch_mod):
+    """the kernel's wait for streamed rows gives up after about a second -- once, not once per frame -- and the call
+    repeats itself with the rows copied up front.  Also: a workgroup narrower than the vocabulary (rows not prefetched) must
+    not read rows that have not arrived (the streaming is simply not used there)."""
+    import time
+
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    B, T, V, K = 16, 1024, 300, 8   # 19 MB of rows: streamed (>= 1 MB, T >= 128, V <= 512)
+    lp = ou.synth_logprobs(B, T, V, 99)
+    want = ou.decode(lp, beam=K, cutoff_top_n=V, which="restated")
+    dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=V, beam_width=K, log_probs_input=True)
+    n.check(n.lib.ctcd_debug_set_host_path(dec._handle, 2, -2))
+    t0 = time.time()
+    out, sc, ts, ln = dec.decode(torch_mod.from_numpy(lp))
+    dt = time.time() - t0
+    got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+    ou.assert_same(_with_nres(got, want), want, "after the give-up")
+    assert dt < 20.0, "the give-up must not be paid once per frame (%.1f s)" % dt
+    # a workgroup of 64 threads over 300 labels: rows are not prefetched
+    dec2 = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=V, beam_width=K, log_probs_input=True)
+    dec2.set_threads(64)
+    out, sc, ts, ln = dec2.decode(torch_mod.from_numpy(lp))
+    got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=sc.numpy(), lens=ln.numpy())
+    ou.assert_same(_with_nres(got, want), want, "64 threads, 300 labels")
+
+
 def test_capability_boundaries(torch_mod):
     """Every CTCD_EUNSUPPORTED edge of the no-LM path: on the supported side of a limit the call decodes
     and matches the oracle; one step beyond, it raises NotImplementedError -- cleanly: the same decoder object then decodes
