@@ -765,11 +765,12 @@ struct HostPool {
   int n_items = 0, next = 0, running = 0;
   unsigned long long epoch = 0;
   bool stop = false;
-  void start(int n) {
-    for (int i = 0; i < n; ++i) th.emplace_back([this] { loop(); });
+  void start(int n) {  // (also grows a running pool: the new threads start behind the jobs already done)
+    unsigned long long e;
+    { std::lock_guard<std::mutex> g(mu); e = epoch; }
+    for (int i = 0; i < n; ++i) th.emplace_back([this, e] { loop(e); });
   }
-  void loop() {
-    unsigned long long seen = 0;
+  void loop(unsigned long long seen) {
     for (;;) {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return stop || epoch != seen; });
@@ -1658,14 +1659,15 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
   HIP_TRY(hipMemcpyAsync(out_sc, d->c_sc.p, kk * 4, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(out_len, d->c_ln.p, kk * 4, hipMemcpyDeviceToHost, stream));
   if (n_results) HIP_TRY(hipMemcpyAsync(n_results, d_nres, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
-  if (!d->workers) {
-    d->workers = new HostPool;
+  {
+    if (!d->workers) d->workers = new HostPool;
     // host threads that expand the results (memory-bound work: 8 bytes written per label position of the padded tensors;
     // the reference's default num_processes = 4 was chosen for its CPU decode): one per 4 MB of output, between 16 and 64,
-    // more if the caller asks, never more than the machine has
+    // more if the caller asks, never more than the machine has.  The pool grows when a later call wants more.
     const long long out_mb = (long long)B * beam * T * 8 >> 20;
     const int want = std::max<long long>(num_processes, std::min<long long>(64, std::max<long long>(16, out_mb / 4)));
-    d->workers->start(std::max(1, std::min(want, (int)std::thread::hardware_concurrency())));
+    const int target = std::max(1, std::min(want, (int)std::thread::hardware_concurrency()));
+    if (target > (int)d->workers->th.size()) d->workers->start(target - (int)d->workers->th.size());
   }
   const int32_t *hh = (const int32_t *)(hs + o_hdr), *he = (const int32_t *)(hs + o_ent);
   const uint32_t *hl = (const uint32_t *)(hs + o_lab);

@@ -178,7 +178,11 @@ struct HostScorer {
     size_t cap = 16;
     // (at most a quarter of the slots are taken: most queries are misses, which probe until they meet an empty slot -- 1.4
     //  dependent accesses at this load against 2.5 at one half; measured -1 % (word model) / -6 % (character model) per frame)
-    while (cap < 4 * nhigher + 2) cap <<= 1;
+    // ... while the table stays small (256 MB: 16 M slots of 16 B); a model of production size keeps the usual half-full table
+    // instead of 6-13 GB of slots, mirrored on the host while it is built
+    const size_t kQuarterFullUpTo = (size_t)16 << 20;
+    while (cap < 4 * nhigher + 2 && cap < kQuarterFullUpTo) cap <<= 1;
+    while (cap < 2 * nhigher + 2) cap <<= 1;
     ng.assign(cap, NgSlot{kEmptySlot, 0, 0, 0});
     for (int n = 2; n <= order; ++n)
       for (const Gram &g : grams[n]) {

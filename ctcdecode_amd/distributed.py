@@ -119,8 +119,20 @@ class CompactGatherer(object):
         self.rank = dist.get_rank(group)
         self.depth = max(1, depth)
         self._host_only = dist.get_backend(group) == "gloo"
-        # control plane: host integers travel over gloo (collective construction: every rank builds its gatherer)
-        self.ctl = group if self._host_only else (ctl_group if ctl_group is not None else dist.new_group(backend="gloo"))
+        # control plane: host integers travel over gloo.  The control group spans exactly the ranks of the data group (ADVICE
+        # r3: a world-wide control group under a sub-group gave all_gather a list of the wrong length, and ranks outside the
+        # sub-group never made the call).  NOTE: creating it is a collective -- torch.distributed.new_group must be called by
+        # EVERY rank of the default group in the same order, also by ranks outside ``group``; callers that decode on a
+        # sub-group either pass ``ctl_group`` (made up front on all ranks) or construct their gatherers on all ranks.
+        if self._host_only:
+            self.ctl = group
+        elif ctl_group is not None:
+            self.ctl = ctl_group
+        elif group is None or group is dist.group.WORLD:
+            self.ctl = dist.new_group(backend="gloo")
+        else:
+            self.ctl = dist.new_group(ranks=dist.get_process_group_ranks(group), backend="gloo")
+        assert dist.get_world_size(self.ctl) == self.world, "control group and data group must span the same ranks"
         self._inflight = []
         self.last = None
         # Optional side stream (device backends): the collectives, and on ``dst`` the expansion kernel, are issued there
