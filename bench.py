@@ -122,6 +122,22 @@ def self_launch(a):
     return rc
 
 
+def synth_rows(torch, B, T, V, seed, kind="randn"):
+    """Synthetic log-probability rows (CPU tensor): log_softmax of N(0,1) logits; "blank": +6 on label 0; "peaky": one label
+    +8 per frame, the same label for runs of 5-15 frames."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lg = torch.randn((B, T, V), generator=g)
+    if kind == "blank":
+        lg[:, :, 0] += 6.0
+    elif kind == "peaky":
+        runs = torch.randint(5, 16, (B, T // 5 + 1), generator=g)
+        labs = torch.randint(0, V, (B, T // 5 + 1), generator=g)
+        for b in range(B):
+            idx = torch.repeat_interleave(labs[b], runs[b])[:T]
+            lg[b, torch.arange(T), idx] += 8.0
+    return lg.log_softmax(-1)
+
+
 def time_e2e(torch, dec, lp_cpu, reps=5, warm=2):
     """SURVEY 8(d)'s primary definition: wall time of one drop-in decode() call -- CPU tensor in, four CPU tensors out."""
     for _ in range(warm):
@@ -174,19 +190,61 @@ def time_pipelined(torch, ctcdecode_amd, dev, lp, labels, V, K, inflight=2, step
     return dt
 
 
+def time_streaming(torch, ctcdecode_amd, dev, lp, V, K, chunk=50, reps=3):
+    """SURVEY 8(f) N3 as a serving loop would drive it: every utterance of the batch is a stream (OnlineCTCBeamDecoder /
+    DecoderState), fed in chunks of `chunk` frames from HBM; the last chunk ends the streams and returns the results (CPU
+    tensors, as the reference's contract has it).  Reported: the steady-state chunk call (median of the calls in which no
+    stream ends: wall clock and the kernel's own time by HIP events), per frame against the one-shot kernel, and the final
+    call with its result delivery."""
+    import statistics
+
+    B, T, _ = lp.shape
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev)
+    ctcdecode_amd._native.check(ctcdecode_amd._native.lib.ctcd_set_timing(dec._handle, 1))
+    import ctypes
+    best = None
+    for _ in range(reps):
+        states = [ctcdecode_amd.DecoderState(dec) for _ in range(B)]
+        chunks = [lp[:, f0:f0 + chunk].contiguous() for f0 in range(0, T, chunk)]
+        torch.cuda.synchronize()
+        walls, kerns = [], []
+        t_all = time.perf_counter()
+        for i, c in enumerate(chunks):
+            t0 = time.perf_counter()
+            res = dec.decode(c, states, [i == len(chunks) - 1] * B)
+            walls.append(time.perf_counter() - t0)
+            ms = ctypes.c_float()
+            ctcdecode_amd._native.lib.ctcd_last_kernel_ms(dec._handle, ctypes.byref(ms))
+            kerns.append(ms.value)
+        total = time.perf_counter() - t_all
+        del states
+        if best is None or total < best[0]:
+            best = (total, walls, kerns, res)
+    total, walls, kerns, res = best
+    mid_w = statistics.median(walls[1:-1]) if len(walls) > 2 else walls[0]
+    mid_k = statistics.median(kerns[1:-1]) if len(kerns) > 2 else kerns[0]
+    return {"what": "%d streams fed in %d-frame chunks through OnlineCTCBeamDecoder.decode (HBM-resident input; the last call ends the streams and returns the CPU result tensors)" % (B, chunk),
+            "chunk_frames": chunk, "calls": len(walls), "ms_per_chunk_call": round(mid_w * 1e3, 3), "us_per_frame": round(mid_w / chunk * 1e6, 3),
+            "kernel_ms_per_chunk": round(mid_k, 3), "kernel_us_per_frame": round(mid_k / chunk * 1e3, 3),
+            "final_call_ms": round(walls[-1] * 1e3, 3), "ms_per_batch": round(total * 1e3, 3), "value": round(B / total, 1), "unit": "utterances/s",
+            "result_lens_sum": int(res[3].sum())}
+
+
 def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
     """Kernel time of the other BASELINE.json configurations' per-GPU shapes (not bench lines: one or two launches each)."""
     out = {}
     traffic_consts = traffic_consts or {}
 
-    def run(name, B, T, V, K, top_n=40, cutoff_prob=1.0, reps=2, **kw):
-        g = torch.Generator(device="cpu").manual_seed(7)
-        lp = torch.randn((B, T, V), generator=g).log_softmax(-1).to(dev)
+    def run(name, B, T, V, K, top_n=40, cutoff_prob=1.0, reps=2, kind="randn", seed=7, prob_input=False, **kw):
+        lp = synth_rows(torch, B, T, V, seed, kind)
+        if prob_input:  # the reference's DEFAULT input mode (log_probs_input=False): probabilities, converted on the device
+            lp = lp.exp()
+        lp = lp.to(dev)
         labels = [str(i) for i in range(V)]
         if V == 29:  # blank, apostrophe, space, a..z: the words of tests/data/test.arpa can be spelled
             labels = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
         dec = ctcdecode_amd.CTCBeamDecoder(labels, cutoff_top_n=top_n, cutoff_prob=cutoff_prob, beam_width=K,
-                                           log_probs_input=True, device=dev, **kw)
+                                           log_probs_input=not prob_input, device=dev, **kw)
         dec.set_timing(True)
         ks, ps, ws = [], [], []
         for _ in range(reps + 1):
@@ -222,6 +280,12 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
         del dec, lp
         torch.cuda.empty_cache()
 
+    # N(0,1) logits emit a label on 88 % of the frames -- unrepresentative of real CTC posteriors; the same
+    # shape with a blank-dominated distribution (+6 on the blank logit) and a peaky one (one label +8 per frame, in runs of
+    # 5-15 frames: the chain-shaped beams of DESIGN.md section 10), and with probabilities as input (the reference's default)
+    run("configs[1] shape, blank-dominated rows (+6 on the blank logit)", 256, 1000, 29, 100, top_n=29, kind="blank")
+    run("configs[1] shape, peaky rows (one label +8 per frame, runs of 5-15 frames)", 256, 1000, 29, 100, top_n=29, kind="peaky")
+    run("configs[1] shape, probability input (log_probs_input=False: device prob -> log pass + decode)", 256, 1000, 29, 100, top_n=29, prob_input=True)
     run("configs[1] shape with 512 utterances per launch (two workgroups per CU)", 512, 1000, 29, 100)
     run("configs[2] per-GPU shape (256 of 2048 utterances, beam 500, T 2000)", 256, 2000, 29, 500, reps=1)
     run("configs[3] (V=10000, top_n 40, cutoff_prob 0.99)", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99)
@@ -475,6 +539,26 @@ def main():
                                      "launches_in_flight": 3, "ms_per_batch": round(pl * 1e3, 3), "value": round(B / pl, 1), "unit": "utterances/s"}
             except Exception as e:
                 line["pipelined"] = {"error": str(e)[:200]}
+            try:  # seeds {0, 1, 2} for the headline shape (kernel time by HIP events, three launches each)
+                vals = []
+                for sd in (0, 1, 2):
+                    lps = synth_rows(torch, B, T, V, sd).to(dev)
+                    ks = []
+                    for _ in range(4):
+                        dec.decode_device(lps, None, check=False)
+                        torch.cuda.synchronize()
+                        ks.append(dec.last_kernel_ms())
+                    vals.append(B / (min(ks[1:]) * 1e-3))
+                    del lps
+                vals.sort()
+                line["seeds"] = {"what": "the headline shape on seeds 0, 1, 2 (kernel time): utterances/s min / median / max", "min": round(vals[0], 1), "median": round(vals[1], 1), "max": round(vals[2], 1)}
+            except Exception as e:
+                line["seeds"] = {"error": str(e)[:200]}
+            try:
+                line["streaming"] = time_streaming(torch, ctcdecode_amd, dev, lp, V, K, chunk=50)
+                line["streaming"]["one_shot_kernel_us_per_frame"] = round(kern_ms * 1e3 / T, 3)
+            except Exception as e:
+                line["streaming"] = {"error": str(e)[:200]}
             try:
                 line["other_configs"] = other_configs(torch, ctcdecode_amd, dev, tj)
             except Exception as e:

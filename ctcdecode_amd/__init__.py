@@ -367,29 +367,43 @@ class OnlineCTCBeamDecoder(object):
         if len(states) != B or len(is_eos_s) != B:
             raise ValueError("states and is_eos_s need one entry per batch item")
         probs = probs.to(device=self._device, dtype=torch.float32).contiguous()
-        if seq_lens is None:
-            lens_cpu = torch.full((B,), T, dtype=torch.int32)
-        else:
+        lens_cpu = None
+        if seq_lens is not None:
             lens_cpu = seq_lens.detach().cpu().to(torch.int32).contiguous()
         K = self._beam_width
-        eos = (ctypes.c_ubyte * max(B, 1))(*[1 if e else 0 for e in is_eos_s])
-        ptrs = (ctypes.c_void_p * max(B, 1))(*[st._ptr(self) for st in states])
+        # (a serving loop calls this once per chunk with the same states: the per-call host work is kept small -- the array of
+        #  state handles is rebuilt only when the list changes, nothing is allocated or read back unless a stream ends)
+        cache = getattr(self, "_ptr_cache", None)
+        if cache is None or len(cache[0]) != B or any(a is not b for a, b in zip(cache[0], states)):
+            cache = (list(states), (ctypes.c_void_p * max(B, 1))(*[st._ptr(self) for st in states]))
+            self._ptr_cache = cache
+        ptrs = cache[1]
+        any_eos = any(is_eos_s)
+        eos = (ctypes.c_ubyte * max(B, 1)).from_buffer_copy(bytes(bytearray(1 if e else 0 for e in is_eos_s)) or b"\0")
         out_T = 0
-        for b in range(B):
-            if is_eos_s[b]:
-                out_T = max(out_T, int(_native.lib.ctcd_stream_frames(ptrs[b])) + max(0, min(int(lens_cpu[b]), T)))
+        if any_eos:
+            for b in range(B):
+                if is_eos_s[b]:
+                    ln = T if lens_cpu is None else max(0, min(int(lens_cpu[b]), T))
+                    out_T = max(out_T, int(_native.lib.ctcd_stream_frames(ptrs[b])) + ln)
         with torch.cuda.device(self._device):
+            scr = getattr(self, "_scratch", None)
+            if scr is None or scr[0].shape[0] != B:
+                scr = (torch.empty((B, K), dtype=torch.float32, device=self._device), torch.empty((B, K), dtype=torch.int32, device=self._device),
+                       torch.empty((B,), dtype=torch.int32, device=self._device))
+                self._scratch = scr
+            scores, out_len, nres = scr
             output = torch.empty((B, K, out_T), dtype=torch.int32, device=self._device)
             timesteps = torch.empty((B, K, out_T), dtype=torch.int32, device=self._device)
-            scores = torch.empty((B, K), dtype=torch.float32, device=self._device)
-            out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
-            nres = torch.empty((B,), dtype=torch.int32, device=self._device)
             stream = torch.cuda.current_stream(self._device).cuda_stream
             _native.check(_native.lib.ctcd_stream_decode(
-                self._handle, ptrs, eos, probs.data_ptr(), lens_cpu.data_ptr(), B, T, V, K, self._num_processes,
+                self._handle, ptrs, eos, probs.data_ptr(), lens_cpu.data_ptr() if lens_cpu is not None else None, B, T, V, K, self._num_processes,
                 float(self._cutoff_prob), int(self._cutoff_top_n), int(self._blank_id), self._log_probs,
                 output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), nres.data_ptr(), out_T, stream))
             _native.check(_native.lib.ctcd_check_status(self._handle, B))
+        if not any_eos:  # nothing ended: no results (binding.cpp:186-205 sizes them to the most results of any item: none)
+            return (torch.zeros((B, 0, 0), dtype=torch.int32), torch.zeros((B, K), dtype=torch.float32),
+                    torch.zeros((B, 0, 0), dtype=torch.int32), torch.zeros((B, K), dtype=torch.int32))
         nres_c = nres.cpu()
         out_len_c = out_len.cpu()
         R = int(nres_c.max()) if B else 0          # binding.cpp:186-205: sized to the most results / the longest beam

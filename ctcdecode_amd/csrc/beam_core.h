@@ -302,15 +302,17 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
 
 // Persistent decoder state of one audio stream (the reference's DecoderState object kept alive between decode()
 // calls, ctc_beam_search_decoder.h:73-124 / ctcdecode/__init__.py:253-272), stored in HBM between launches:
-// hdr[0..7] = {frames fed so far (abs_time_step, ctc_beam_search_decoder.cpp:69), beam size, pool count, window log,
-// best key, danger mode, worst key, reserved}; arrays = the 13 beam arrays then fin, K entries each (kStateArrays).  The node pool lives in
+// hdr[0..11] = {frames fed so far (abs_time_step, ctc_beam_search_decoder.cpp:69), beam size, pool count, window log,
+// best key, danger mode, worst key, the speculative select's prediction (valid, distance, margin), reserved}; arrays = the 13 beam arrays then fin, K entries each (kStateArrays).  The node pool lives in
 // the same allocation and is passed separately.
 struct StreamState {
   int *hdr;
   int *arrays;
   int finish;  // this call ends the stream: run DecoderState::decode()
 };
-enum { SH_FRAMES = 0, SH_N, SH_POOL, SH_WLOG, SH_MAXKEY, SH_DANGER, SH_MINKEY, SH_WORDS = 8 };
+enum { SH_FRAMES = 0, SH_N, SH_POOL, SH_WLOG, SH_MAXKEY, SH_DANGER, SH_MINKEY,
+       SH_SP_PRED, SH_SP_GAP, SH_SP_MARGIN,  // the speculative select's prediction (Decoder::kSpec): a chunk starts where the last one stopped
+       SH_WORDS = 12 };
 constexpr int kStateArrays = 14;                               // without the LM tier
 constexpr int kStateArraysLm = kStateArrays + kBeamArraysLm;   // with it: the LM arrays follow fin
 CTC_HD int state_arrays(int lm) { return lm ? kStateArraysLm : kStateArrays; }
@@ -799,7 +801,7 @@ struct Decoder {
       for (int c = tid; c < d.V; c += nt) w.rank_of[c] = -1;
     zero_key_tail(0);
     if (kSpec) x.sync();
-    spec_reset(x.uni(ss.hdr[SH_FRAMES]));
+    spec_reset(x.uni(ss.hdr[SH_FRAMES]), ss.hdr);
     x.sync_full();
   }
   CTC_HD void save_state(const StreamState &ss, int frames) {
@@ -826,6 +828,9 @@ struct Decoder {
       ss.hdr[SH_FRAMES] = frames; ss.hdr[SH_N] = st_n; ss.hdr[SH_POOL] = st_pool; ss.hdr[SH_WLOG] = st_wlog;
       ss.hdr[SH_MAXKEY] = (int)st_maxkey; ss.hdr[SH_MINKEY] = (int)st_minkey;
       ss.hdr[SH_DANGER] = w.vars[VAR_DANGER];
+      ss.hdr[SH_SP_PRED] = kSpec ? w.vars[VAR_SPEC + SP_PRED] : 0;  // (kernels without the speculative select write 0: a later
+      ss.hdr[SH_SP_GAP] = kSpec ? w.vars[VAR_SPEC + SP_GAP] : 0;    //  chunk on one that has it starts without a prediction)
+      ss.hdr[SH_SP_MARGIN] = kSpec ? w.vars[VAR_SPEC + SP_MARGIN] : 0;
     }
   }
 
@@ -939,11 +944,14 @@ struct Decoder {
   }
 
   // start of an utterance / of a stream's chunk: no prediction yet, empty hot list, clear survivor bitmap
-  CTC_HD void spec_reset(int t0) {
+  CTC_HD void spec_reset(int t0, const int *hdr = nullptr) {
     if (!kSpec) return;
     if (x.tid() == 0) {
       int *sp = w.vars + VAR_SPEC;
       sp[SP_THR] = -1; sp[SP_BEST] = 0; sp[SP_MARGIN] = (int)ctcmath::f32_to_bits(0.125f); sp[SP_GAP] = 0; sp[SP_PRED] = 0;
+      if (hdr && hdr[SH_SP_PRED] == 1) {  // a stream's chunk continues with the prediction the previous chunk ended on
+        sp[SP_PRED] = 1; sp[SP_GAP] = hdr[SH_SP_GAP]; sp[SP_MARGIN] = hdr[SH_SP_MARGIN];
+      }
       sp[SP_WLOG] = st_wlog; sp[SP_ANCHOR] = (int)st_maxkey;
       w.vars[VAR_G] = 0;  // (the hot list's length is counted in the select's result group: one read gives it and the danger flag)
       w.vars[VAR_E] = 0;

@@ -838,12 +838,19 @@ struct ctcd_decoder {
   bool input_timed_out = false;   // set by ctcd_check_status when an utterance reports ST_INPUT_TIMEOUT
   long long mirror_cap_override = -1;  // tests: labels the host mirror of the compact results holds (-1: a third of the worst case)
   hipStream_t last_stream = nullptr;  // the stream of the last decode launch (ctcd_check_status reads the status words on it)
+  // streaming calls: their per-item arguments (block pointers, pool capacities, end-of-stream flags, chunk lengths) travel
+  // in ONE copy from page-locked staging -- two slots, an event each: a chunk call costs no stream synchronisation
+  char *h_stargs[2] = {nullptr, nullptr};
+  size_t h_stargs_cap = 0;
+  hipEvent_t ev_stargs[2] = {nullptr, nullptr};
+  unsigned long long stream_calls = 0;
   std::mutex mu;
   std::mutex mu_host;  // the host-tensor entry points: compact buffers, page-locked staging and the worker threads are per decoder
 };
 
 // One audio stream's parked decoder state (ctcd_stream_*): a single HBM block [header | beam arrays | node pool].
 struct ctcd_stream {
+  unsigned long long seen_in_call = 0;  // ctcd_stream_decode: "this state is already part of the current call" in O(1)
   int device = 0;
   ctcd_scorer *scorer = nullptr;  // DecoderState is created with its scorer (binding.cpp:243-261)
   char *block = nullptr;
@@ -875,12 +882,15 @@ struct CompactOut {          // compact result delivery (beam_core.h OutRefs::c_
   unsigned m_cap = 0;
 };
 
-struct StreamCall {          // extra arguments of a streaming decode
+struct StreamCall {          // extra arguments of a streaming decode (lens: the chunk lengths, host memory)
   ctcd_stream **states;
   const unsigned char *is_eos;  // host
   int out_T;
+  const int32_t *lens;          // host: frames of this chunk per item
+  bool any_eos;
 };
 
+std::atomic<unsigned long long> g_stream_call_id{0};
 // (the parked arrays are always laid out for the LM tier's larger set: a stream block is sized once, before its scorer matters)
 size_t stream_pool_offset(int beam) { return ((size_t)(SH_WORDS + kStateArraysLm * (size_t)beam) * 4 + 255) / 256 * 256; }
 // a stream block holds [header | beam arrays | node pool (nodes * 12 B) | express pointers (nodes * 4 B) | high parts of the
@@ -955,6 +965,10 @@ void ctcd_destroy(ctcd_decoder *d) {
   if (d->fg_in) (void)hipFree(d->fg_in);
   if (d->h_cnt) (void)hipHostFree(d->h_cnt);
   if (d->h_flagged) (void)hipHostFree(d->h_flagged);
+  for (int i = 0; i < 2; ++i) {
+    if (d->h_stargs[i]) (void)hipHostFree(d->h_stargs[i]);
+    if (d->ev_stargs[i]) (void)hipEventDestroy(d->ev_stargs[i]);
+  }
   if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
   if (d->ev_in) (void)hipEventDestroy(d->ev_in);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->ev3); }
@@ -1055,15 +1069,56 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     HIP_TRY(hipMemsetAsync(out_tok, 0, kt * 4, stream));
     HIP_TRY(hipMemsetAsync(out_ts, 0, kt * 4, stream));
   }
-  HIP_TRY(hipMemsetAsync(out_sc, 0, (size_t)B * beam * 4, stream));
-  HIP_TRY(hipMemsetAsync(out_len, 0, (size_t)B * beam * 4, stream));
-  if (sc && n_results) HIP_TRY(hipMemsetAsync(n_results, 0, (size_t)B * 4, stream));
+  if (!sc || sc->any_eos) {  // (a streaming call in which no stream ends writes no results: nothing to define)
+    HIP_TRY(hipMemsetAsync(out_sc, 0, (size_t)B * beam * 4, stream));
+    HIP_TRY(hipMemsetAsync(out_len, 0, (size_t)B * beam * 4, stream));
+    if (sc && n_results) HIP_TRY(hipMemsetAsync(n_results, 0, (size_t)B * 4, stream));
+  }
 
   if (!d->tables_ready) {
     if ((rc = d->tables.ensure(sizeof(ctcmath::Tables)))) return rc;
     HIP_TRY(hipMemcpy(d->tables.p, ctcmath::host_tables().w, sizeof(ctcmath::Tables), hipMemcpyHostToDevice));
     d->tables_ready = true;
   }
+  // streaming: per-item block pointers, pool capacities and end-of-stream flags go to the device
+  char **st_base = nullptr;
+  int *st_cap = nullptr;
+  unsigned char *st_eos = nullptr;
+  if (sc) {
+    // [block pointers | pool capacities | chunk lengths | end-of-stream flags], staged in page-locked memory (two slots,
+    // an event each) and sent with ONE asynchronous copy: a chunk call synchronises nothing (round 3: two stream
+    // synchronisations per call, one for this block and one for the lengths)
+    const size_t off_cap = (size_t)B * 8, off_len = off_cap + (size_t)B * 4, off_eos = off_len + (size_t)B * 4, need = (off_eos + (size_t)B + 31) & ~(size_t)15;
+    if ((rc = d->st_args.ensure(2 * need))) return rc;
+    if (d->h_stargs_cap < need) {
+      for (int i = 0; i < 2; ++i) {
+        if (d->ev_stargs[i]) HIP_TRY(hipEventSynchronize(d->ev_stargs[i]));
+        if (d->h_stargs[i]) (void)hipHostFree(d->h_stargs[i]);
+        d->h_stargs[i] = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&d->h_stargs[i], need, hipHostMallocDefault));
+        if (!d->ev_stargs[i]) HIP_TRY(hipEventCreateWithFlags(&d->ev_stargs[i], hipEventDisableTiming));
+      }
+      d->h_stargs_cap = need;
+    }
+    const int slot = (int)(d->stream_calls++ & 1);
+    HIP_TRY(hipEventSynchronize(d->ev_stargs[slot]));  // (the copy of two calls ago: long done)
+    char *hb = d->h_stargs[slot];
+    for (int b = 0; b < B; ++b) {
+      ctcd_stream *st = sc->states[b];
+      ((char **)hb)[b] = st->block;
+      ((int *)(hb + off_cap))[b] = (int)(st->cap_frames * beam + 1);
+      ((int *)(hb + off_len))[b] = sc->lens[b];
+      hb[off_eos + b] = sc->is_eos[b] ? 1 : 0;
+    }
+    char *db = (char *)d->st_args.p + (size_t)slot * need;
+    HIP_TRY(hipMemcpyAsync(db, hb, off_eos + (size_t)B, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(d->ev_stargs[slot], stream));
+    st_base = (char **)db;
+    st_cap = (int *)(db + off_cap);
+    st_eos = (unsigned char *)db + off_eos;
+    seq_lens = (const int32_t *)(db + off_len);
+  }
+
   if (log_input == 2) {  // raw logits: normalise once, in HBM; everything below sees log-probabilities
     if (T > 0) {
       if ((rc = d->lsm.ensure((size_t)B * T * V * 4))) return rc;
@@ -1083,27 +1138,6 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   // every status word starts as -1 ("no result"): a workgroup that never ran cannot read back as ST_OK
   HIP_TRY(hipMemsetAsync(d->status.p, 0xff, (size_t)B * 4, stream));
   d->last_stream = stream;
-  // streaming: per-item block pointers, pool capacities and end-of-stream flags go to the device
-  char **st_base = nullptr;
-  int *st_cap = nullptr;
-  unsigned char *st_eos = nullptr;
-  if (sc) {
-    const size_t off_cap = (size_t)B * 8, off_eos = off_cap + (size_t)B * 4;
-    if ((rc = d->st_args.ensure(off_eos + (size_t)B + 16))) return rc;
-    std::vector<char> hostbuf(off_eos + (size_t)B);
-    for (int b = 0; b < B; ++b) {
-      ctcd_stream *st = sc->states[b];
-      ((char **)hostbuf.data())[b] = st->block;
-      ((int *)(hostbuf.data() + off_cap))[b] = (int)(st->cap_frames * beam + 1);
-      hostbuf[off_eos + b] = sc->is_eos[b] ? 1 : 0;
-    }
-    HIP_TRY(hipMemcpyAsync(d->st_args.p, hostbuf.data(), hostbuf.size(), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));  // hostbuf is about to go out of scope
-    st_base = (char **)d->st_args.p;
-    st_cap = (int *)((char *)d->st_args.p + off_cap);
-    st_eos = (unsigned char *)d->st_args.p + off_eos;
-  }
-
   const float *logp = probs;
   d->prune_flagged_rows = 0;
   d->flagged_pending = false;
@@ -1420,12 +1454,15 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
   CTC_ON_DEVICE(d->device);
   hipStream_t stream = (hipStream_t)stream_;
   std::vector<int32_t> lens(B);
+  const unsigned long long call_id = ++g_stream_call_id;
+  bool any_eos = false;
   for (int b = 0; b < B; ++b) {
     ctcd_stream *st = states[b];
     if (!st || st->V != V || st->beam != beam) return fail(CTCD_EINVAL, "stream state does not match the decoder configuration");
     if (st->scorer != states[0]->scorer) return fail(CTCD_EINVAL, "the streams of one batch must share their scorer");
-    for (int c = 0; c < b; ++c)
-      if (states[c] == st) return fail(CTCD_EINVAL, "the same stream state appears twice in one batch");
+    if (st->seen_in_call == call_id) return fail(CTCD_EINVAL, "the same stream state appears twice in one batch");
+    st->seen_in_call = call_id;
+    any_eos |= is_eos[b] != 0;
     int len = seq_lens_host ? seq_lens_host[b] : T;
     len = len < 0 ? 0 : (len > T ? T : len);  // binding.cpp:171
     lens[b] = len;
@@ -1450,13 +1487,10 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
       st->cap_frames = cap;
     }
   }
-  int rc;
-  if ((rc = d->st_lens.ensure((size_t)B * 4 + 16))) return rc;
-  HIP_TRY(hipMemcpyAsync(d->st_lens.p, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  StreamCall sc{states, is_eos, out_T};
-  rc = decode_common(d, probs, (const int32_t *)d->st_lens.p, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok,
-                     out_ts, out_sc, out_len, n_results, stream_, &sc, states[0]->scorer);
+  // (the chunk lengths travel with the other per-item arguments: decode_common)
+  StreamCall sc{states, is_eos, out_T, lens.data(), any_eos};
+  int rc = decode_common(d, probs, nullptr, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok,
+                         out_ts, out_sc, out_len, n_results, stream_, &sc, states[0]->scorer);
   if (rc) return rc;
   for (int b = 0; b < B; ++b) states[b]->frames += lens[b];
   return CTCD_OK;
