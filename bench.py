@@ -65,6 +65,8 @@ def parse():
                          "'full' = the four padded tensors")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the gather path even with one rank (self-test)")
     ap.add_argument("--backend", default="", help="torch.distributed backend (default nccl = RCCL; gloo when ranks share a device)")
+    ap.add_argument("--min-shard", type=int, default=0, help="configs 2 / 4 (strong scaling): at least this many utterances per rank -- fill a GPU (256 = its CU count) "
+                    "before adding ranks; the ranks left over get empty shards (ctcdecode_amd.distributed.shard_size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e and other_configs measurements (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
@@ -362,7 +364,7 @@ def main():
     if strong:  # contiguous blocks of ceil(B / world) utterances, as decode_sharded cuts them
         from ctcdecode_amd.distributed import shard_bounds
 
-        lo, hi = shard_bounds(B_total, world, rank)
+        lo, hi = shard_bounds(B_total, world, rank, a.min_shard)
         B = hi - lo
     else:
         B = a.batch or cfg["batch"]
@@ -396,7 +398,8 @@ def main():
     if use_dist and a.gather != "none":
         from ctcdecode_amd.distributed import make_gatherer
 
-        per = (B_total + world - 1) // world if strong else B  # the padded shard size of the "full" format
+        from ctcdecode_amd.distributed import shard_size
+        per = shard_size(B_total, world, a.min_shard) if strong else B  # the padded shard size of the "full" format
         gatherer = make_gatherer(a.gather_format, per, K, T, V, dev, dst=0, depth=2, decoder=dec,
                                  stream=torch.cuda.Stream(device=dev) if lookahead else None)
     decs = [dec]
@@ -512,6 +515,23 @@ def main():
             "latency": {"frame_clocks": round(frame_clocks), "floor_clocks": floor, "frame_over_floor": round(frame_clocks / floor, 2),
                         "shader_ghz_assumed": SHADER_GHZ, "floor_terms": FRAME_FLOOR},
         }
+        if strong and not a.no_extras:
+            # The partition rule: an utterance occupies one CU, so a shard below the CU count idles CUs
+            # without finishing sooner.  This GPU's kernel time for the shard of the named 8-GPU partition and for a shard
+            # that fills it: equal times mean half the GPUs do the same job in the same time (--min-shard 256).
+            try:
+                probe = {}
+                for nb in sorted({max(1, B_total // 8), min(B_total, 256)}):
+                    lpp = lp[:nb] if nb <= lp.shape[0] else torch.cat([lp] * ((nb + lp.shape[0] - 1) // lp.shape[0]))[:nb]
+                    ks = []
+                    for _ in range(3):
+                        dec.decode_device(lpp, None, check=False)
+                        torch.cuda.synchronize()
+                        ks.append(dec.last_kernel_ms())
+                    probe["%d utterances on one GPU" % nb] = {"kernel_ms": round(min(ks[1:]), 3), "utterances_per_s": round(nb / (min(ks[1:]) * 1e-3), 1)}
+                line["partition_probe"] = {"what": "shard of the named 8-rank partition (B/8) vs a shard that fills the GPU's 256 CUs; rule: --min-shard 256 (shard_size)", **probe}
+            except Exception as e:
+                line["partition_probe"] = {"error": str(e)[:200]}
         if shared:
             line["config"]["oversubscribed"] = "%d ranks on %d device(s): a dry run of the N-rank path, not a scaling number" % (world, ndev)
         if world == 1 and not a.no_extras and a.config == 1:

@@ -9,20 +9,32 @@ import torch
 import torch.distributed as dist
 
 
-def shard_bounds(batch, world, rank):
-    """[lo, hi) of the utterances rank ``rank`` decodes; blocks of ceil(batch / world), the last ones may be short/empty."""
+def shard_size(batch, world, min_shard=0):
+    """Utterances per rank: ceil(batch / world), but not fewer than ``min_shard``.
+
+    The partition rule: one utterance occupies one workgroup = one CU, and the time axis cannot be
+    split (a true recurrence), so a shard smaller than the CU count leaves CUs idle without finishing any sooner -- 128
+    utterances take 7.7 ms on half of an MI355X's 256 CUs, 256 take the same wall time on all of them.  ``min_shard`` = the
+    CU count fills GPUs before it adds ranks: BASELINE's configs[4] (1024 utterances) then runs on 4 ranks x 256 instead of
+    8 x 128 in the same time, and the other ranks get empty shards (free for the next batch)."""
     per = (batch + world - 1) // world
+    return max(per, int(min_shard)) if min_shard else per
+
+
+def shard_bounds(batch, world, rank, min_shard=0):
+    """[lo, hi) of the utterances rank ``rank`` decodes; blocks of ``shard_size``, the last ones may be short/empty."""
+    per = shard_size(batch, world, min_shard)
     lo = min(rank * per, batch)
     return lo, min(lo + per, batch)
 
 
-def gather_results(results, batch, dst=0, group=None):
+def gather_results(results, batch, dst=0, group=None, min_shard=0):
     """``results`` = (output[b,K,T], scores[b,K], timesteps[b,K,T], out_lens[b,K]) of this rank's shard.
     Returns the four full-batch tensors on rank ``dst`` (None elsewhere).  Shards are zero-padded to equal size for the
     collective and trimmed afterwards."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    per = (batch + world - 1) // world
+    per = shard_size(batch, world, min_shard)
     out = []
     host_only = dist.get_backend(group) == "gloo"  # gloo gathers host tensors only
     for t in results:
@@ -41,16 +53,16 @@ def gather_results(results, batch, dst=0, group=None):
     return tuple(out) if rank == dst else None
 
 
-def decode_sharded(decode_fn, probs, seq_lens=None, dst=0, group=None):
+def decode_sharded(decode_fn, probs, seq_lens=None, dst=0, group=None, min_shard=0):
     """Decode a full batch that every rank holds (or can index): rank r decodes ``probs[lo:hi]`` with
     ``decode_fn(probs_shard, seq_lens_shard) -> (output, scores, timesteps, out_lens)`` and the results are gathered to
     ``dst``.  With ``decode_fn = CTCBeamDecoder.decode_device`` the tensors stay in HBM and travel over RCCL/xGMI."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     B = probs.shape[0]
-    lo, hi = shard_bounds(B, world, rank)
+    lo, hi = shard_bounds(B, world, rank, min_shard)  # (min_shard: fill GPUs before adding ranks -- shard_size)
     res = decode_fn(probs[lo:hi], None if seq_lens is None else seq_lens[lo:hi])
-    return gather_results(res, B, dst=dst, group=group)
+    return gather_results(res, B, dst=dst, group=group, min_shard=min_shard)
 
 
 class ResultGatherer(object):

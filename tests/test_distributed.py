@@ -45,13 +45,17 @@ def _worker(rank, world, port, B, ret):
         return (torch.from_numpy(r["tokens"]), torch.from_numpy(r["scores"]), torch.from_numpy(r["timesteps"]), torch.from_numpy(r["lens"]))
 
     got = dd.decode_sharded(decode_fn, lp, sl, dst=0)
+    # ... and with the partition rule "fill a GPU before adding ranks" (min_shard: here 4 utterances -- rank 1 gets what is
+    # left, possibly nothing)
+    got2 = dd.decode_sharded(decode_fn, lp, sl, dst=0, min_shard=4)
     ok = True
     if rank == 0:
         want = ou.decode(lp.numpy(), sl.numpy(), beam=K, threads=1)
-        ok = (np.array_equal(got[0].numpy(), want["tokens"]) and np.array_equal(got[1].numpy().view(np.uint32), want["scores"].view(np.uint32))
+        ok = all(np.array_equal(a.numpy(), b.numpy()) for a, b in zip(got, got2))
+        ok = ok and (np.array_equal(got[0].numpy(), want["tokens"]) and np.array_equal(got[1].numpy().view(np.uint32), want["scores"].view(np.uint32))
               and np.array_equal(got[2].numpy(), want["timesteps"]) and np.array_equal(got[3].numpy(), want["lens"]))
     else:
-        ok = got is None
+        ok = got is None and got2 is None
     lo, hi = dd.shard_bounds(B, world, rank)
     ok = ok and 0 <= lo <= hi <= B
     ret[rank] = bool(ok)
@@ -89,6 +93,14 @@ def test_shard_bounds_cover_the_batch():
                 lo, hi = dd.shard_bounds(B, world, r)
                 seen += list(range(lo, hi))
             assert seen == list(range(B))
+            # the partition rule: shards of at least min_shard fill ranks from the front, the rest stay empty
+            seen, sizes = [], []
+            for r in range(world):
+                lo, hi = dd.shard_bounds(B, world, r, min_shard=256)
+                seen += list(range(lo, hi))
+                sizes.append(hi - lo)
+            assert seen == list(range(B)) and all(sz in (0, B % 256 or 256, 256) or sz == -(-B // world) for sz in sizes)
+    assert [dd.shard_bounds(1024, 8, r, min_shard=256) for r in range(8)] == [(0, 256), (256, 512), (512, 768), (768, 1024)] + [(1024, 1024)] * 4
 
 
 def _gatherer_worker(rank, world, port, ret):
