@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Turns a round-3 GPU session's raw outputs (gpurun_out/<tag>: rocprofv3 CSVs, bench line, timeline) into the small files
+"""Turns an evidence session's raw outputs (tools/gpu_profile.sh <tag> -> gpurun_out/<tag>: rocprofv3 CSVs, bench line, timelines) into the small files
 committed under profiles/:  <tag>_kernel_stats.{csv,md} (bench.py), <tag>_other_configs_kernel_stats.md,
 <tag>_extras_kernel_stats.md, <tag>_pmc.json (FETCH_SIZE / WRITE_SIZE per launch and kernel, with the calibration of the
 counters against a copy of known size), <tag>_timeline.json, <tag>_bench.json; and points profiles/traffic_latest.json
-at the new numbers.      python tools/summarize_r03.py r03e"""
+at the new numbers.      python tools/summarize_profiles.py r04a"""
 import collections
 import csv
 import glob
@@ -38,7 +38,9 @@ def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles", tag)
-    stats_md(os.path.join(src, "prof", "trace_kernel_stats.csv"), dst + "_kernel_stats", "`python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras` (configs[1]: B=256, T=1000, V=29, beam 100)")
+    import subprocess
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+    stats_md(os.path.join(src, "prof", "trace_kernel_stats.csv"), dst + "_kernel_stats", "`python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras` (configs[1]: B=256, T=1000, V=29, beam 100); tree " + head)
     stats_md(os.path.join(src, "prof_cfg", "trace_kernel_stats.csv"), dst + "_other_configs_kernel_stats", "`python tools/bench_configs.py --only 234 --reps 1` (configs[2] per-GPU shape: beam 500, T 2000; configs[3]: V=10000 pruned; configs[4] shape without LM)")
     stats_md(os.path.join(src, "prof_extras", "trace_kernel_stats.csv"), dst + "_extras_kernel_stats", "`python tools/profile_extras.py`: LM instantiation (configs[4] per-GPU shape, test.arpa), two-workgroups-per-CU build (512 utterances), log_softmax_rows_kernel (B=64, T=500, V=10000 logits), expand_compact_kernel (256 x 100 x 1000), 1 GiB device copy (counter calibration)")
     pmc = {"unit": "KiB per launch as rocprofv3 reports FETCH_SIZE / WRITE_SIZE (separate --pmc passes)", "kernels": {}}
@@ -77,13 +79,23 @@ def main():
             lat["prune_hbm_bytes_per_launch"] = int((2 * prune[0].get("FETCH_SIZE_KiB", 0) + prune[0].get("WRITE_SIZE_KiB", 0)) * 1024)
         json.dump(lat, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"))
     json.dump(pmc, open(dst + "_pmc.json", "w"), indent=1)
-    for name in ("timeline.json", "bench.json"):
+    # instruction counters of the headline kernel (per wave: counter / SQ_WAVES)
+    ins = counters(os.path.join(src, "pmc_insts"))
+    per = {}
+    for (k, cn), v in ins.items():
+        if "ctc_beam_decode_kernel" in k:
+            per.setdefault(k[:120], {})[cn] = sum(v) / len(v)
+    if per:
+        json.dump({"unit": "per launch (rocprofv3 --pmc, one pass)", "kernels": per}, open(dst + "_pmc_insts.json", "w"), indent=1)
+    for name in ("timeline.json", "timeline_blank.json", "timeline_lm.json", "bench.json", "parity_sweep.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), dst + "_" + name)
     if os.path.exists(os.path.join(src, "prof_extras.log")):
         last = [ln for ln in open(os.path.join(src, "prof_extras.log")) if ln.startswith("{")]
         if last:
             json.dump(json.loads(last[-1]), open(dst + "_extras_timings.json", "w"), indent=1)
+    if os.path.exists(os.path.join(src, "pytest_gpu.log")):
+        open(dst + "_pytest_gpu_tail.txt", "w").write("".join(open(os.path.join(src, "pytest_gpu.log")).readlines()[-16:]))
     print(json.dumps(pmc, indent=1)[:3000])
 
 
