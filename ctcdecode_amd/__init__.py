@@ -11,7 +11,7 @@ import torch
 from . import _native
 from ._native import NativeError  # noqa: F401
 
-__all__ = ["CTCBeamDecoder", "OnlineCTCBeamDecoder", "DecoderState", "NativeError"]
+__all__ = ["CTCBeamDecoder", "OnlineCTCBeamDecoder", "DecoderState", "NativeError", "CallbackScorer", "KenlmScorer"]
 HAVE_LM = True  # the external-scorer tier (model_path / alpha / beta) is part of this build
 
 
@@ -37,6 +37,94 @@ class _Scorer(object):
             self.handle = None
 
 
+class CallbackScorer(object):
+    """The swappable scorer: a language model behind a host callback (``ctcd_scorer_create_callback``,
+    include/ctcdecode_amd.h) -- the counterpart of handing the reference's decoder another ``Scorer`` implementation
+    (ctcdecode/src/scorer.h:41-78).  Pass it to ``CTCBeamDecoder(..., scorer=...)`` / ``OnlineCTCBeamDecoder``.
+
+    ``cond_log10(words)`` receives the window's ``max_order`` words (tuple of str, oldest first, ``"<s>"``-padded) and
+    returns log10 p(words[-1] | words[:-1]) -- or ``None`` when the window holds a word the model does not know
+    (the reference's OOV_SCORE, scorer.cpp:86-88).  It must be a pure function of the words: every distinct window is
+    asked for once and cached on the device.  ``vocabulary``: the model's words (builds the dictionary of a word model;
+    only single characters = character model, scorer.cpp:65-71).  An exception inside the callback fails the decode and
+    is re-raised from it.
+    """
+
+    def __init__(self, cond_log10, vocabulary, max_order, labels, alpha=0.0, beta=0.0, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ctcdecode_amd: no HIP device visible; this decoder has no CPU path")
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._fn = cond_log10
+        self._error = None
+
+        def trampoline(_user, words, n, out):
+            try:
+                r = self._fn(tuple(words[i].decode("utf-8") for i in range(n)))
+                if r is None:
+                    return 1
+                out[0] = float(r)
+                return 0
+            except BaseException as e:  # (an exception must not unwind through the C frames)
+                self._error = e
+                return -1
+
+        self._c_fn = _native.COND_LOG10_FN(trampoline)  # kept alive with the scorer
+        voc = [str(w).encode("utf-8") for w in vocabulary]
+        varr = (ctypes.c_char_p * max(len(voc), 1))(*voc)
+        larr = (ctypes.c_char_p * len(labels))(*[str(x).encode("utf-8") for x in labels])
+        h = ctypes.c_void_p()
+        _native.check(_native.lib.ctcd_scorer_create_callback(ctypes.byref(h), float(alpha), float(beta), int(max_order), varr, len(voc), self._c_fn, None,
+                                                              larr, len(labels), int(index)))
+        self.handle = h
+        self.device_index = int(index)
+        self.num_labels = len(labels)
+
+    def callback_calls(self):
+        """Distinct windows the callback has been asked for so far."""
+        return int(_native.lib.ctcd_scorer_callback_calls(self.handle))
+
+    def _raise_pending(self):
+        e, self._error = self._error, None
+        if e is not None:
+            raise e
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                _native.lib.ctcd_scorer_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class KenlmScorer(CallbackScorer):
+    """A kenlm model -- binary files included -- behind the scorer hook, through the ``kenlm`` Python module (not part of
+    this image: ImportError if it is missing).  ``vocabulary``: the model's words (a binary model does not list them; pass
+    the word list it was trained with, as the reference's Scorer reads them from the model, scorer.cpp:196-230)."""
+
+    def __init__(self, model_path, vocabulary, labels, alpha=0.0, beta=0.0, device=None):
+        import kenlm  # noqa: F401  (optional dependency)
+
+        self._model = kenlm.Model(str(model_path))
+        model = self._model
+
+        def cond_log10(words):
+            # Scorer::get_log_cond_prob (scorer.cpp:74-93): feed the window from the empty context, OOV if any word is unknown
+            state, out = kenlm.State(), kenlm.State()
+            model.NullContextWrite(state)
+            p = 0.0
+            for w in words:
+                if w not in model:
+                    return None
+                p = model.BaseScore(state, w, out)
+                state, out = out, state
+            return p
+
+        CallbackScorer.__init__(self, cond_log10, vocabulary, model.order, labels, alpha, beta, device)
+
+
 def _to_host(tensors):
     """Device -> host copy of the result tensors through page-locked memory (PyTorch's caching host allocator recycles
     the blocks), all copies in flight together, one synchronisation: several times faster than ``.cpu()`` on pageable
@@ -48,6 +136,16 @@ def _to_host(tensors):
         outs.append(h)
     torch.cuda.current_stream(tensors[0].device).synchronize()
     return tuple(outs)
+
+
+def _adopt_scorer(scorer, model_path, num_labels, device_index):
+    if model_path:
+        raise ValueError("pass either model_path or scorer, not both")
+    if not isinstance(scorer, CallbackScorer):
+        raise TypeError("scorer must be a ctcdecode_amd.CallbackScorer (or KenlmScorer)")
+    if scorer.num_labels != num_labels or scorer.device_index != device_index:
+        raise ValueError("the scorer was built for other labels / another device than this decoder")
+    return scorer
 
 
 class CTCBeamDecoder(object):
@@ -62,7 +160,7 @@ class CTCBeamDecoder(object):
     """
 
     def __init__(self, labels, model_path=None, alpha=0, beta=0, cutoff_top_n=40, cutoff_prob=1.0, beam_width=100,
-                 num_processes=4, blank_id=0, log_probs_input=False, device=None, logits_input=False):
+                 num_processes=4, blank_id=0, log_probs_input=False, device=None, logits_input=False, scorer=None):
         self.cutoff_top_n = cutoff_top_n
         self._beam_width = beam_width
         self._scorer = None
@@ -84,8 +182,16 @@ class CTCBeamDecoder(object):
         h = ctypes.c_void_p()
         _native.check(_native.lib.ctcd_create(ctypes.byref(h), self._device.index))
         self._handle = h
-        if model_path:  # ctcdecode/__init__.py:47-50 (`if model_path:`: None and "" both mean no scorer)
+        if scorer is not None:  # a ready-made scorer object (CallbackScorer / KenlmScorer): the swappable-scorer hook
+            self._scorer = _adopt_scorer(scorer, model_path, self._num_labels, self._device.index)
+        elif model_path:  # ctcdecode/__init__.py:47-50 (`if model_path:`: None and "" both mean no scorer)
             self._scorer = _Scorer(alpha, beta, model_path, self._labels, self._device.index)
+
+    def _check(self, rc):
+        """``_native.check`` for the calls a scorer callback runs under: an exception raised inside the callback comes first."""
+        if rc and self._scorer is not None and hasattr(self._scorer, "_raise_pending"):
+            self._scorer._raise_pending()
+        _native.check(rc)
 
     def set_threads(self, n):
         _native.check(_native.lib.ctcd_set_threads(self._handle, int(n)))
@@ -138,7 +244,7 @@ class CTCBeamDecoder(object):
             out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
             stream = torch.cuda.current_stream(self._device).cuda_stream
             if self._scorer is not None:  # ctcdecode/__init__.py:87-104 (paddle_beam_decode_lm)
-                _native.check(_native.lib.ctcd_beam_decode_lm(
+                self._check(_native.lib.ctcd_beam_decode_lm(
                     self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K,
                     self._num_processes, float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
                     self._scorer.handle, output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), None, stream))
@@ -178,7 +284,7 @@ class CTCBeamDecoder(object):
         out_len = torch.empty((B, K), dtype=torch.int32, pin_memory=pin)
         with torch.cuda.device(self._device):
             stream = torch.cuda.current_stream(self._device).cuda_stream
-            _native.check(_native.lib.ctcd_beam_decode_to_host(
+            self._check(_native.lib.ctcd_beam_decode_to_host(
                 self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, 1 if on_dev else 0, B, T, V, K,
                 self._num_processes, float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
                 self._scorer.handle if self._scorer is not None else None, output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(),
@@ -329,7 +435,7 @@ class OnlineCTCBeamDecoder(object):
     every stream stay in HBM between calls; ``timesteps`` count frames from the beginning of the stream."""
 
     def __init__(self, labels, model_path=None, alpha=0, beta=0, cutoff_top_n=40, cutoff_prob=1.0, beam_width=100,
-                 num_processes=4, blank_id=0, log_probs_input=False, device=None, logits_input=False):
+                 num_processes=4, blank_id=0, log_probs_input=False, device=None, logits_input=False, scorer=None):
         self._cutoff_top_n = cutoff_top_n
         self._beam_width = beam_width
         self._scorer = None
@@ -349,8 +455,16 @@ class OnlineCTCBeamDecoder(object):
         h = ctypes.c_void_p()
         _native.check(_native.lib.ctcd_create(ctypes.byref(h), self._device.index))
         self._handle = h
-        if model_path:  # ctcdecode/__init__.py:183-187
+        if scorer is not None:
+            self._scorer = _adopt_scorer(scorer, model_path, self._num_labels, self._device.index)
+        elif model_path:  # ctcdecode/__init__.py:183-187
             self._scorer = _Scorer(alpha, beta, model_path, self._labels, self._device.index)
+
+    def _check(self, rc):
+        """``_native.check`` for the calls a scorer callback runs under: an exception raised inside the callback comes first."""
+        if rc and self._scorer is not None and hasattr(self._scorer, "_raise_pending"):
+            self._scorer._raise_pending()
+        _native.check(rc)
 
     def set_threads(self, n):
         """Test hook (as CTCBeamDecoder.set_threads): threads per workgroup, 0 = the library's choice."""
@@ -396,7 +510,7 @@ class OnlineCTCBeamDecoder(object):
             output = torch.empty((B, K, out_T), dtype=torch.int32, device=self._device)
             timesteps = torch.empty((B, K, out_T), dtype=torch.int32, device=self._device)
             stream = torch.cuda.current_stream(self._device).cuda_stream
-            _native.check(_native.lib.ctcd_stream_decode(
+            self._check(_native.lib.ctcd_stream_decode(
                 self._handle, ptrs, eos, probs.data_ptr(), lens_cpu.data_ptr() if lens_cpu is not None else None, B, T, V, K, self._num_processes,
                 float(self._cutoff_prob), int(self._cutoff_top_n), int(self._blank_id), self._log_probs,
                 output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), nres.data_ptr(), out_T, stream))

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("CTCDECODE_AMD_LIB") or os.path.join(LIB_DIR, "libctcd
 SOURCES = ["ctcdecode_amd.hip"]
 KERNEL_SOURCE = "decode_kernels.hip"  # compiled once per group of kernel instantiations (decode_kernel.h CTC_KERNEL_LIST), in parallel
 KERNEL_GROUPS = 12
-HEADERS = ["decode_kernels.hip", "decode_kernel.h", "beam_core.h", "stl_emul.h", "exact_math.h", "exact_math_f64.h", "exact_math_f64_tables.h", "lm_tables.h", "lm_build.h", "compact_results.h", os.path.join("..", "..", "include", "ctcdecode_amd.h")]
+HEADERS = ["decode_kernels.hip", "decode_kernel.h", "beam_core.h", "stl_emul.h", "exact_math.h", "exact_math_f64.h", "exact_math_f64_tables.h", "lm_tables.h", "lm_build.h", "lm_callback.h", "compact_results.h", os.path.join("..", "..", "include", "ctcdecode_amd.h")]
 ROCM = os.environ.get("ROCM_HOME", "/opt/rocm")
 
 

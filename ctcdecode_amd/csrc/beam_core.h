@@ -163,7 +163,8 @@ enum {
   // (the first four are what every thread reads before phase B: one 16-byte group)
   VAR_SPEC = VAR_PAR0 + 2 * P_SIZE, SP_THR = 0, SP_WLOG, SP_ANCHOR, SP_PRED, SP_BEST, SP_MARGIN, SP_GAP, SP_ROWMAX,
   VAR_ROWMAX = VAR_SPEC + SP_ROWMAX,
-  VAR_COUNT = VAR_SPEC + 8
+  VAR_LMMISS = VAR_SPEC + 8,  // host-side scorer hook: this frame asked for something the cache does not hold (sticky within a launch)
+  VAR_COUNT = VAR_SPEC + 12
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
 constexpr int kBinsLog = 10;
@@ -368,7 +369,9 @@ struct OutRefs {
   uint32_t *m_rag;
   unsigned m_cap;
 };
-enum : int { ST_COMPACT_OVERFLOW = 3, ST_INPUT_TIMEOUT = 4 };
+enum : int { ST_COMPACT_OVERFLOW = 3, ST_INPUT_TIMEOUT = 4,
+             ST_NEED_HOST = 5,   // host-side scorer hook: a query the table cache does not hold yet -- the utterance is parked at a frame boundary
+             ST_CB_DANGER = 6 }; // ... and degenerate inputs (danger mode) are not supported with a callback scorer
 
 // What it takes to name a slot of a frame: the beam the frame started from, its #entries, #non-blank candidates (and the
 // multiplier that divides by it), the blank's rank; the layout itself is in w.ostart / w.cstart / w.anc.
@@ -438,6 +441,7 @@ struct Decoder {
       lm_char_v = lm->char_based != 0; lm_wide_v = lm->dict_wide != 0; lm_space = lm->space_id;
       lm_alpha = lm->alpha; lm_beta = lm->beta;
       lm_dict = lm->dict;
+      lm_cb = lm->cb != 0;
     }
   }
   CTC_HD int node_tstep(const PoolNode &pn, int id) const { return (int)(pn.cht >> 16) | (CTC_RARE(long_t) ? pool_thi[id] << 16 : 0); }
@@ -536,6 +540,27 @@ struct Decoder {
   int lm_space = -1;
   double lm_alpha = 0.0, lm_beta = 0.0;
   const ctclm::DictNode *lm_dict = nullptr;
+  bool lm_cb = false;  // host-side scorer hook: the tables are a cache of a host callback's answers (lm_tables.h LmView::cb)
+  // get_log_cond_prob through the tables.  With a callback scorer a value that is not cached yet comes back as NaN: the pair
+  // is queued for the host, the frame is marked (it will not be committed: step() / finish() return ST_NEED_HOST) and the
+  // caller's state is left where it was; a cached "out of vocabulary" answer (-inf) becomes the reference's OOV_SCORE.
+  CTC_HD double lm_cond_(uint32_t *st, int *cl, uint32_t word, bool *missed = nullptr) const {
+    const uint32_t st0 = *st;
+    const int cl0 = *cl;
+    const double v = ctclm::lm_cond(*lm, st, cl, word);
+    if (CTC_RARE(lm_cb)) {
+      if (v != v) {
+        w.vars[VAR_LMMISS] = 1;
+        const unsigned i = x.global_add(lm->cb_count, 1u);
+        if (i < lm->cb_cap) { lm->cb_miss[2 * i] = st0; lm->cb_miss[2 * i + 1] = word; }
+        *st = st0; *cl = cl0;
+        if (missed) *missed = true;
+        return 0.0;
+      }
+      if (v == -__builtin_huge_val()) return ctclm::kOovScore;
+    }
+    return v;
+  }
   static constexpr int kLmPending = -1;       // dfc of an entry whose dictionary record / cached window are not fetched yet
   int st_par = 0;  // which copy of the beam is current
 
@@ -592,7 +617,7 @@ struct Decoder {
     if (!lm_char_()) return mk_f64(b.spc_lo[P], b.spc_hi[P]);
     uint32_t st = (uint32_t)b.lmst[P];
     int cl = b.lmcl[P];
-    return ctclm::lm_cond(*lm, &st, &cl, lm->label_word[c]);
+    return lm_cond_(&st, &cl, lm->label_word[c]);
   }
   // may entry P be extended by c at all?  path_trie.cpp:59-70: only along the dictionary (word models)
   CTC_HD bool lm_allows(const Beam &b, int P, int c) const {
@@ -612,7 +637,7 @@ struct Decoder {
       return;
     }
     if (lm_char_()) {
-      acc += ctclm::lm_cond(*lm, &st, &cl, lm->label_word[c]);  // Scorer::get_log_prob sums the same windows (scorer.cpp:111-120)
+      acc += lm_cond_(&st, &cl, lm->label_word[c]);  // Scorer::get_log_prob sums the same windows (scorer.cpp:111-120)
       dst.dn[k] = 0; dst.dmlo[k] = 0; dst.dmhi[k] = 0; dst.dfc[k] = 0; dst.spc_lo[k] = 0; dst.spc_hi[k] = 0; dst.spst[k] = 0; dst.spcl[k] = 0;
     } else if (c == lm_space) {  // a word is complete: its window joins the sum, the speller restarts at the root (path_trie.cpp:83-92)
       acc += mk_f64(src.spc_lo[from], src.spc_hi[from]);
@@ -638,15 +663,17 @@ struct Decoder {
   // of path_trie.cpp:59-70) and the window "..., word spelled so far" -- used when a space follows
   // (ctc_beam_search_decoder.cpp:128) and for the last word in decode() (:173-185).
   CTC_HD void lm_resolve_entry(const Beam &b, int k, const ctclm::DictNode &info) const {
-    b.dmlo[k] = (int)info.mask_lo; b.dmhi[k] = (int)info.mask_hi; b.dfc[k] = (int)info.first_child;
     double cond = ctclm::kOovScore;
     uint32_t st2 = 0;
     int cl2 = 0;
     if (info.word != ctclm::kNoWord) {
       st2 = (uint32_t)b.lmst[k];
       cl2 = b.lmcl[k];
-      cond = ctclm::lm_cond(*lm, &st2, &cl2, info.word);
+      bool missed = false;
+      cond = lm_cond_(&st2, &cl2, info.word, &missed);
+      if (CTC_RARE(missed)) return;  // (callback scorer: not cached yet -- the entry stays pending, the frame will not be committed)
     }
+    b.dmlo[k] = (int)info.mask_lo; b.dmhi[k] = (int)info.mask_hi; b.dfc[k] = (int)info.first_child;
     put_f64(cond, &b.spc_lo[k], &b.spc_hi[k]);
     b.spst[k] = (int)st2; b.spcl[k] = cl2;
   }
@@ -750,6 +777,7 @@ struct Decoder {
       reset_pvars(pvars(1));
       w.vars[VAR_DANGER] = lm_params_extreme() ? 1 : 0;
       w.vars[VAR_INTO] = 0;
+      w.vars[VAR_LMMISS] = 0;
       w.apos[0] = 0; w.fin[0] = 0;
     }
     st_n = 1; st_pool = 1; st_wlog = 32;  // first select looks at the whole key range
@@ -794,6 +822,7 @@ struct Decoder {
       reset_pvars(pvars(1));
       w.vars[VAR_DANGER] = ss.hdr[SH_DANGER];
       w.vars[VAR_INTO] = 0;
+      w.vars[VAR_LMMISS] = 0;
     }
     for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
     for (int i = tid; i < 2 * K; i += nt) { w.hit[i] = 0; w.ancbuf[i] = -1; w.acntbuf[i] = 0; }
@@ -1246,7 +1275,12 @@ struct Decoder {
       full_beam = n == K;
     }
     auto cut = [&](float lp, float prefix_score) { return LM && full_beam && lp + prefix_score < min_cutoff; };
-    if (LM && CTC_RARE(x.uni(w.vars[VAR_DANGER]) != 0)) lm_sorted_order(b, n);
+    if (LM && CTC_RARE(x.uni(w.vars[VAR_DANGER]) != 0)) {
+      // (a frame that is abandoned because the callback scorer's cache missed has already overwritten the order the previous
+      //  frame left -- which only danger mode reads: the combination is refused rather than served wrong)
+      if (lm_cb) return ST_CB_DANGER;
+      lm_sorted_order(b, n);
+    }
 
     // ---- A1: per beam entry, from the LCP array alone: the end of its subtree range (first later entry whose LCP
     // with its predecessor is shallower than the entry), found by a wave-wide search; every entry then "paints" its
@@ -1820,6 +1854,10 @@ struct Decoder {
     x.mark(7);
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
     x.mark(9);
+    // host-side scorer hook: the frame asked for something the cache does not hold -- nothing of it is committed (the next
+    // beam lives in the other copy, its nodes beyond the pool's count; the few things a frame changes in place -- a prefix's
+    // best label probability and its node's time stamp -- are rewritten identically when the frame runs again)
+    if (LM && CTC_RARE(lm_cb) && x.uni(w.vars[VAR_LMMISS]) != 0) return ST_NEED_HOST;
     if (kTailZero && LM) {  // (the emission has read its survivors' keys: nothing looks at this frame's slots any more)
       const int S_next = n_new * (2 + Vnb);
       if (CTC_RARE(S_next < S))
@@ -1900,6 +1938,9 @@ struct Decoder {
       uint64_t *pk = sort_scratch();
       if (LM) {
         for (int a = tid; a < n; a += nt) {
+          // (callback scorer: an entry whose window is not cached yet has no LM fields -- the launch ends below and finish()
+          //  runs again once the host has answered; asking with what the fields happen to hold would queue nonsense)
+          if (CTC_RARE(lm_cb) && b.dfc[a] == kLmPending) continue;
           // the word the prefix ends in, when it does not end in a space (:173-185; word models only)
           const bool partial = !lm_char_() && b.dep[a] > 0 && ch[a] != lm_space;
           const bool word_here = partial && lm_allows(b, a, lm_space);  // a word of the model ends exactly here
@@ -1918,18 +1959,19 @@ struct Decoder {
           uint32_t st = (uint32_t)b.lmst[a];
           int cl = b.lmcl[a];
           if (b.dep[a] == 0) {               // empty prefix: the sentence is N x "<s>" then "</s>" (:97-100)
-            total += ctclm::lm_cond(*lm, &st, &cl, lm->w_bos);
+            total += lm_cond_(&st, &cl, lm->w_bos);
           } else if (partial) {
             total += wcond;
             if (word_here) { st = (uint32_t)b.spst[a]; cl = b.spcl[a]; } else { st = 0; cl = 0; }
           }
-          total += ctclm::lm_cond(*lm, &st, &cl, lm->w_eos);
+          total += lm_cond_(&st, &cl, lm->w_eos);
           double ap = (double)e;
           ap = ap - (double)(size_t)b.dep[a] * lm_beta;   // "remove word insert": per label (:203)
           ap -= total * lm_alpha;                          // :205
           approx[a] = (float)ap;
         }
         x.sync();
+        if (CTC_RARE(lm_cb) && x.uni(w.vars[VAR_LMMISS]) != 0) return ST_NEED_HOST;  // (nothing has been written to the results yet)
       }
       for (int p = tid; p < nres; p += nt) {
         const int a = w.fin[p];
@@ -2227,6 +2269,11 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     x.mark(10);
     const int st = dec.step(in, t == len - 1, stage, pre_lp, next_cnt, next_val);
     x.mark(12);
+    if (LM && CTC_RARE(st == ST_NEED_HOST)) {  // park the utterance in front of this frame; the host fills the cache and resumes it
+      dec.lm_resolve_pending();                 // (queues what the pending entries need as well: fewer round trips)
+      if (ss) dec.save_state(*ss, t0 + t);
+      return st;
+    }
     if (st != ST_OK) return st;
     // (streamed input that stopped arriving: step() ended with a full fence, the flag is visible to every wave)
     if (frames_ready != nullptr && (t & 15) == 15 && x.uni(w.vars[VAR_INTO]) != 0) return ST_INPUT_TIMEOUT;

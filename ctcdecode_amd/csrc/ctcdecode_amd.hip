@@ -27,6 +27,7 @@
 #include "decode_kernel.h"
 #include "exact_math_f64.h"
 #include "lm_build.h"
+#include "lm_callback.h"
 #include "compact_results.h"
 
 namespace {
@@ -867,7 +868,14 @@ struct ctcd_scorer {
   int device = 0;
   char *blob = nullptr;      // one HBM allocation holding every table
   ctclm::LmView dview;       // the tables as the kernel sees them (alpha / beta are refreshed at every launch)
+  // Host-side scorer hook (ctcd_scorer_create_callback, lm_callback.h): the device tables are a cache of the callback's
+  // answers -- grown between launches (cb_sync); `host` keeps the scalar facts the accessors report
+  ctclm::CallbackLm *cbl = nullptr;
+  char *cb_ng = nullptr, *cb_st = nullptr, *cb_uni = nullptr, *cb_miss = nullptr;  // cache slots | zeroed state arrays | NaN unigrams | miss list + counter
+  size_t cb_ng_slots = 0, cb_st_cap = 0;
+  std::mutex cb_mu;          // one decode at a time mutates the cache
 };
+constexpr uint32_t kCbMissCap = 1u << 18;  // queued (state, word) pairs per round (2 MB); more are dropped and asked again
 
 namespace {
 
@@ -888,6 +896,12 @@ struct StreamCall {          // extra arguments of a streaming decode (lens: the
   int out_T;
   const int32_t *lens;          // host: frames of this chunk per item
   bool any_eos;
+  // resumed launches of the scorer hook (decode_lm_callback): the results of items that finished in an earlier launch stay
+  // (nothing is zero-filled), every item starts at its own frame of the rows, and reports how far its parked state got
+  bool no_clear = false;
+  const int *frame_off = nullptr;   // device, [B]
+  int *frames_done = nullptr;       // device, [B]
+  const int32_t *row_lens = nullptr;  // device, [B]: frame_off + lens = the rows the pre-passes (log conversion, pruning) cover
 };
 
 std::atomic<unsigned long long> g_stream_call_id{0};
@@ -1065,11 +1079,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     HIP_TRY(hipMemsetAsync(co->count, 0, 4, stream));
     HIP_TRY(hipMemsetAsync(co->hdr, 0, (size_t)B * 16, stream));
   }
-  if (kt) {
+  if (kt && !(sc && sc->no_clear)) {
     HIP_TRY(hipMemsetAsync(out_tok, 0, kt * 4, stream));
     HIP_TRY(hipMemsetAsync(out_ts, 0, kt * 4, stream));
   }
-  if (!sc || sc->any_eos) {  // (a streaming call in which no stream ends writes no results: nothing to define)
+  if ((!sc || sc->any_eos) && !(sc && sc->no_clear)) {  // (a streaming call in which no stream ends writes no results: nothing to define)
     HIP_TRY(hipMemsetAsync(out_sc, 0, (size_t)B * beam * 4, stream));
     HIP_TRY(hipMemsetAsync(out_len, 0, (size_t)B * beam * 4, stream));
     if (sc && n_results) HIP_TRY(hipMemsetAsync(n_results, 0, (size_t)B * 4, stream));
@@ -1118,14 +1132,16 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     st_eos = (unsigned char *)db + off_eos;
     seq_lens = (const int32_t *)(db + off_len);
   }
+  // the rows the pre-passes cover (resumed launches of the scorer hook start inside the rows: StreamCall::row_lens)
+  const int32_t *pre_lens = (sc && sc->row_lens) ? sc->row_lens : seq_lens;
 
   if (log_input == 2) {  // raw logits: normalise once, in HBM; everything below sees log-probabilities
     if (T > 0) {
       if ((rc = d->lsm.ensure((size_t)B * T * V * 4))) return rc;
-      if (seq_lens) HIP_TRY(hipMemsetAsync(d->lsm.p, 0, (size_t)B * T * V * 4, stream));  // frames past an utterance's end stay defined
+      if (pre_lens) HIP_TRY(hipMemsetAsync(d->lsm.p, 0, (size_t)B * T * V * 4, stream));  // frames past an utterance's end stay defined
       const long long rows = (long long)B * T;
       hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 256 * 64)), dim3(256), 0, stream, probs,
-                         (float *)d->lsm.p, rows, seq_lens, T, V, (const uint64_t *)d->tables.p);
+                         (float *)d->lsm.p, rows, pre_lens, T, V, (const uint64_t *)d->tables.p);
       HIP_TRY(hipGetLastError());
       probs = (const float *)d->lsm.p;
     }
@@ -1184,7 +1200,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     HIP_TRY(hipMemsetAsync(n_flag, 0, 8, stream));
     HIP_TRY(hipMemsetAsync(d->pr_cnt.p, 0, (size_t)rows * 4, stream));
     PruneArgs pa;
-    pa.in = probs; pa.seq_lens = seq_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
+    pa.in = probs; pa.seq_lens = pre_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
     pa.stride = stride; pa.rows = rows; pa.cutoff_prob = cutoff_prob; pa.cnt = (int *)d->pr_cnt.p; pa.ch = (int *)d->pr_ch.p;
     pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
     void *pargs[] = {&pa};
@@ -1203,8 +1219,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     const size_t n = (size_t)B * T * V;
     if ((rc = d->logp.ensure(n * 4))) return rc;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-    if (seq_lens) HIP_TRY(hipMemsetAsync(d->logp.p, 0, n * 4, stream));  // frames past an utterance's end stay defined
-    hipLaunchKernelGGL(prob_to_log_kernel, dim3(blocks), dim3(256), 0, stream, probs, (float *)d->logp.p, n, seq_lens, T, V);
+    if (pre_lens) HIP_TRY(hipMemsetAsync(d->logp.p, 0, n * 4, stream));  // frames past an utterance's end stay defined
+    hipLaunchKernelGGL(prob_to_log_kernel, dim3(blocks), dim3(256), 0, stream, probs, (float *)d->logp.p, n, pre_lens, T, V);
     HIP_TRY(hipGetLastError());
     logp = (const float *)d->logp.p;
   }
@@ -1233,6 +1249,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     a.lm.beta = scorer->host.beta;
   }
   a.frames_ready = frames_ready;  // (streamed input of the host-tensor entry point; null: every row is in place)
+  a.frame_off = sc ? sc->frame_off : nullptr;
+  a.frames_done = sc ? sc->frames_done : nullptr;
   a.pr_cnt = nullptr; a.pr_ch = nullptr; a.pr_lp = nullptr; a.pr_stride = 0;
   if (dims.use_rank_table) {
     a.pr_cnt = (const int *)d->pr_cnt.p; a.pr_ch = (const int *)d->pr_ch.p; a.pr_lp = (const float *)d->pr_lp.p;
@@ -1385,7 +1403,93 @@ void ctcd_scorer_destroy(ctcd_scorer *s) {
   if (!s) return;
   DeviceGuard guard_(s->device);
   if (s->blob) (void)hipFree(s->blob);
+  for (char *p : {s->cb_ng, s->cb_st, s->cb_uni, s->cb_miss})
+    if (p) (void)hipFree(p);
+  delete s->cbl;
   delete s;
+}
+
+// ---- the host-side scorer hook (binding.cpp:122-150 hands the decoder an opaque scorer; scorer.h:41-78 is its interface)
+// Brings the device copy of the cache up to date with the host's: whole tables after a rehash / growth, single slots otherwise.
+static int cb_sync(ctcd_scorer *s) {
+  ctclm::CallbackLm &c = *s->cbl;
+  ctclm::HostScorer &h = c.hs;
+  if (c.rehashed || s->cb_ng_slots != h.ng.size()) {
+    if (s->cb_ng_slots != h.ng.size()) {
+      if (s->cb_ng) (void)hipFree(s->cb_ng);
+      s->cb_ng = nullptr;
+      HIP_TRY(hipMalloc((void **)&s->cb_ng, h.ng.size() * sizeof(ctclm::NgSlot)));
+      s->cb_ng_slots = h.ng.size();
+    }
+    HIP_TRY(hipMemcpy(s->cb_ng, h.ng.data(), h.ng.size() * sizeof(ctclm::NgSlot), hipMemcpyHostToDevice));
+  } else {
+    for (uint32_t i : c.dirty) HIP_TRY(hipMemcpy(s->cb_ng + (size_t)i * sizeof(ctclm::NgSlot), &h.ng[i], sizeof(ctclm::NgSlot), hipMemcpyHostToDevice));
+  }
+  c.rehashed = false;
+  c.dirty.clear();
+  if (s->cb_st_cap < h.st_bo.size()) {  // every state backs off to the empty context with weight 0: two zeroed arrays
+    if (s->cb_st) (void)hipFree(s->cb_st);
+    s->cb_st = nullptr;
+    const size_t cap = h.st_bo.size() * 2;
+    HIP_TRY(hipMalloc((void **)&s->cb_st, cap * 8));
+    HIP_TRY(hipMemset(s->cb_st, 0, cap * 8));
+    s->cb_st_cap = cap;
+  }
+  s->dview.ng = (const ctclm::NgSlot *)s->cb_ng;
+  s->dview.ng_mask = (uint32_t)h.ng.size() - 1;
+  s->dview.st_bo = (const float *)s->cb_st;
+  s->dview.st_fail = (const uint32_t *)(s->cb_st + s->cb_st_cap * 4);
+  return CTCD_OK;
+}
+
+int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, int max_order, const char *const *vocabulary, int n_vocabulary,
+                                ctcd_cond_log10_fn fn, void *user, const char *const *labels, int V, int device_id) {
+  if (!out || !fn || !labels || V <= 0 || n_vocabulary < 0 || (n_vocabulary && !vocabulary)) return fail(CTCD_EINVAL, "bad scorer arguments");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(CTCD_EINVAL, "no such HIP device");
+  std::vector<std::string> lab(V), voc(n_vocabulary);
+  for (int i = 0; i < V; ++i) { if (!labels[i]) return fail(CTCD_EINVAL, "null label"); lab[i] = labels[i]; }
+  for (int i = 0; i < n_vocabulary; ++i) { if (!vocabulary[i]) return fail(CTCD_EINVAL, "null vocabulary word"); voc[i] = vocabulary[i]; }
+  ctcd_scorer *s = new ctcd_scorer;
+  s->device = device_id;
+  s->cbl = new ctclm::CallbackLm;
+  if (!s->cbl->build(alpha, beta, max_order, voc, lab, (ctclm::CondLog10Fn)fn, user)) {
+    const std::string msg = s->cbl->hs.error;
+    ctcd_scorer_destroy(s);
+    return fail(CTCD_EINVAL, msg);
+  }
+  const ctclm::HostScorer &h = s->cbl->hs;
+  // the scalar facts the accessors and the launches read (the tables stay with the callback object)
+  s->host.alpha = alpha; s->host.beta = beta; s->host.order = h.order; s->host.char_based = h.char_based; s->host.dict_size = h.dict_size;
+  s->host.space_id = h.space_id; s->host.labels = h.labels; s->host.dict_wide = h.dict_wide;
+  CTC_ON_DEVICE(device_id);
+  size_t off = 0;
+  auto place = [&off](size_t bytes) { const size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+  const size_t o_up = place(h.uni_prob.size() * 4), o_us = place(h.uni_state.size() * 4), o_dc = place(h.dict.size() * sizeof(ctclm::DictNode)),
+               o_lw = place(h.label_word.size() * 4), o_dl = place(h.dict_lab.size() * 4);
+  hipError_t e = hipMalloc((void **)&s->cb_uni, off ? off : 256);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->cb_miss, (size_t)kCbMissCap * 8 + 256);
+  if (e != hipSuccess) { ctcd_scorer_destroy(s); return fail(CTCD_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  auto up = [&](size_t o, const void *src, size_t bytes) { return bytes ? hipMemcpy(s->cb_uni + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
+  if ((e = up(o_up, h.uni_prob.data(), h.uni_prob.size() * 4)) != hipSuccess || (e = up(o_us, h.uni_state.data(), h.uni_state.size() * 4)) != hipSuccess ||
+      (e = up(o_dc, h.dict.data(), h.dict.size() * sizeof(ctclm::DictNode))) != hipSuccess ||
+      (e = up(o_lw, h.label_word.data(), h.label_word.size() * 4)) != hipSuccess || (e = up(o_dl, h.dict_lab.data(), h.dict_lab.size() * 4)) != hipSuccess) {
+    ctcd_scorer_destroy(s);
+    return fail(CTCD_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+  }
+  s->dview = h.view();
+  s->dview.uni_prob = (const float *)(s->cb_uni + o_up); s->dview.uni_state = (const uint32_t *)(s->cb_uni + o_us);
+  s->dview.dict = (const ctclm::DictNode *)(s->cb_uni + o_dc); s->dview.label_word = (const uint32_t *)(s->cb_uni + o_lw);
+  s->dview.dict_lab = (const uint32_t *)(s->cb_uni + o_dl);
+  s->dview.cb = 1;
+  s->dview.cb_count = (unsigned *)s->cb_miss;
+  s->dview.cb_miss = (uint32_t *)(s->cb_miss + 256);
+  s->dview.cb_cap = kCbMissCap;
+  const int rc = cb_sync(s);
+  if (rc) { ctcd_scorer_destroy(s); return rc; }
+  *out = s;
+  return CTCD_OK;
 }
 int ctcd_scorer_is_character_based(const ctcd_scorer *s) { return s ? (s->host.char_based ? 1 : 0) : -1; }
 int ctcd_scorer_max_order(const ctcd_scorer *s) { return s ? s->host.order : -1; }
@@ -1398,15 +1502,142 @@ int ctcd_scorer_reset_params(ctcd_scorer *s, double alpha, double beta) {
 }
 double ctcd_scorer_cond_log_prob(const ctcd_scorer *s, const char *const *words, int n) {
   if (!s || !words || n < 0) return 0.0;
+  if (s->cbl) {  // the callback itself, with the reference's conversion (scorer.cpp:74-93)
+    float p10 = 0.f;
+    const int rc = n > 0 ? s->cbl->fn(s->cbl->user, words, n, &p10) : 1;
+    return rc == 0 ? (double)p10 / (double)0.4342944819f : ctclm::kOovScore;
+  }
   std::vector<std::string> w(n);
   for (int i = 0; i < n; ++i) w[i] = words[i] ? words[i] : "";
   return s->host.cond_log_prob(w);
+}
+// ... and in the form the scorer hook speaks (ctcd_cond_log10_fn): the float32 log10 probability before the reference's
+// conversion; returns 1 for a window with an unknown word.  Lets the built-in tables serve as a callback (tests, adapters).
+int ctcd_scorer_cond_log10(const ctcd_scorer *s, const char *const *words, int n, float *log10_prob) {
+  if (!s || !words || n <= 0 || !log10_prob) return -1;
+  if (s->cbl) return s->cbl->fn(s->cbl->user, words, n, log10_prob);
+  std::vector<std::string> w(n);
+  for (int i = 0; i < n; ++i) w[i] = words[i] ? words[i] : "";
+  return s->host.cond_log10(w, log10_prob);
+}
+long long ctcd_scorer_callback_calls(const ctcd_scorer *s) { return s && s->cbl ? (long long)s->cbl->queries : 0; }
+
+// Decoding with a callback scorer (ctcd_scorer_create_callback).  A launch decodes until an utterance asks for a (history, word)
+// pair the device cache does not hold, parks that utterance in front of the frame it was in (every utterance runs as a stream:
+// the caller's own, or a temporary one) and queues the pair; the host asks the callback, inserts the answers and launches
+// again -- the parked utterances resume where they stopped, the finished ones pass through untouched -- until every utterance
+// has consumed its rows.  Results equal those of a scorer whose tables were complete from the start (tests: the built-in ARPA
+// tables behind the callback, bit for bit).  A capability, not a fast path: a launch per round of misses plus the callback's
+// own time; a warm cache needs one launch.
+static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char *is_eos, const int32_t *lens, const float *probs, int B, int T, int V,
+                     int beam, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer, int32_t *out_tok,
+                     int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, int out_T, void *stream_) {
+  std::lock_guard<std::mutex> cache_lock(scorer->cb_mu);
+  hipStream_t stream = (hipStream_t)stream_;
+  struct Scratch {
+    char *ctl = nullptr;
+    ~Scratch() { if (ctl) (void)hipFree(ctl); }
+  } mem;
+  HIP_TRY(hipMalloc((void **)&mem.ctl, (size_t)B * 12 + 256));  // [frame offsets | frames done | row lengths]
+  int *d_off = (int *)mem.ctl, *d_done = d_off + B, *d_rows = d_done + B;
+  HIP_TRY(hipMemcpyAsync(d_rows, lens, (size_t)B * 4, hipMemcpyHostToDevice, stream));
+  std::vector<int32_t> done(B, 0), rem(B), st_h(B), fd_h(B);
+  std::vector<unsigned char> eos(B), finished(B, 0);
+  std::vector<uint32_t> miss;
+  int rc;
+  for (int round = 0;; ++round) {
+    if (round > 4 * T + 64) return fail(CTCD_EINTERNAL, "scorer hook: the decode does not make progress");
+    if ((rc = cb_sync(scorer))) return rc;
+    int left = 0;
+    bool any_eos = false;
+    for (int b = 0; b < B; ++b) {
+      rem[b] = finished[b] ? 0 : lens[b] - done[b];
+      eos[b] = finished[b] ? 0 : is_eos[b];
+      any_eos |= eos[b] != 0;
+      left += !finished[b];
+    }
+    if (!left) break;
+    HIP_TRY(hipMemcpyAsync(d_off, done.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(scorer->cb_miss, 0, 4, stream));
+    StreamCall sc{states, eos.data(), out_T, rem.data(), any_eos};
+    sc.no_clear = round > 0;
+    sc.frame_off = d_off;
+    sc.frames_done = d_done;
+    sc.row_lens = d_rows;
+    if ((rc = decode_common(d, probs, nullptr, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok, out_ts, out_sc, out_len,
+                            n_results, stream_, &sc, scorer)))
+      return rc;
+    unsigned nmiss = 0;
+    HIP_TRY(hipMemcpyAsync(st_h.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(fd_h.data(), d_done, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&nmiss, scorer->cb_miss, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    bool need = false;
+    for (int b = 0; b < B; ++b) {
+      if (finished[b]) continue;
+      if (st_h[b] == ST_OK) { finished[b] = 1; continue; }
+      if (st_h[b] == ST_CB_DANGER)
+        return fail(CTCD_EUNSUPPORTED, "a callback scorer does not support rows with infinite / overflowing log-probabilities (item " + std::to_string(b) + ")");
+      if (st_h[b] != ST_NEED_HOST) return fail(CTCD_EINTERNAL, "decoder status " + std::to_string(st_h[b]) + " for item " + std::to_string(b));
+      done[b] = (int32_t)(fd_h[b] - states[b]->frames);  // (the parked state counts the stream's frames; the rows, this call's)
+      need = true;
+    }
+    if (need) {
+      if (nmiss == 0) return fail(CTCD_EINTERNAL, "scorer hook: an utterance waits for the host but queued nothing");
+      const unsigned take = nmiss < kCbMissCap ? nmiss : kCbMissCap;  // (pairs beyond the list's capacity are asked for again next round)
+      miss.resize((size_t)2 * take);
+      HIP_TRY(hipMemcpy(miss.data(), scorer->cb_miss + 256, (size_t)take * 8, hipMemcpyDeviceToHost));
+      for (unsigned i = 0; i < take; ++i)
+        if (!scorer->cbl->resolve(miss[2 * i], miss[2 * i + 1])) return fail(CTCD_EINVAL, scorer->cbl->hs.error);
+    }
+  }
+  return CTCD_OK;
+}
+
+// ... for a whole batch: temporary streams in one allocation, a block per utterance sized for all T frames
+static int decode_lm_callback(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, double cutoff_prob,
+                              int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer, int32_t *out_tok, int32_t *out_ts,
+                              float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  if (B <= 0 || T < 0 || beam <= 0 || beam > kMaxBeam) return B == 0 ? CTCD_OK : fail(CTCD_EINVAL, "bad arguments");
+  CTC_ON_DEVICE(d->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<int32_t> len(B, T);
+  if (seq_lens) {
+    HIP_TRY(hipMemcpyAsync(len.data(), seq_lens, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int b = 0; b < B; ++b) len[b] = len[b] < 0 ? 0 : (len[b] > T ? T : len[b]);  // binding.cpp:64-65
+  }
+  const long long capf = T > 0 ? T : 1;
+  const size_t blk = (stream_block_bytes(capf, beam) + 255) / 256 * 256;
+  struct Scratch {
+    char *blocks = nullptr;
+    ~Scratch() { if (blocks) (void)hipFree(blocks); }
+  } mem;
+  HIP_TRY(hipMalloc((void **)&mem.blocks, blk * (size_t)B));
+  std::vector<ctcd_stream> sts(B);
+  std::vector<ctcd_stream *> states(B);
+  for (int b = 0; b < B; ++b) {
+    ctcd_stream &st = sts[b];
+    st.device = d->device; st.scorer = scorer; st.block = mem.blocks + (size_t)b * blk; st.bytes = blk; st.V = V; st.beam = beam; st.frames = 0; st.cap_frames = capf;
+    states[b] = &st;
+    HIP_TRY(hipMemsetAsync(st.block, 0, stream_pool_offset(beam), stream));  // frames == 0: the first launch initialises the beam
+    HIP_TRY(hipMemsetAsync(st.block + stream_thi_offset(capf, beam), 0, stream_nodes(capf, beam) * sizeof(int), stream));
+  }
+  const std::vector<unsigned char> eos(B, 1);
+  const int rc = cb_rounds(d, states.data(), eos.data(), len.data(), probs, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, scorer, out_tok,
+                           out_ts, out_sc, out_len, n_results, T, stream_);
+  (void)hipStreamSynchronize(stream);  // (the blocks are freed on return)
+  return rc;
 }
 
 int ctcd_beam_decode_lm(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                         int /*num_processes*/, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer,
                         int32_t *out_tok, int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
   if (!scorer) return fail(CTCD_EINVAL, "scorer == NULL (use ctcd_beam_decode)");
+  if (scorer->cbl)
+    return decode_lm_callback(d, probs, seq_lens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, scorer, out_tok, out_ts, out_sc,
+                              out_len, n_results, stream_);
   return decode_common(d, probs, seq_lens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok, out_ts, out_sc,
                        out_len, n_results, stream_, nullptr, scorer);
 }
@@ -1488,6 +1719,13 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
     }
   }
   // (the chunk lengths travel with the other per-item arguments: decode_common)
+  if (states[0]->scorer && states[0]->scorer->cbl) {  // a callback scorer: as many launches as its cache needs
+    const int rc = cb_rounds(d, states, is_eos, lens.data(), probs, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, states[0]->scorer, out_tok,
+                             out_ts, out_sc, out_len, n_results, out_T, stream_);
+    if (rc) return rc;
+    for (int b = 0; b < B; ++b) states[b]->frames += lens[b];
+    return CTCD_OK;
+  }
   StreamCall sc{states, is_eos, out_T, lens.data(), any_eos};
   int rc = decode_common(d, probs, nullptr, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok,
                          out_ts, out_sc, out_len, n_results, stream_, &sc, states[0]->scorer);
@@ -1514,6 +1752,7 @@ int ctcd_beam_decode_compact(ctcd_decoder *d, const float *probs, const int32_t 
                              ctcd_scorer *scorer, int32_t *c_hdr, int32_t *c_ent, uint32_t *c_labels, uint32_t *c_count,
                              long long label_capacity, float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
   if (!c_hdr || !c_ent || !c_labels || !c_count || label_capacity <= 0) return fail(CTCD_EINVAL, "compact buffers missing");
+  if (scorer && scorer->cbl) return fail(CTCD_EUNSUPPORTED, "compact results with a callback scorer (decode into the padded tensors: ctcd_beam_decode_lm)");
   CompactOut co{c_hdr, c_ent, c_labels, c_count, (unsigned)std::min<long long>(label_capacity, 0xFFFFFFFFLL)};
   return decode_common(d, probs, seq_lens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, out_sc,
                        out_len, n_results, stream_, nullptr, scorer, &co);
@@ -1584,7 +1823,7 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
   // (V <= the workgroup size the launch will use -- decode_common: the caller's, or at least 512 -- so that the kernel
   //  prefetches its rows: ADVICE r3; rows that are not prefetched wait as well since round 4, this keeps the fast form)
   const bool stream_in = !probs_on_device && log_input == 1 && !pruned_in && T >= 128 && T <= 65536 && V <= (d->threads ? d->threads : 512) &&
-                         nin >= ((size_t)1 << 20) && !d->no_input_streaming && !d->profile;
+                         nin >= ((size_t)1 << 20) && !d->no_input_streaming && !d->profile && !(scorer && scorer->cbl);
   int nblk = 0;
   int blk[10];
   const int *frames_ready = nullptr;
@@ -1621,13 +1860,18 @@ static int decode_to_host_locked(ctcd_decoder *d, const float *probs, const int3
     dprobs = (const float *)din;
     dlens = seq_lens ? (const int32_t *)(din + off_sl) : nullptr;
   }
-  if (T > 65536 || V > 65535 || T == 0) {  // outside the compact format's 16-bit fields: the padded tensors travel
+  const bool hook = scorer && scorer->cbl;  // a callback scorer: launch after launch (cb_rounds) into the padded tensors
+  if (T > 65536 || V > 65535 || T == 0 || hook) {  // outside the compact format's 16-bit fields: the padded tensors travel
     const size_t kt = kk * T * 4;
     const size_t o_ts = (kt + 15) / 16 * 16, o_sc = o_ts * 2, o_ln = o_sc + (kk * 4 + 15) / 16 * 16, o_nr = o_ln + (kk * 4 + 15) / 16 * 16;
     if ((rc = d->stage_out.ensure(o_nr + (size_t)B * 4 + 16))) return rc;
     char *dout = (char *)d->stage_out.p;
-    rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, (int32_t *)dout, (int32_t *)(dout + o_ts),
-                       (float *)(dout + o_sc), (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), stream, nullptr, scorer);
+    if (hook)
+      rc = decode_lm_callback(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, scorer, (int32_t *)dout,
+                              (int32_t *)(dout + o_ts), (float *)(dout + o_sc), (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), stream);
+    else
+      rc = decode_common(d, dprobs, dlens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, (int32_t *)dout, (int32_t *)(dout + o_ts),
+                         (float *)(dout + o_sc), (int32_t *)(dout + o_ln), (int32_t *)(dout + o_nr), stream, nullptr, scorer);
     if (rc) return rc;
     if ((rc = ctcd_check_status(d, B))) return rc;
     if (kt) {

@@ -770,6 +770,10 @@ struct KernelArgs {
   const float *raw;         // [B, T, V] as given by the caller
   int raw_log;              // 1: they are log-probabilities
   const int *frames_ready;  // streamed input (host-tensor entry point): frames of every utterance that have arrived; null: all
+  // host-side scorer hook (resumed launches): per item, the frame of its [T, V] rows this launch starts at (null: 0), and
+  // where the kernel reports the frames the item's parked state has consumed when the launch ends (null: nowhere)
+  const int *frame_off;
+  int *frames_done;
   const int *pr_cnt;        // pruned mode: [B, T] candidates per frame (null in identity mode)
   const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
   const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
@@ -815,11 +819,12 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
   __syncthreads();
   if (PROF == 1) x.last = (long long)wall_clock64();
+  const size_t f0 = a.frame_off ? (size_t)__builtin_amdgcn_readfirstlane(a.frame_off[b]) : 0;  // (resumed launches of the scorer hook)
   PrunedRows prow;
   if (PRUNED) {
-    prow.cnt = a.pr_cnt + (size_t)b * a.T;
-    prow.ch = a.pr_ch + (size_t)b * a.T * a.pr_stride;
-    prow.lp = a.pr_lp + (size_t)b * a.T * a.pr_stride;
+    prow.cnt = a.pr_cnt + (size_t)b * a.T + f0;
+    prow.ch = a.pr_ch + ((size_t)b * a.T + f0) * a.pr_stride;
+    prow.lp = a.pr_lp + ((size_t)b * a.T + f0) * a.pr_stride;
     prow.stride = a.pr_stride;
   }
   PoolNode *pool = a.pool + (size_t)b * a.pool_stride;
@@ -847,11 +852,14 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #else
   if (LM) lmv = &a.lm;
 #endif
-  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + (size_t)b * a.T * a.V,
+  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
-                                  a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + (size_t)b * a.T * a.V : nullptr, a.raw_log,
+                                  a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + ((size_t)b * a.T + f0) * a.V : nullptr, a.raw_log,
                                   PRUNED ? (const int *)nullptr : a.frames_ready);
-  if (threadIdx.x == 0) a.status[b] = st;
+  if (threadIdx.x == 0) {
+    a.status[b] = st;
+    if (a.frames_done && a.st_base) a.frames_done[b] = ss.hdr[SH_FRAMES];  // (written by this thread in save_state)
+  }
   if (PROF == 2 && a.tl && b == 0) {
     __syncthreads();
     for (int i = threadIdx.x; i < 16 * kTlCap; i += blockDim.x) a.tl[i] = tlbuf[i];  // (LM build: [16][kTimelineCap / 2])

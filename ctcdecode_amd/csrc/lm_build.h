@@ -69,6 +69,7 @@ struct HostScorer {
     v.dict_lab = dict_lab.data(); v.dict_wide = dict_wide ? 1 : 0;
     v.ng_mask = (uint32_t)ng.size() - 1; v.order = order; v.char_based = char_based ? 1 : 0; v.space_id = space_id;
     v.s0 = s0; v.clean0 = clean0; v.w_bos = w_bos; v.w_eos = w_eos; v.alpha = alpha; v.beta = beta;
+    v.cb = 0; v.cb_miss = nullptr; v.cb_count = nullptr; v.cb_cap = 0;
     return v;
   }
 
@@ -214,6 +215,12 @@ struct HostScorer {
       s0 = st;
       clean0 = cl;
     }
+    return build_labels_and_dictionary();
+  }
+
+  // The label map and, for word models, the dictionary -- from `labels`, `vocab`, `word_id` and `char_based` (shared with
+  // the callback scorer, lm_callback.h, whose vocabulary comes from the caller instead of an ARPA file).
+  bool build_labels_and_dictionary() {
     // ---- labels (set_char_map, scorer.cpp:148-161): the last label that reads " " is the space
     std::unordered_map<std::string, int> cmap;
     for (size_t i = 0; i < labels.size(); ++i) {
@@ -283,6 +290,21 @@ struct HostScorer {
     return true;
   }
 
+  // ... the same query in the form the host-side scorer hook speaks (lm_callback.h): the float32 log10 probability kenlm's
+  // BaseScore returns for the last word, before the reference divides it by NUM_FLT_LOGE; returns 1 for a window with an
+  // unknown word (the reference's OOV_SCORE), else 0
+  int cond_log10(const std::vector<std::string> &words, float *p10) const {
+    const LmView v = view();
+    uint32_t st = 0;
+    float p = 0.f;
+    for (const std::string &w : words) {
+      const uint32_t id = id_of(w);
+      if (id == 0) return 1;
+      p = lm_score(v, st, id, &st);
+    }
+    *p10 = p;
+    return 0;
+  }
   // Scorer::get_log_cond_prob (scorer.cpp:74-93) on explicit words -- test / introspection entry
   double cond_log_prob(const std::vector<std::string> &words) const {
     const LmView v = view();

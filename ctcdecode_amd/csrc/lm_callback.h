@@ -1,0 +1,148 @@
+// lm_callback.h -- the host-side swappable scorer hook (north_star: "the KenLM Scorer hook stays on host behind
+// the existing swappable-scorer interface").  Host-only; no HIP types.
+//
+// The reference hands its decoder an opaque `void *scorer` (ctcdecode/src/binding.cpp:122-140) whose
+// Scorer::get_log_cond_prob(words) (scorer.h:41-78, scorer.cpp:74-93) any implementation can back; it is called inside the
+// per-frame loop (ctc_beam_search_decoder.cpp:120-137).  A host call per query is not an option inside a kernel that spends a
+// few microseconds per frame, so the hook is served through a CACHE in the very tables the built-in scorer uses
+// (lm_tables.h):
+//
+//   * a state is a word HISTORY (the N-1 words a window starts with; state 1 = N-1 x "<s>", what make_ngram pads a short
+//     prefix with, scorer.cpp:184-189), (state, word) -> {log10 probability as float32 -- what kenlm's BaseScore returns and
+//     the reference divides by NUM_FLT_LOGE --, next state} in the same open-addressed table of 16-byte slots;
+//   * every state "backs off" to the empty context with weight 0 and every unigram probability is NaN: a pair the cache does
+//     not hold reads as NaN through the unchanged n-gram query of the kernel.  The kernel then queues the pair, abandons the
+//     frame it is in and parks the utterance in front of it (the streaming machinery: beam_core.h ST_NEED_HOST); the host
+//     asks the callback, inserts the answers and resumes the launch.  A window the callback calls out-of-vocabulary is cached
+//     as -inf and becomes the reference's OOV_SCORE (scorer.h:16) in the kernel;
+//   * the dictionary of a word model (scorer.cpp:196-230) and the label map are built from the vocabulary the caller supplies,
+//     exactly as for an ARPA file (lm_build.h build_labels_and_dictionary).
+//
+// The built-in ARPA tables are one implementation of the same interface (HostScorer::cond_log10): tests run the decoder with a
+// callback that asks them and require bit-identical results.  A callback backed by the `kenlm` Python module (binary models
+// included) is ctcdecode_amd.KenlmScorer.
+#pragma once
+#include <cmath>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "lm_build.h"
+
+namespace ctclm {
+
+// log10 p(words[n-1] | words[0 .. n-2]) as kenlm's BaseScore gives it (float32).  Returns 0 = ok, 1 = the window holds an
+// out-of-vocabulary word (the reference returns OOV_SCORE), < 0 = error (the decode fails).
+typedef int (*CondLog10Fn)(void *user, const char *const *words, int n, float *log10_prob);
+
+struct CallbackLm {
+  HostScorer hs;  // labels, dictionary, and the cache tables (ng, st_bo, st_fail, uni_prob, uni_state)
+  CondLog10Fn fn = nullptr;
+  void *user = nullptr;
+  std::vector<std::vector<uint32_t>> hist;                 // per state: its word history (state 0 is never used)
+  std::map<std::vector<uint32_t>, uint32_t> state_of;
+  size_t used = 0;                                         // cache slots in use
+  std::vector<uint32_t> dirty;                             // slots written since the device copy was last brought up to date
+  bool rehashed = true;                                    // the whole table must travel
+  unsigned long long queries = 0;                          // callback calls so far
+
+  uint32_t state_id(const std::vector<uint32_t> &h) {
+    auto it = state_of.find(h);
+    if (it != state_of.end()) return it->second;
+    const uint32_t id = (uint32_t)hist.size();
+    hist.push_back(h);
+    state_of.emplace(h, id);
+    if (hs.st_bo.size() <= id) { hs.st_bo.resize((size_t)id * 2 + 64, 0.0f); hs.st_fail.resize(hs.st_bo.size(), 0u); }
+    return id;
+  }
+
+  bool build(double alpha, double beta, int order, const std::vector<std::string> &vocabulary, const std::vector<std::string> &labels,
+             CondLog10Fn fn_, void *user_) {
+    if (!fn_) return hs.fail("no scorer callback");
+    if (order < 1 || order > kMaxOrder) return hs.fail("max_order must be in [1, 6] (KENLM_MAX_ORDER of the reference's build)");
+    fn = fn_; user = user_;
+    hs.alpha = alpha; hs.beta = beta; hs.order = order; hs.labels = labels;
+    hs.vocab.assign(1, "<unk>");
+    auto add = [&](const std::string &w) {
+      if (w == "<unk>" || hs.word_id.count(w)) return;
+      hs.word_id[w] = (uint32_t)hs.vocab.size();
+      hs.vocab.push_back(w);
+    };
+    for (const std::string &w : vocabulary) add(w);
+    add("<s>");
+    add("</s>");
+    hs.char_based = true;  // Scorer::load_lm's test (scorer.cpp:65-71)
+    for (const std::string &w : hs.vocab)
+      if (w != "<unk>" && w != "<s>" && w != "</s>" && HostScorer::utf8_len(w) > 1) hs.char_based = false;
+    // a character model is asked about every label: labels the vocabulary does not list get ids of their own, so that the
+    // CALLBACK decides what is out of vocabulary (the reference passes the strings through, scorer.cpp:163-194)
+    if (hs.char_based)
+      for (const std::string &l : labels) add(l);
+    hs.w_bos = hs.id_of("<s>");
+    hs.w_eos = hs.id_of("</s>");
+    hs.uni_prob.assign(hs.vocab.size(), std::numeric_limits<float>::quiet_NaN());
+    hs.uni_state.assign(hs.vocab.size(), 0u);
+    hs.st_bo.assign(64, 0.0f);
+    hs.st_fail.assign(64, 0u);
+    hs.ng.assign(1024, NgSlot{kEmptySlot, 0, 0, 0});
+    hist.assign(1, std::vector<uint32_t>());  // state 0: the kernel's "empty context", never a key
+    state_of.clear();
+    hs.s0 = state_id(std::vector<uint32_t>((size_t)order - 1, hs.w_bos));
+    hs.clean0 = order - 1;  // no word is ever "unknown" to the tables: the callback decides
+    used = 0; dirty.clear(); rehashed = true;
+    return hs.build_labels_and_dictionary();
+  }
+
+  void insert(const NgSlot &s) {
+    if ((used + 1) * 2 > hs.ng.size()) {  // at most half full
+      std::vector<NgSlot> old;
+      old.swap(hs.ng);
+      hs.ng.assign(old.size() * 2, NgSlot{kEmptySlot, 0, 0, 0});
+      for (const NgSlot &o : old)
+        if (o.state != kEmptySlot) place(o);
+      rehashed = true;
+    }
+    const uint32_t h = place(s);
+    ++used;
+    if (!rehashed) dirty.push_back(h);
+  }
+  uint32_t place(const NgSlot &s) {
+    const uint32_t mask = (uint32_t)hs.ng.size() - 1;
+    uint32_t h = ng_hash(s.state, s.word) & mask;
+    while (hs.ng[h].state != kEmptySlot) h = (h + 1) & mask;
+    hs.ng[h] = s;
+    return h;
+  }
+  bool cached(uint32_t state, uint32_t word) const {
+    const uint32_t mask = (uint32_t)hs.ng.size() - 1;
+    for (uint32_t h = ng_hash(state, word) & mask; hs.ng[h].state != kEmptySlot; h = (h + 1) & mask)
+      if (hs.ng[h].state == state && hs.ng[h].word == word) return true;
+    return false;
+  }
+
+  // one queued pair: ask the callback, cache the answer.  false: the callback failed (hs.error says how)
+  bool resolve(uint32_t state, uint32_t word) {
+    if (state == 0 || state >= hist.size() || word == 0 || word >= hs.vocab.size()) return hs.fail("scorer hook: the kernel queued a query that cannot exist (state " + std::to_string(state) + " of " + std::to_string(hist.size()) + ", word " + std::to_string(word) + " of " + std::to_string(hs.vocab.size()) + ")");
+    if (cached(state, word)) return true;  // (queued by several prefixes / utterances in the same round)
+    std::vector<uint32_t> win = hist[state];
+    win.push_back(word);
+    std::vector<const char *> ptr;
+    for (uint32_t id : win) ptr.push_back(hs.vocab[id].c_str());
+    float p10 = 0.f;
+    const int rc = fn(user, ptr.data(), (int)ptr.size(), &p10);
+    ++queries;
+    if (rc < 0) return hs.fail("scorer hook: the callback reported an error");
+    if (rc == 0 && !(p10 == p10)) return hs.fail("scorer hook: the callback returned NaN");
+    if (rc != 0) p10 = -std::numeric_limits<float>::infinity();
+    NgSlot s;
+    s.state = state; s.word = word;
+    std::memcpy(&s.prob_bits, &p10, 4);
+    std::vector<uint32_t> nh(win.end() - (hs.order - 1), win.end());  // the window's last N-1 words
+    s.next = state_id(nh);
+    insert(s);
+    return true;
+  }
+};
+
+}  // namespace ctclm

@@ -65,6 +65,15 @@ struct LmView {
   int clean0;                  // N-1 if "<s>" is a word of the model, else 0
   uint32_t w_bos, w_eos;       // word ids of "<s>" and "</s>" (0 = unknown)
   double alpha, beta;
+  // Host-side scorer hook (lm_callback.h): the tables are a CACHE of a host callback's answers -- an explicit automaton over
+  // word histories, filled on demand.  A (state, word) pair that is not cached yet reads as NaN (every uni_prob is NaN,
+  // every state backs off to the empty context with weight 0); the kernel then appends the pair to cb_miss (cb_count is its
+  // bump counter, cb_cap pairs fit) and ends the launch for that utterance at the frame boundary; the host asks the
+  // callback, inserts, and the launch resumes.  A cached "out of vocabulary" answer is log10 prob = -inf.
+  int cb;                      // 1: callback scorer
+  uint32_t *cb_miss;           // [cb_cap][2] (state, word)
+  unsigned *cb_count;
+  uint32_t cb_cap;
 };
 
 CTC_HD uint32_t ng_hash(uint32_t state, uint32_t word) {

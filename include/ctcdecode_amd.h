@@ -119,6 +119,33 @@ int ctcd_scorer_dict_size(const ctcd_scorer *scorer);
 int ctcd_scorer_reset_params(ctcd_scorer *scorer, double alpha, double beta);
 /* Scorer::get_log_cond_prob (scorer.cpp:74-93) on explicit words, evaluated on the host copy of the tables (tests). */
 double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *words, int n);
+/* ---- The swappable scorer: a scorer whose language model lives behind a HOST callback.  The reference's decoder takes an
+ * opaque `void *scorer` (binding.cpp:122-140) and only ever calls Scorer::get_log_cond_prob(words) on the language-model side
+ * (scorer.h:41-78, scorer.cpp:74-93; called from ctc_beam_search_decoder.cpp:120-137 with the window make_ngram built,
+ * scorer.cpp:163-194); this is that interface across the C ABI, for models the built-in ARPA tables do not cover (binary
+ * kenlm files through the `kenlm` module, a neural LM, a remote service ...).
+ *   fn(user, words, n, &log10_prob): the window's n = max_order words, oldest first, "<s>"-padded as make_ngram pads them;
+ *     store log10 p(words[n-1] | words[0..n-2]) as float32 -- what kenlm's BaseScore returns, the decoder applies the
+ *     reference's conversion p / NUM_FLT_LOGE (scorer.cpp:92) -- and return 0; return 1 if the window holds a word the model
+ *     does not know (the reference's OOV_SCORE, scorer.cpp:86-88); return < 0 to fail the decode.  Must be a pure function
+ *     of the words: answers are cached on the device ((history, word) -> log10 prob, the same tables the built-in scorer
+ *     queries inside the kernel) and each distinct window is asked for once per scorer.  Called on the thread that calls
+ *     the decode, between kernel launches: a launch runs until an utterance needs a window that is not cached, parks that
+ *     utterance at the frame boundary, and resumes after the host has asked.
+ *   vocabulary: the model's words (what Scorer::fill_dictionary reads from the model, scorer.cpp:196-230): builds the
+ *     dictionary of a word model; all entries single characters <=> character model (scorer.cpp:65-71).
+ *   Results equal those of a scorer that knew every answer from the start (tests/test_gpu_lm.py: the built-in tables behind
+ *   the callback give bit-identical output).  Accepted by ctcd_beam_decode_lm, ctcd_beam_decode_lm_host,
+ *   ctcd_beam_decode_to_host and ctcd_stream_create_lm / ctcd_stream_decode; ctcd_beam_decode_compact refuses it.
+ *   Not supported with it: rows that hold +-inf or overflow float32 sums (CTCD_EUNSUPPORTED).
+ * ctcd_scorer_cond_log10 evaluates any scorer in the callback's own form (so the built-in tables can sit behind one);
+ * ctcd_scorer_callback_calls counts the callback invocations so far (= distinct windows cached). */
+typedef int (*ctcd_cond_log10_fn)(void *user, const char *const *words, int n, float *log10_prob);
+int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, int max_order, const char *const *vocabulary,
+                                int n_vocabulary, ctcd_cond_log10_fn fn, void *user, const char *const *labels, int V, int device_id);
+int ctcd_scorer_cond_log10(const ctcd_scorer *scorer, const char *const *words, int n, float *log10_prob);
+long long ctcd_scorer_callback_calls(const ctcd_scorer *scorer);
+
 int ctcd_beam_decode_lm(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                         int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer,
                         int32_t *out_tokens, int32_t *out_timesteps, float *out_scores, int32_t *out_lens, int32_t *n_results,

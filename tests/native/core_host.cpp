@@ -5,6 +5,7 @@
 #define CTC_EXACT_MATH_HOST_TABLES
 #include "../../ctcdecode_amd/csrc/beam_core.h"
 #include "../../ctcdecode_amd/csrc/lm_build.h"
+#include "../../ctcdecode_amd/csrc/lm_callback.h"
 #include "../../ctcdecode_amd/csrc/compact_results.h"
 
 #include <algorithm>
@@ -288,6 +289,81 @@ extern "C" int ctccore_decode_lm_f32(const float *probs, const int32_t *seq_lens
   }
   return decode_impl(in, seq_lens, B, T, V, beam, num_threads, cutoff_prob, cutoff_top_n, blank_id, out_tokens, out_timesteps,
                      out_scores, out_lens, n_results, &view, probs, log_input);
+}
+
+// The host-side scorer hook (lm_callback.h) driven the way the product drives it: the decode runs against a CACHE of a
+// callback's answers; an utterance that asks for something the cache does not hold is parked in front of the frame it was in
+// (ST_NEED_HOST), the queued pairs are answered by the callback, and the utterance resumes from its parked state.  The
+// callback here asks the built-in ARPA tables (HostScorer::cond_log10) -- one implementation of the interface -- so the
+// results must equal ctccore_decode_lm_f32's bit for bit.  stats2: {callback calls, resumptions}.
+extern "C" int ctccore_decode_lm_cb_f32(const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, int blank_id, int log_input,
+                                        double alpha, double beta, const char *lm_path, const char *labels, int32_t *out_tokens,
+                                        int32_t *out_timesteps, float *out_scores, int32_t *out_lens, int32_t *n_results, long long *stats2) {
+  using namespace ctcbeam;
+  std::vector<std::string> lab(V);
+  for (int i = 0; i < V; ++i) { lab[i] = labels; labels += lab[i].size() + 1; }
+  ctclm::HostScorer ref;
+  if (!ref.build(alpha, beta, lm_path, lab)) return -100;
+  std::vector<std::string> vocabulary;
+  for (const std::string &w : ref.vocab)
+    if (w != "<unk>") vocabulary.push_back(w);
+  ctclm::CallbackLm cb;
+  auto fn = [](void *user, const char *const *words, int n, float *p10) -> int {
+    const ctclm::HostScorer *r = (const ctclm::HostScorer *)user;
+    std::vector<std::string> ws(words, words + n);
+    return r->cond_log10(ws, p10);
+  };
+  if (!cb.build(alpha, beta, ref.order, vocabulary, lab, fn, &ref)) return -101;
+  if (cb.hs.char_based != ref.char_based || cb.hs.dict_size != ref.dict_size) return -102;
+  std::vector<float> logp;
+  const float *in = probs;
+  if (!log_input) {
+    logp.resize((size_t)B * T * V);
+    for (size_t i = 0; i < logp.size(); ++i) logp[i] = (float)std::log((double)probs[i] + (double)std::numeric_limits<float>::min());
+    in = logp.data();
+  }
+  Dims d;
+  d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0; d.lm = 1;
+  Work w;
+  size_t far_bytes = 0;
+  std::vector<char> mem(carve<0>(w, nullptr, nullptr, d, &far_bytes) + 64);
+  std::vector<char> far(far_bytes + 64);
+  std::vector<uint32_t> miss(2 * 65536);
+  unsigned nmiss = 0;
+  long long resumes = 0;
+  const bool wordlm = !cb.hs.char_based && !cb.hs.dict_wide && !getenv("CTC_HOST_GENERAL_LM");
+  for (int b = 0; b < B; ++b) {
+    std::vector<int> hdr(SH_WORDS, 0), arrays((size_t)kStateArraysLm * beam, 0);
+    std::vector<PoolNode> pool((size_t)1 + (size_t)beam * T);
+    std::vector<int> pool_up(2 * pool.size());
+    int len = seq_lens ? seq_lens[b] : T;
+    len = std::max(0, std::min(len, T));
+    for (int guard = 0;; ++guard) {
+      if (guard > 4 * T + 64) return -103;  // (every resumption consumes a frame or answers a query: this cannot loop)
+      ctclm::LmView view = cb.hs.view();
+      view.cb = 1; view.cb_miss = miss.data(); view.cb_count = &nmiss; view.cb_cap = (uint32_t)(miss.size() / 2);
+      nmiss = 0;
+      const int done = hdr[SH_FRAMES];
+      carve<0>(w, mem.data(), far.data(), d, nullptr);
+      HostX x;
+      StreamState ss{hdr.data(), arrays.data(), 1};
+      const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, 0u};
+      const float *rows = in + ((size_t)b * T + done) * V, *raw = probs + ((size_t)b * T + done) * V;
+      int st;
+      if (wordlm) st = decode_utterance<true, false, true, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
+                                     (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss, &view, raw, log_input);
+      else st = decode_utterance<true, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
+                                     (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss, &view, raw, log_input);
+      if (st == ST_OK) break;
+      if (st != ST_NEED_HOST) return -st;
+      if (nmiss == 0 || nmiss > view.cb_cap) return -104;
+      for (unsigned i = 0; i < nmiss; ++i)
+        if (!cb.resolve(miss[2 * i], miss[2 * i + 1])) return -105;
+      ++resumes;
+    }
+  }
+  if (stats2) { stats2[0] = (long long)cb.queries; stats2[1] = resumes; }
+  return 1;
 }
 
 // Compact result delivery: decode every item into the compact form (one shared label buffer, bump-allocated), then expand

@@ -234,6 +234,29 @@ def decode_core_host_lm(probs, alpha, beta, lm_path, labels, seq_lens=None, beam
     return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres, meta=tuple(int(v) for v in meta))
 
 
+def decode_core_host_lm_cb(probs, alpha, beta, lm_path, labels, seq_lens=None, beam=100, blank_id=0, log_input=True):
+    """The host-side scorer hook on the host build of the core: the decode asks a CACHE of a callback's answers, parks an
+    utterance when the cache misses and resumes it once the callback (here: the built-in ARPA tables) has answered."""
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    B, T, V = probs.shape
+    if seq_lens is not None:
+        seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    tok = np.zeros((B, beam, T), np.int32)
+    ts = np.zeros((B, beam, T), np.int32)
+    sc = np.zeros((B, beam), np.float32)
+    ln = np.zeros((B, beam), np.int32)
+    nres = np.zeros((B,), np.int32)
+    stats = np.zeros((2,), np.int64)
+    lib = ctypes.CDLL(build_core_host())
+    rc = lib.ctccore_decode_lm_cb_f32(_ptr(probs, _f32p), _ptr(seq_lens, _i32p) if seq_lens is not None else None, B, T, V, beam, blank_id,
+                                      1 if log_input else 0, ctypes.c_double(alpha), ctypes.c_double(beta), lm_path.encode(), _pack(labels),
+                                      _ptr(tok, _i32p), _ptr(ts, _i32p), _ptr(sc, _f32p), _ptr(ln, _i32p), _ptr(nres, _i32p),
+                                      stats.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
+    if rc != 1:
+        raise RuntimeError("ctccore_decode_lm_cb_f32 failed: %d" % rc)
+    return dict(tokens=tok, timesteps=ts, scores=sc, lens=ln, nres=nres, callback_calls=int(stats[0]), resumptions=int(stats[1]))
+
+
 def decode_core_host_compact(probs, seq_lens=None, beam=100, blank_id=0):
     """The host build of the core writing COMPACT results, expanded by the product's host expansion (compact_results.h)."""
     probs = np.ascontiguousarray(probs, dtype=np.float32)

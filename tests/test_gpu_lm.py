@@ -252,3 +252,170 @@ def test_lm_host_pointer_entry_and_scorer_queries(torch_mod):
     assert got == ou.Scorer(0.0, 0.0, lm["lm_path"], lm["labels"], "restated").cond_logprob(["bad", "bad"])
     with pytest.raises(ValueError):
         n.check(n.lib.ctcd_scorer_create(ctypes.byref(sc), 0.0, 0.0, b"/nonexistent.arpa", labels, V, 0))
+
+
+# ---- the swappable scorer (include/ctcdecode_amd.h "The swappable scorer") -------------------------------
+def _arpa_words(path):
+    """The unigrams of an ARPA file (what Scorer::fill_dictionary reads from the model, scorer.cpp:196-230)."""
+    words, on = [], False
+    with open(path, encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith("\\"):
+                on = line == "\\1-grams:"
+                continue
+            if on and line:
+                words.append(line.split("\t")[1] if "\t" in line else line.split()[1])
+    return words
+
+
+class _BuiltinBehindCallback(object):
+    """The built-in ARPA tables as ONE implementation of the callback interface: cond_log10(words) asks ctcd_scorer_cond_log10 of a
+    scorer built the usual way.  A decode through the hook must then equal the built-in path -- and the reference fixtures -- bit for bit."""
+
+    def __init__(self, lm, device=0):
+        import ctcdecode_amd._native as n
+
+        self.n = n
+        self.labels = list(lm["labels"])
+        arr = (ctypes.c_char_p * len(self.labels))(*[x.encode("utf-8") for x in self.labels])
+        self.h = ctypes.c_void_p()
+        n.check(n.lib.ctcd_scorer_create(ctypes.byref(self.h), 0.0, 0.0, lm["lm_path"].encode(), arr, len(self.labels), device))
+        self.order = int(n.lib.ctcd_scorer_max_order(self.h))
+        self.vocabulary = _arpa_words(lm["lm_path"])
+        self.asked = []
+
+    def __call__(self, words):
+        self.asked.append(words)
+        arr = (ctypes.c_char_p * len(words))(*[w.encode("utf-8") for w in words])
+        p = ctypes.c_float()
+        rc = self.n.lib.ctcd_scorer_cond_log10(self.h, arr, len(words), ctypes.byref(p))
+        assert rc in (0, 1)
+        return None if rc else p.value
+
+    def close(self):
+        self.n.lib.ctcd_scorer_destroy(self.h)
+
+
+@pytest.mark.parametrize("name", gu.lm_names())
+def test_scorer_hook_reference_fixtures(torch_mod, name):
+    """Every committed LM fixture decoded through a CALLBACK scorer: decode() (host tensors) and decode_device() equal the
+    reference's outputs bit for bit; the callback is asked for each distinct window once (a second decode asks nothing)."""
+    import ctcdecode_amd
+
+    args, lm, want = gu.load_lm(name)
+    inner = _BuiltinBehindCallback(lm)
+    try:
+        sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, lm["labels"], alpha=lm["alpha"], beta=lm["beta"], device="cuda:0")
+        dec = ctcdecode_amd.CTCBeamDecoder(lm["labels"], scorer=sc, cutoff_top_n=args["cutoff_top_n"], cutoff_prob=args.get("cutoff_prob", 1.0),
+                                           beam_width=args["beam"], blank_id=args["blank_id"], log_probs_input=bool(args["log_input"]), device="cuda:0")
+        assert (int(dec.character_based()), dec.max_order(), dec.dict_size()) == lm["meta"]
+        x = torch_mod.from_numpy(np.ascontiguousarray(args["probs"]))
+        sl = torch_mod.from_numpy(args["seq_lens"]) if args.get("seq_lens") is not None else None
+        out, scs, ts, ln = dec.decode(x, sl)
+        got = dict(tokens=out.numpy(), timesteps=ts.numpy(), scores=scs.numpy(), lens=ln.numpy())
+        ou.assert_same(_with_nres(got, want), want, name + " through the hook")
+        calls = sc.callback_calls()
+        assert calls == len(inner.asked) > 0 and len(set(inner.asked)) == calls  # no window twice
+        assert all(len(w) == inner.order for w in inner.asked)
+        out2, scs2, ts2, ln2 = dec.decode_device(x, sl)  # warm cache: one launch, no callback
+        assert sc.callback_calls() == calls
+        got2 = dict(tokens=out2.cpu().numpy(), timesteps=ts2.cpu().numpy(), scores=scs2.cpu().numpy(), lens=ln2.cpu().numpy())
+        ou.assert_same(_with_nres(got2, want), want, name + " through the hook, warm")
+    finally:
+        inner.close()
+
+
+def test_scorer_hook_batch_with_pruning_and_streaming(torch_mod):
+    """A batch large enough that utterances park at different frames, with vocabulary pruning, against the built-in scorer; then
+    the same scorer behind OnlineCTCBeamDecoder (chunked) == one-shot."""
+    import ctcdecode_amd
+
+    lm = dict(labels=LABELS29, lm_path=TEST_ARPA)
+    B, T, V, K = 24, 90, 29, 32
+    lp = ou.synth_logprobs(B, T, V, 4242, blank_bias=1.0)
+    lp[:, :, LABELS29.index(" ")] += np.float32(1.5)
+    m = lp.max(-1, keepdims=True)
+    lp = (lp - (m + np.log(np.exp(lp - m).sum(-1, keepdims=True)))).astype(np.float32)
+    sl = np.random.default_rng(5).integers(0, T + 1, size=B).astype(np.int32)
+    x = torch_mod.from_numpy(lp)
+    inner = _BuiltinBehindCallback(lm)
+    try:
+        for topn, cp in ((V, 1.0), (12, 0.999)):
+            ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.7, beta=0.9, beam_width=K, cutoff_top_n=topn, cutoff_prob=cp,
+                                               log_probs_input=True)
+            want = [t.numpy() for t in ref.decode(x, torch_mod.from_numpy(sl))]
+            sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, LABELS29, alpha=0.7, beta=0.9)
+            dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc, beam_width=K, cutoff_top_n=topn, cutoff_prob=cp, log_probs_input=True)
+            got = [t.numpy() for t in dec.decode(x, torch_mod.from_numpy(sl))]
+            for g, w in zip(got, want):
+                assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), (topn, cp)
+            assert sc.callback_calls() > 0
+        # streaming: a fresh scorer (cold cache), chunk boundaries that split the parked frames
+        sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, LABELS29, alpha=0.7, beta=0.9)
+        ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.7, beta=0.9, beam_width=K, log_probs_input=True)
+        want = [t.numpy() for t in ref.decode(x[:6])]
+        dec = ctcdecode_amd.OnlineCTCBeamDecoder(LABELS29, scorer=sc, beam_width=K, log_probs_input=True)
+        states = [ctcdecode_amd.DecoderState(dec) for _ in range(6)]
+        bounds = [0, 7, 7, 40, T]
+        for i in range(len(bounds) - 1):
+            out, scs, ts, ln = dec.decode(x[:6, bounds[i]:bounds[i + 1]], states, [i == len(bounds) - 2] * 6)
+        assert np.array_equal(scs.numpy().view(np.uint32), want[1].view(np.uint32)) and np.array_equal(ln.numpy(), want[3])
+        L = out.shape[2]
+        assert np.array_equal(out.numpy(), want[0][:, : out.shape[1], :L]) and np.array_equal(ts.numpy(), want[2][:, : out.shape[1], :L])
+        assert sc.callback_calls() > 0
+    finally:
+        inner.close()
+
+
+def test_scorer_hook_callback_decides_vocabulary_and_errors_propagate(torch_mod):
+    """The callback -- not the tables -- decides what is out of vocabulary (None -> the reference's OOV_SCORE); an exception inside
+    it fails the decode and is re-raised; the compact entry point refuses a callback scorer."""
+    import ctcdecode_amd
+
+    labels = ["_", "a", "b", " "]
+    lp = ou.synth_logprobs(2, 30, 4, 9, blank_bias=0.5)
+    x = torch_mod.from_numpy(lp)
+
+    def uniform(words):  # "b..." words are unknown to this model
+        return None if any(w.startswith("b") for w in words) else -1.0
+
+    sc = ctcdecode_amd.CallbackScorer(uniform, ["a", "aa", "ab", "b", "ba"], 2, labels, alpha=1.0, beta=0.5)
+    dec = ctcdecode_amd.CTCBeamDecoder(labels, scorer=sc, beam_width=8, log_probs_input=True)
+    out, scs, ts, ln = dec.decode(x)
+    assert np.isfinite(scs.numpy()[:, 0]).all() and sc.callback_calls() > 0
+    # the same model as ARPA-free oracle arithmetic: every known window log10 p = -1, OOV windows -1000 (checked through the
+    # host build of the same core in tests/test_lm.py; here: determinism + the warm cache giving the same answer)
+    out2, scs2, _, _ = dec.decode(x)
+    assert np.array_equal(scs.numpy().view(np.uint32), scs2.numpy().view(np.uint32)) and np.array_equal(out.numpy(), out2.numpy())
+    with pytest.raises(NotImplementedError):
+        dec.decode_compact(x)
+
+    class Boom(Exception):
+        pass
+
+    def broken(words):
+        raise Boom("no model today")
+
+    sc2 = ctcdecode_amd.CallbackScorer(broken, ["a"], 2, labels)
+    dec2 = ctcdecode_amd.CTCBeamDecoder(labels, scorer=sc2, beam_width=8, log_probs_input=True)
+    with pytest.raises(Boom):
+        dec2.decode(x)
+    with pytest.raises(ValueError):
+        ctcdecode_amd.CTCBeamDecoder(labels, scorer=sc2, model_path=TEST_ARPA)
+
+
+def test_kenlm_scorer_matches_builtin_tables(torch_mod):
+    """KenlmScorer (the `kenlm` module behind the hook) against the built-in ARPA tables; needs the optional `kenlm` module."""
+    kenlm = pytest.importorskip("kenlm")  # noqa: F841
+    import ctcdecode_amd
+
+    lp = ou.synth_logprobs(4, 80, 29, 31, blank_bias=1.0)
+    x = torch_mod.from_numpy(lp)
+    ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.5, beta=1.0, beam_width=50, log_probs_input=True)
+    want = [t.numpy() for t in ref.decode(x)]
+    sc = ctcdecode_amd.KenlmScorer(TEST_ARPA, _arpa_words(TEST_ARPA), LABELS29, alpha=0.5, beta=1.0)
+    dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc, beam_width=50, log_probs_input=True)
+    got = [t.numpy() for t in dec.decode(x)]
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))

@@ -341,3 +341,36 @@ def test_reset_params_and_accessors():
     assert not np.array_equal(a["scores"], b["scores"])
     ch = ou.Scorer(0.5, 1.0, os.path.join(DATA, "chars.arpa"), ["_", "a", "b", "c", "d", "'", "é"], "restated")
     assert ch.is_character_based() and ch.dict_size() == 0
+
+
+# ---- the host-side scorer hook (ctcdecode_amd/csrc/lm_callback.h): the decode asks a CACHE of a callback's answers, parks an
+# utterance when the cache misses (ST_NEED_HOST) and resumes it once the callback has answered.  The callback used here asks the
+# built-in ARPA tables -- one implementation of the interface -- so the results must equal the fixtures bit for bit.
+@pytest.mark.parametrize("name", [n for n in gu.lm_names() if n not in ("abcd_topn",)])  # (the hook's host driver takes unpruned rows)
+def test_scorer_hook_matches_committed_lm_fixtures(name):
+    args, lm, want = gu.load_lm(name)
+    if args["cutoff_top_n"] < args["probs"].shape[2]:
+        pytest.skip("pruned fixture")
+    got = ou.decode_core_host_lm_cb(args["probs"], lm["alpha"], lm["beta"], lm["lm_path"], lm["labels"], seq_lens=args["seq_lens"], beam=args["beam"],
+                                    blank_id=args["blank_id"], log_input=args["log_input"])
+    ou.assert_same(got, want, name)
+    assert got["callback_calls"] > 0 and got["resumptions"] > 0
+
+
+def test_scorer_hook_random_sweep():
+    """Random word / character model configurations: callback path == built-in path of the same core (bit for bit), with far fewer
+    callback calls than queries (the cache) and every utterance resumed at least once."""
+    rng = np.random.default_rng(77)
+    labels = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
+    for it in range(24):
+        arpa = os.path.join(gu.DATA_DIR, ["test.arpa", "chars.arpa", "abcd_words.arpa"][it % 3])
+        labs = labels if it % 3 != 2 else ["_", " ", "a", "b", "c", "d"]
+        V = len(labs)
+        T = int(rng.integers(1, 70))
+        K = int(rng.choice([1, 3, 8, 20, 40]))
+        lp = ou.synth_logprobs(2, T, V, int(rng.integers(0, 1 << 30)), blank_bias=float(rng.choice([0.0, 2.0, 4.0])), quant=[None, 0.5, 1.0][it % 3])
+        sl = rng.integers(0, T + 2, size=2).astype(np.int32) if it % 4 == 0 else None
+        alpha, beta = float(rng.choice([0.0, 0.5, 1.3])), float(rng.choice([0.0, 1.0, -0.7]))
+        a = ou.decode_core_host_lm(lp, alpha, beta, arpa, labs, seq_lens=sl, beam=K, cutoff_top_n=V, threads=1)
+        b = ou.decode_core_host_lm_cb(lp, alpha, beta, arpa, labs, seq_lens=sl, beam=K)
+        ou.assert_same(b, a, "it %d %s" % (it, os.path.basename(arpa)))
