@@ -391,6 +391,11 @@ struct FullSyncView {
   CTC_HD void sync() { x.sync_full(); }
   CTC_HD int uni(int v) const { return x.uni(v); }
   CTC_HD void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) { x.block_scan_u32(mine, base_out, total_out); }
+  CTC_HD int lanes() const { return x.lanes(); }
+  CTC_HD auto ballot(bool p) const { return x.ballot(p); }
+  template <class M> CTC_HD int count(M m) const { return x.count(m); }
+  template <class M> CTC_HD int count_below(M m) const { return x.count_below(m); }
+  CTC_HD uint32_t first_lane(uint32_t v) const { return x.first_lane(v); }
 };
 
 // IDENT: the utterance is decoded without vocabulary pruning (candidate r of every frame is label r).  A compile-time
@@ -1178,7 +1183,8 @@ struct Decoder {
   // each.  Returns the cut.
   template <class XX>
   CTC_HD int hoare_round(XX &xx, Ek *v, int first, int last, LrT *Lp, LrT *Rp) {
-    return stlemu::hoare_round_parallel(xx, v, first, last, [](const Ek &e) { return EO::key(e); }, Lp, Rp, &w.vars[VAR_CUT]);
+    if (FARREP) return stlemu::hoare_round_parallel(xx, v, first, last, [](const Ek &e) { return EO::key(e); }, Lp, Rp, &w.vars[VAR_CUT]);
+    return stlemu::hoare_round_parallel_chunks(xx, v, first, last, [](const Ek &e) { return EO::key(e); }, Lp, Rp, &w.vars[VAR_CUT]);
   }
 
   // std::nth_element(begin, begin+K, end, prefix_compare) on the DFS-ordered candidate list (w.ek[0, N)).

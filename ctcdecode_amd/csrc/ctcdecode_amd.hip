@@ -533,6 +533,11 @@ __global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
 struct WgSortX {
   uint32_t *wsum;  // one word per wave (shared)
   // exclusive prefix (in thread order) and total of one word per thread; contains a barrier
+  __device__ __forceinline__ int lanes() const { return 64; }
+  __device__ __forceinline__ uint64_t ballot(bool p) const { return __builtin_amdgcn_ballot_w64(p); }
+  __device__ __forceinline__ int count(uint64_t m) const { return __builtin_popcountll(m); }
+  __device__ __forceinline__ int count_below(uint64_t m) const { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+  __device__ __forceinline__ uint32_t first_lane(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
   __device__ __forceinline__ void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) {
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
     uint32_t incl = mine;

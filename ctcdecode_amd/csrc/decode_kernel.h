@@ -695,6 +695,10 @@ struct DevX {
 
   // Exclusive prefix (in thread order) and total of one 32-bit value per thread; contains one barrier.  (Used with two
   // 16-bit counters packed into the word.)
+  // group operations of stl_emul.h hoare_round_parallel: a group is a wavefront
+  __device__ __forceinline__ int count(uint64_t m) const { return __builtin_popcountll(m); }
+  __device__ __forceinline__ int count_below(uint64_t m) const { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+  __device__ __forceinline__ uint32_t first_lane(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
   __device__ __forceinline__ void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) {
     const int t = (int)threadIdx.x, wave = t >> 6, nw = (nt() + 63) >> 6;
     const uint32_t incl = (uint32_t)wave_scan((int)mine, 0, [](int a, int b) { return a + b; });

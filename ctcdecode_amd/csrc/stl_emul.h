@@ -24,6 +24,15 @@
 #else
 #define STLEMU_HD inline
 #endif
+// The serial building blocks are real functions in device code (one copy per element type and comparator instead of one per
+// call site: the decode kernels carried 22 KB of inlined copies, a third of their code) -- they run on rare paths (the exact
+// replay of a tie at the beam's boundary, the final ordering of the results), one lane at a time, and take their array through
+// a generic pointer.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define STLEMU_FN __host__ __device__ __attribute__((noinline))
+#else
+#define STLEMU_FN STLEMU_HD
+#endif
 
 namespace stlemu {
 
@@ -77,7 +86,7 @@ STLEMU_HD int hoare_split(T *v, int lo, int hi, int piv, C before) {
 }
 
 template <class T, class C>
-STLEMU_HD int split_with_median_pivot(T *v, int first, int last, C before) {
+STLEMU_FN int split_with_median_pivot(T *v, int first, int last, C before) {
   int mid = first + (last - first) / 2;
   median_to(v, first, first + 1, mid, last - 1, before);
   return hoare_split(v, first + 1, last, first, before);
@@ -130,14 +139,14 @@ STLEMU_HD void pop_to(T *v, int first, int middle, int at, C before) {
 }
 
 template <class T, class C>
-STLEMU_HD void heap_select(T *v, int first, int middle, int last, C before) {
+STLEMU_FN void heap_select(T *v, int first, int middle, int last, C before) {
   heapify(v, first, middle, before);
   for (int i = middle; i < last; ++i)
     if (before(v[i], v[first])) pop_to(v, first, middle, i, before);
 }
 
 template <class T, class C>
-STLEMU_HD void heap_sort_down(T *v, int first, int last, C before) {
+STLEMU_FN void heap_sort_down(T *v, int first, int last, C before) {
   while (last - first > 1) {
     --last;
     pop_to(v, first, last, last, before);
@@ -145,7 +154,7 @@ STLEMU_HD void heap_sort_down(T *v, int first, int last, C before) {
 }
 
 template <class T, class C>
-STLEMU_HD void linear_insert_unguarded(T *v, int at, C before) {
+STLEMU_FN void linear_insert_unguarded(T *v, int at, C before) {
   T value = v[at];
   int prev = at - 1;
   while (before(value, v[prev])) {
@@ -157,7 +166,7 @@ STLEMU_HD void linear_insert_unguarded(T *v, int at, C before) {
 }
 
 template <class T, class C>
-STLEMU_HD void insertion_sort(T *v, int first, int last, C before) {
+STLEMU_FN void insertion_sort(T *v, int first, int last, C before) {
   if (first == last) return;
   for (int i = first + 1; i != last; ++i) {
     if (before(v[i], v[first])) {
@@ -301,11 +310,81 @@ STLEMU_HD void sort_parallel(X &x, T *v, int n, C before, I *cur, I *nxt, I *sma
 // Every thread counts, in its own stretch of the range, the stops of the two scans (left-to-right: elements not better
 // than the pivot; right-to-left: elements not worse); one prefix over the threads turns the counts into the stops' ranks;
 // the t-th stop from the left is exchanged with the t-th from the right until the scans cross -- the exchanges of the
-// serial loop.  X additionally provides block_scan_u32(mine, &exclusive_prefix, &total) (contains a barrier).
+// serial loop.  X additionally provides block_scan_u32(mine, &exclusive_prefix, &total) (contains a barrier) and the group
+// operations lanes(), ballot(bool) -> mask, count(mask), count_below(mask) (set bits of the lanes below the caller's),
+// first_lane(v) (the value the group's first lane holds).
 // Lp, Rp: scratch for last - first + 1 positions each (P = uint16_t: n < 65536, the two counts travel in one scanned
 // word; P = uint32_t: any n, two scans); *cutvar: one shared word.  Returns the cut.
 template <class X, class T, class KeyOf, class P>
 STLEMU_HD int hoare_round_parallel(X &x, T *v, int first, int last, KeyOf key_of, P *Lp, P *Rp, int *cutvar) {
+  const int tid = x.tid(), nt = x.nt();
+  constexpr bool wide = sizeof(P) > 2;
+  auto before = [&](const T &a, const T &b) { return key_of(a) > key_of(b); };
+  if (tid == 0) median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
+  x.sync();
+  const int lo = first + 1, m = last - lo;
+  const auto kp = key_of(v[first]);
+  // The range is cut into one stretch per GROUP of x.lanes() threads (a wavefront on the GPU, a single thread on the host),
+  // the lanes of a group taking neighbouring elements: the group's loads are contiguous (the array is in HBM for the first
+  // rounds of a wide beam) and a stop's rank within the stretch is a ballot + a count of the lanes below.
+  const int W = x.lanes(), lane = tid % W, grp = tid / W, ng = nt / W;
+  const int per = ((m + ng - 1) / ng + W - 1) / W * W;  // stretch length: a multiple of the group width
+  const int g0 = grp * per < m ? grp * per : m, g1 = g0 + per < m ? g0 + per : m;
+  uint32_t mineL = 0, mineR = 0;  // #left stops, #right stops of this group's stretch (identical in its lanes)
+  for (int i = g0; i < g1; i += W) {
+    const bool in = i + lane < g1;
+    const auto k = in ? key_of(v[lo + i + lane]) : kp;
+    mineL += (uint32_t)x.count(x.ballot(in && k <= kp));
+    mineR += (uint32_t)x.count(x.ballot(in && k >= kp));
+  }
+  uint32_t runL, runR;
+  int nL, nR;
+  if (wide) {
+    uint32_t totL, totR;
+    x.block_scan_u32(lane == 0 ? mineL : 0u, &runL, &totL);
+    x.block_scan_u32(lane == 0 ? mineR : 0u, &runR, &totR);
+    nL = (int)totL; nR = (int)totR;
+  } else {
+    uint32_t run, tot;
+    x.block_scan_u32(lane == 0 ? (mineL | (mineR << 16)) : 0u, &run, &tot);
+    runL = run & 0xFFFFu; runR = run >> 16;
+    nL = (int)(tot & 0xFFFFu); nR = (int)(tot >> 16);
+  }
+  runL = x.first_lane(runL); runR = x.first_lane(runR);  // (the group's base: the exclusive prefix its first lane received)
+  for (int i = g0; i < g1; i += W) {
+    const bool in = i + lane < g1;
+    const auto k = in ? key_of(v[lo + i + lane]) : kp;
+    const bool isL = in && k <= kp, isR = in && k >= kp;
+    const auto bl = x.ballot(isL), br = x.ballot(isR);
+    if (isL) Lp[runL + (uint32_t)x.count_below(bl)] = (P)(lo + i + lane);
+    if (isR) Rp[nR - 1 - (int)(runR + (uint32_t)x.count_below(br))] = (P)(lo + i + lane);
+    runL += (uint32_t)x.count(bl);
+    runR += (uint32_t)x.count(br);
+  }
+  if (tid == 0) Rp[nR] = (P)first;  // the pivot itself stops the right-to-left scan
+  x.sync();
+  // Iteration t of the serial loop stops its left scan at min(Lp[t], Rp[t-1]) (the element swapped into Rp[t-1] is itself
+  // a stop) and ends, returning that position, as soon as it is not left of the right scan's stop.
+  const int tmax = nL < nR + 1 ? nL : nR + 1;
+  auto crossed = [&](int t) { return t >= nL || t > nR || Lp[t] >= Rp[t]; };
+  for (int t = tid; t <= tmax; t += nt) {
+    if (!crossed(t)) {
+      exch(v, (int)Lp[t], (int)Rp[t]);
+    } else if (t == 0 || !crossed(t - 1)) {
+      int c = t < nL ? (int)Lp[t] : 0x7fffffff;
+      if (t > 0 && (int)Rp[t - 1] < c) c = (int)Rp[t - 1];
+      *cutvar = c;
+    }
+  }
+  x.sync();
+  return x.uni(*cutvar);
+}
+
+// The same step with one contiguous chunk per THREAD (no group operations): the form for arrays in LDS that are a few
+// elements per thread long -- measured: at 3 000 elements the ballots of the group form cost more than its neighbouring
+// loads save (the north-star kernel's frame 3.7 % longer), at 15 000 elements in HBM the group form wins (wide beam -6 %).
+template <class X, class T, class KeyOf, class P>
+STLEMU_HD int hoare_round_parallel_chunks(X &x, T *v, int first, int last, KeyOf key_of, P *Lp, P *Rp, int *cutvar) {
   const int tid = x.tid(), nt = x.nt();
   constexpr bool wide = sizeof(P) > 2;
   auto before = [&](const T &a, const T &b) { return key_of(a) > key_of(b); };

@@ -174,6 +174,9 @@ struct HostX {
       if (pred(s)) emit(k++, s);
   }
   void block_scan_u32(uint32_t mine, uint32_t *base_out, uint32_t *total_out) { *base_out = 0; *total_out = mine; }
+  int count(unsigned long long m) const { return (int)m; }
+  int count_below(unsigned long long) const { return 0; }
+  uint32_t first_lane(uint32_t v) const { return v; }
   void wave_max_to(int *p, uint32_t v) { *p = (int)std::max((uint32_t)*p, v); }
   void wave_min_to(int *p, uint32_t v) { *p = (int)std::min((uint32_t)*p, v); }
   unsigned global_add(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }

@@ -75,6 +75,11 @@ static void check_all(const std::vector<int> &key, std::mt19937 &g) {
       int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
       int uni(int v) const { return v; }
       void block_scan_u32(uint32_t mine, uint32_t *base, uint32_t *total) { *base = 0; *total = mine; }
+      int lanes() const { return 1; }
+      uint32_t ballot(bool p) const { return p ? 1u : 0u; }
+      int count(uint32_t m) const { return (int)m; }
+      int count_below(uint32_t) const { return 0; }
+      uint32_t first_lane(uint32_t v) const { return v; }
     } sx2;
     for (int rep = 0; rep < 3; ++rep) {
       const int limit = rep == 0 ? n : rep == 1 ? std::min(n, 40) : 1 + (int)(g() % n);
