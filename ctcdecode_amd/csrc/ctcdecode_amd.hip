@@ -1286,6 +1286,11 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
   if (!scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel)
     fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, 2> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>;
+#elif defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 3
+  // Workgroup-size sweep (tools/build_variants.sh nt512:CTC_QUICK_BUILD=3,CTC_QUICK_NT=512; raw_multi.py --threads 512)
+  if (big || !fixed || pruned_mode || scorer || occ2 || threads != CTC_QUICK_NT || d->profile)
+    return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD=3: only the fixed-layout, no-prune, no-LM kernel with CTC_QUICK_NT threads was compiled (ctcd_set_threads)");
+  fn = (const void *)ctc_beam_decode_kernel<0, 0, 1, false, CTC_QUICK_NT>;
 #elif defined(CTC_QUICK_BUILD)
   // Experiment builds (tools/build_variants.sh, seconds instead of minutes): only the north-star class kernel and its
   // barrier-timeline twin exist; everything else is refused.

@@ -876,6 +876,8 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #define CTC_KERNEL_GROUPS 12
 #if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2  // experiment builds of the LM tier: its north-star class kernel and the timeline twin
 #define CTC_KERNEL_LIST(X) X(0, 0, 1, false, 1024, 2, false, 0) X(2, 0, 1, false, 1024, 2, false, 1) X(0, 0, 1, false, 1024, true, false, 1) X(2, 0, 1, false, 1024, true, false, 0)
+#elif defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 3  // workgroup-size sweep: the north-star class kernel with CTC_QUICK_NT threads folded in
+#define CTC_KERNEL_LIST(X) X(0, 0, 1, false, CTC_QUICK_NT, false, false, 0)
 #elif defined(CTC_QUICK_BUILD)  // experiment builds: the north-star class kernels and the barrier-timeline twin only
 #define CTC_KERNEL_LIST(X) \
   X(0, 0, 1, false, 1024, false, false, 0) X(2, 0, 1, false, 1024, false, false, 1) X(0, 0, 1, false, 1024, false, true, 1)

@@ -17,6 +17,9 @@ if "--lm" in args:
     i = args.index("--lm"); lm_path = args[i + 1]; del args[i:i + 2]
 if "--cu-sharing" in args:
     i = args.index("--cu-sharing"); cu_sharing = int(args[i + 1]); del args[i:i + 2]
+threads = 0  # --threads N: ctcd_set_threads (the workgroup-size sweep's builds hold one size each: CTC_QUICK_BUILD=3)
+if "--threads" in args:
+    i = args.index("--threads"); threads = [int(v) for v in args[i + 1].split(",")]; del args[i:i + 2]
 kind = "randn"  # --kind randn | blank (+6 on the blank logit) | peaky (one label +8 per frame, in runs of 5-15 frames)
 if "--kind" in args:
     i = args.index("--kind"); kind = args[i + 1]; del args[i:i + 2]
@@ -44,6 +47,9 @@ for p in paths:
     assert lib.ctcd_create(ctypes.byref(h), 0) == 0
     lib.ctcd_set_timing.argtypes = [P, I]
     lib.ctcd_set_timing(h, 1)
+    if threads:  # one size for all builds, or one per build
+        lib.ctcd_set_threads.argtypes = [P, I]
+        assert lib.ctcd_set_threads(h, threads[len(libs)] if len(threads) > 1 else threads[0]) == 0
     if cu_sharing is not None:
         lib.ctcd_set_cu_sharing.argtypes = [P, I]
         assert lib.ctcd_set_cu_sharing(h, cu_sharing) == 0
