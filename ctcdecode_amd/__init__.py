@@ -470,9 +470,13 @@ class OnlineCTCBeamDecoder(object):
         """Test hook (as CTCBeamDecoder.set_threads): threads per workgroup, 0 = the library's choice."""
         _native.check(_native.lib.ctcd_set_threads(self._handle, int(n)))
 
-    def decode(self, probs, states, is_eos_s, seq_lens=None):
+    def decode(self, probs, states, is_eos_s, seq_lens=None, check=True):
         """Same contract as ctcdecode/__init__.py:189-238: returns CPU tensors (beam_results[B, R, L], beam_scores[B, K],
-        timesteps[B, R, L], out_lens[B, K]) with R = most results of any item that ended (0 if none), L = longest beam."""
+        timesteps[B, R, L], out_lens[B, K]) with R = most results of any item that ended (0 if none), L = longest beam.
+
+        ``check=False`` (extension): a call in which no stream ends returns as soon as the chunk's kernel is queued on the
+        current stream instead of waiting for its status words -- a serving loop feeds chunk after chunk without a host
+        synchronisation in between; a failure surfaces at the next checked call (every call that ends a stream is one)."""
         if probs.dim() != 3:
             raise ValueError("probs must be [batch, time, labels]")
         B, T, V = probs.shape
@@ -514,7 +518,8 @@ class OnlineCTCBeamDecoder(object):
                 self._handle, ptrs, eos, probs.data_ptr(), lens_cpu.data_ptr() if lens_cpu is not None else None, B, T, V, K, self._num_processes,
                 float(self._cutoff_prob), int(self._cutoff_top_n), int(self._blank_id), self._log_probs,
                 output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), nres.data_ptr(), out_T, stream))
-            _native.check(_native.lib.ctcd_check_status(self._handle, B))
+            if check or any_eos:
+                _native.check(_native.lib.ctcd_check_status(self._handle, B))
         if not any_eos:  # nothing ended: no results (binding.cpp:186-205 sizes them to the most results of any item: none)
             return (torch.zeros((B, 0, 0), dtype=torch.int32), torch.zeros((B, K), dtype=torch.float32),
                     torch.zeros((B, 0, 0), dtype=torch.int32), torch.zeros((B, K), dtype=torch.int32))

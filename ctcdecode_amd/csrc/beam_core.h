@@ -1406,7 +1406,11 @@ struct Decoder {
     // ---- B: score every candidate, lay it out in DFS (Euler-tour) slot order and count it into the select histogram.
     // B1 (beam entries themselves + revived children) and B2 (brand-new children) are independent: with enough
     // waves they run side by side on disjoint threads.
-    const int n1 = (SMALLV && x.nt_is(1024)) ? kSmallK : (n + 63) & ~63;  // (fixed-layout class: two entry waves, a compile-time split)
+    // (fixed-layout class: two entry waves, a compile-time split.  Wider beams: two entry waves as well, taking the entries in
+    //  several rounds -- the children's part is the longer one, an entry round costs 0.7 us, a round of children 0.25 us on
+    //  fourteen waves: at beam 500 eight entry waves left the children 32 rounds on the other eight, 44.4 -> 42.8 ms per batch;
+    //  four entry waves 43.3, one 44.8)
+    const int n1 = (SMALLV && x.nt_is(1024)) ? kSmallK : ((n + 63) & ~63) > 128 ? 128 : (n + 63) & ~63;
     const bool split = nt - n1 >= 128;
     if (!split || tid < n1) {
 #if defined(CTC_EXP_B1_PRIO)
