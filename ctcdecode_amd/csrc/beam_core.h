@@ -180,7 +180,8 @@ constexpr int kExpress = 32;
 // how often a frame takes the paths that are rare on random input and common on beams shaped by a dictionary or by
 // peaky acoustic posteriors.
 enum Event { EV_FRAMES, EV_CANDIDATES, EV_EXACT, EV_INTERNAL, EV_PINNED, EV_LPC_UPDATE, EV_DEAD_PARENT, EV_REVIVE_CAND, EV_REVIVED, EV_WALK,
-             EV_WALK_HOPS, EV_FAST_SELECT, EV_SINGLE_KEY, EV_BUCKET_KEYS, EV_SPEC_OK, EV_SPEC_UNDER, EV_SPEC_OVER, EV_SPEC_OTHER, EV_SPEC_HOT, EV_COUNT };
+             EV_WALK_HOPS, EV_FAST_SELECT, EV_SINGLE_KEY, EV_BUCKET_KEYS, EV_SPEC_OK, EV_SPEC_UNDER, EV_SPEC_OVER, EV_SPEC_OTHER, EV_SPEC_HOT,
+             EV_SLOW_BELOW, EV_SLOW_CROWDED, EV_SLOW_SINGLE, EV_SLOW_ROUNDS, EV_TIE_FRAMES, EV_TIE_KEYS, EV_TIE_BIG, EV_TIE_UNSETTLED, EV_COUNT };
 
 struct Work {
   // The beam is double-buffered: step t reads the copy of parity p and writes the other one.  cur / nxt are re-derived
@@ -1091,19 +1092,22 @@ struct Decoder {
       const int bstar = fb[0], above = fb[1], total = fb[2], inb = fb[3];
       uint64_t blo = 0, bhi = 0;
       bool again = true;
+      if (tid == 0) x.count(EV_SLOW_ROUNDS, 1);
       if (bstar < 0) {  // the K-th key lies below the window: look at everything under it
+        if (tid == 0) x.count(EV_SLOW_BELOW, 1);
         gbase += total; need -= total; hi = lo; lo = 1;
       } else {
         blo = lo + ((uint64_t)bstar << shift);
         bhi = (bstar == kBins - 1) ? hi : blo + ((uint64_t)1 << shift);
         if (bhi > hi) bhi = hi;  // keys at or above hi are already counted in gbase
         if (shift == 0 && bstar < kBins - 1) {  // the bucket is a single key value
+          if (tid == 0) x.count(EV_SLOW_SINGLE, 1);
           if (tid == 0) { w.vars[VAR_TAU] = (int)(uint32_t)blo; w.vars[VAR_G] = gbase + above; w.vars[VAR_E] = inb; }
           x.sync();
           return false;
         }
         if (inb <= kListCap) again = false;
-        else { gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
+        else { if (tid == 0) x.count(EV_SLOW_CROWDED, 1); gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
       }
       if (!again) {  // exact rank inside the bucket, on offsets from its base
         rank_bucket<true>(S, pv, (uint32_t)blo, (uint32_t)(bhi - blo - 1), first, need - above, gbase + above, inb);
@@ -1651,9 +1655,18 @@ struct Decoder {
       tau = (uint32_t)tv[0];
       const int E = tv[2], m = K - tv[1];
       if (CTC_RARE(E > m)) {
+        if (tid == 0) { x.count(EV_TIE_FRAMES, 1); x.count(EV_TIE_KEYS, E); if (E > kListCap) x.count(EV_TIE_BIG, 1); }
         have_bitmap = false;
         if (resolve_by_character(S, tau, m, E, pv, &lz)) tauc = (uint32_t)x.uni(w.vars[VAR_TAUC]);
         else exact = true;  // the boundary splits a group of equivalent prefixes
+      } else if (!SMALLV && !have_bitmap) {
+        // Wide beams: the select left its fast path (at beam 500 on random rows one frame in four: a key value near the K-th is
+        // shared by more candidates than the bucket list holds -- equal scores are inherited by the children of equal prefixes)
+        // and knows tau without having marked the survivors.  One pass that only writes the survivor bitmap, then the same
+        // parallel expansion as the fast path, instead of an ordered compaction of all S slots.
+        x.mark_ge(S, w.skey, tau, w.bitmap);
+        x.sync();
+        have_bitmap = true;
       }
 #ifdef CTC_EXP_ALWAYS_EXACT  // (measurement builds: the cost of one exact replay = the change of the frame time)
       exact = true;

@@ -1314,10 +1314,14 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (!d->profile && fixed && !big && threads == 1024)  // the usual case: workgroup size folded into the code
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
   if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, false, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
-  if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes only
-    if (big || !fixed || pruned_mode) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels, no pruning");
+  if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes and for the first wide-beam layout
     if (threads != 1024) return fail(CTCD_EUNSUPPORTED, "barrier timeline: 1024 threads per workgroup (the product configuration)");
-    fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024>;
+    if (big && far_level == 1 && !pruned_mode) {
+      fn = (const void *)ctc_beam_decode_kernel<2, 1, 0, false, 1024>;  // (a quarter of the stamps: its LDS is nearly full)
+    } else {
+      if (big || !fixed || pruned_mode) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128 and <= 32 labels, or the first wide-beam layout; no pruning");
+      fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024>;
+    }
   }
 #undef CTC_PICK
   if (scorer) {

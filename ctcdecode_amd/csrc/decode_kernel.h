@@ -537,6 +537,17 @@ struct DevX {
       else list_group<1, false>(S, skey, s0, b32, bspan, direct, bmw, list, lslot, lcount);
     }
   }
+  // bit s of the bitmap = (skey[s] >= tau), for every word that covers [0, S): one ballot per 64 slots
+  __device__ __forceinline__ void mark_ge(int S, const uint32_t *skey, uint32_t tau, uint32_t *bitmap) {
+    const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    for (int s0 = wave * 64; s0 < S; s0 += nw * 64) {
+      const int s = s0 + lane;
+      const uint32_t k = s < S ? skey[s] : 0u;
+      const unsigned long long m = CTC_BALLOT(k >= tau);
+      if (lane == 0) { bitmap[2 * (s0 >> 6)] = (uint32_t)m; bitmap[2 * (s0 >> 6) + 1] = (uint32_t)(m >> 32); }
+    }
+  }
   // out[r] = s for the r-th set bit s of the bitmap (ascending); one wave, the others wait at the closing barrier.
   // CLUSTERED: the set bits come in long runs (the LM tier: a dictionary-constrained beam keeps the children of few
   // parents) -- one lane per BYTE of the bitmap on as many waves as that takes, instead of one lane per 64-bit word on
@@ -810,7 +821,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   if (LAYOUT == 1) carve<0, OCC2>(w, smem, a.far + (size_t)b * a.far_stride, fixed_layout_dims(LM != 0), nullptr);
   else carve<BIG>(w, smem, a.far + (size_t)b * a.far_stride, a.dims, nullptr);
   __shared__ long long prof[16];
-  constexpr int kTlCap = LM ? kTimelineCap / 2 : kTimelineCap;  // (the LM tier's workspace leaves 8 KB for the stamps)
+  constexpr int kTlCap = (LM || BIG) ? kTimelineCap / 2 : kTimelineCap;  // (the LM tier's and the wide-beam layout's workspaces leave 8 KB for the stamps)
   __shared__ long long tlbuf[PROF == 2 ? 16 * kTlCap : 1];
   __shared__ int tlcnt[16];
   if (PROF == 2 && threadIdx.x < 16) tlcnt[threadIdx.x] = kTlCap;
@@ -894,7 +905,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(0, 0, 1, false, 1024, false, true, 0) X(0, 0, 1, true, 1024, false, true, 1) X(0, 0, 1, false, 1024, true, true, 10) X(0, 0, 1, true, 1024, true, true, 11) \
   X(0, 1, 0, false, 0, true, false, 6) X(0, 1, 0, true, 0, true, false, 7) X(0, 2, 0, false, 0, true, false, 8) X(0, 2, 0, true, 0, true, false, 9) \
   X(0, 3, 0, false, 0, false, false, 5) X(0, 3, 0, true, 0, false, false, 4) X(0, 3, 0, false, 0, true, false, 6) X(0, 3, 0, true, 0, true, false, 7) \
-  X(0, 1, 0, false, 1024, false, false, 9) X(0, 1, 0, true, 1024, false, false, 10)
+  X(0, 1, 0, false, 1024, false, false, 9) X(0, 1, 0, true, 1024, false, false, 10) X(2, 1, 0, false, 1024, false, false, 11)
 #endif
 
 }  // namespace ctcdk

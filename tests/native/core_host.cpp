@@ -112,6 +112,11 @@ struct HostX {
   }
   int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
   void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
+  void mark_ge(int S, const uint32_t *skey, uint32_t tau, uint32_t *bitmap) {
+    for (int wd = 0; wd < 2 * ((S + 63) / 64); ++wd) bitmap[wd] = 0u;
+    for (int s = 0; s < S; ++s)
+      if (skey[s] >= tau) bitmap[s >> 5] |= 1u << (s & 31);
+  }
   uint32_t bitsel(uint32_t mask, uint32_t a, uint32_t b) const { return (a & mask) | (b & ~mask); }
   int sum8(int v) const { return v; }
   int sum4(int v) const { return v; }

@@ -75,7 +75,7 @@ def main():
         cap = _native.lib.ctcd_debug_timeline_cap()
         buf = np.zeros((16, cap), np.int64)
         _native.check(_native.lib.ctcd_debug_timeline(dec._handle, 0, 0, buf.ctypes.data_as(ctypes.c_void_p)))
-        if a.lm:  # the LM build of the timeline kernel records half as many stamps per wave
+        if a.lm or a.beam > 128:  # the LM build of the timeline kernel records half as many stamps per wave, the wide-beam build too
             cap //= 2
             buf = buf.reshape(-1)[:16 * cap].reshape(16, cap)
         nw = int((buf[:, 0] != 0).sum())

@@ -18,7 +18,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 NAMES = ["frames", "candidates", "exact replays", "entries with in-beam descendants", "entries whose parent is in the beam",
          "pool updates of a label probability", "entries below a dead interior node", "revival candidates", "revived nodes that survive",
          "pool walks", "hops of those walks", "selects on the fast path", "... whose bucket holds a single key", "keys in the K-th key's bucket",
-         "speculative select: settled the frame", "... too few hot keys", "... too many hot keys", "... handed back (ties, last frame, danger mode)", "hot keys"]
+         "speculative select: settled the frame", "... too few hot keys", "... too many hot keys", "... handed back (ties, last frame, danger mode)", "hot keys",
+         "histogram select: K-th key below the window", "... crowded bucket (more than 128 keys), another round", "... ended on a single key value", "... rounds of the slow path",
+         "frames with several candidates on the K-th score", "... such candidates", "... more than 128 of them", "(unused)"]
 
 
 def main():
