@@ -51,7 +51,10 @@ def test_online_signature_mirrors_reference():
     sig = inspect.signature(ctcdecode_amd.OnlineCTCBeamDecoder.__init__)
     assert list(sig.parameters)[1:11] == ["labels", "model_path", "alpha", "beta", "cutoff_top_n", "cutoff_prob", "beam_width", "num_processes", "blank_id", "log_probs_input"]
     # ctcdecode/__init__.py:189
-    assert list(inspect.signature(ctcdecode_amd.OnlineCTCBeamDecoder.decode).parameters) == ["self", "probs", "states", "is_eos_s", "seq_lens"]
+    dsig = inspect.signature(ctcdecode_amd.OnlineCTCBeamDecoder.decode)
+    assert list(dsig.parameters)[:5] == ["self", "probs", "states", "is_eos_s", "seq_lens"]
+    # (extensions come after the reference's parameters and have defaults that keep the reference's behaviour: check=True)
+    assert all(p.default is not inspect._empty for p in list(dsig.parameters.values())[5:]) and dsig.parameters["check"].default is True
     assert list(inspect.signature(ctcdecode_amd.DecoderState.__init__).parameters) == ["self", "decoder"]
 
 
