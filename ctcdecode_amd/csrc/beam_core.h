@@ -419,7 +419,7 @@ struct FullSyncView {
 // (info_of_slot); the rare paths that look at every slot (ties at the K boundary, exact replay) first rebuild all of them
 // (fill_info).  Round 2 wrote S info words per frame to HBM: 30 GB per configs[2] launch, 18x the algorithmic bytes.
 // FARREP: the exact replay's scratch lives in HBM (carve).  HUGE: more than 65535 candidate slots (carve BIG == 3).
-template <class X, bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, bool WORDLM = false>
+template <class X, bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, bool WORDLM = false, bool CB = false>
 struct Decoder {
   using EO = EkOps<HUGE>;
   using Ek = typename EO::E;
@@ -447,7 +447,6 @@ struct Decoder {
       lm_char_v = lm->char_based != 0; lm_wide_v = lm->dict_wide != 0; lm_space = lm->space_id;
       lm_alpha = lm->alpha; lm_beta = lm->beta;
       lm_dict = lm->dict;
-      lm_cb = lm->cb != 0;
     }
   }
   CTC_HD int node_tstep(const PoolNode &pn, int id) const { return (int)(pn.cht >> 16) | (CTC_RARE(long_t) ? pool_thi[id] << 16 : 0); }
@@ -546,7 +545,10 @@ struct Decoder {
   int lm_space = -1;
   double lm_alpha = 0.0, lm_beta = 0.0;
   const ctclm::DictNode *lm_dict = nullptr;
-  bool lm_cb = false;  // host-side scorer hook: the tables are a cache of a host callback's answers (lm_tables.h LmView::cb)
+  // Host-side scorer hook: the tables are a cache of a host callback's answers (lm_tables.h LmView::cb).  A compile-time switch
+  // (CB): as a run-time flag the hook's checks and the state they keep alive cost the built-in scorer's kernels 11 % per frame
+  // (12.36 against 11.16 ms at the configs[4] shape); callback scorers get instantiations of their own.
+  static constexpr bool lm_cb = LM && CB;
   // get_log_cond_prob through the tables.  With a callback scorer a value that is not cached yet comes back as NaN: the pair
   // is queued for the host, the frame is marked (it will not be committed: step() / finish() return ST_NEED_HOST) and the
   // caller's state is left where it was; a cached "out of vocabulary" answer (-inf) becomes the reference's OOV_SCORE.
@@ -2159,13 +2161,13 @@ struct PrunedRows {
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
 // LM tier: `lm` = the scorer's tables, `raw` = the caller's own [len, V] rows (log-probabilities or probabilities,
 // `raw_log` says which): ctc_beam_search_decoder.cpp:78 takes the blank's log-probability from them directly.
-template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, bool WORDLM = false, class X>
+template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, bool WORDLM = false, bool CB = false, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr, const ctclm::LmView *lm = nullptr, const float *raw = nullptr,
                             int raw_log = 1, const int *frames_ready = nullptr) {
   if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
-  using Dec0 = Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE, WORDLM>;
+  using Dec0 = Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE, WORDLM, CB>;
   Dec0 dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
@@ -2223,7 +2225,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
     // danger mode looks one row ahead: row t + 1 is examined while frame t is decoded (row 0 where it is loaded)
     int next_cnt = 0;  // threads below it hold a value of row t + 1 in next_val
     float next_val = 0.f;
-    using Dec = Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE, WORDLM>;
+    using Dec = Dec0;
     if (IDENT) {
       in.Vc = d.V;
       in.identity = 1;

@@ -1056,7 +1056,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout && (!scorer || threads == 1024);
   const Dims ldims = fixed ? fixed_layout_dims(scorer != nullptr) : dims;
   // two workgroups per CU (OCC2 build of the fixed-layout kernel): batches that outnumber the CUs, or on request
-  const bool occ2 = fixed && threads == 1024 && !d->profile && (d->cu_sharing == 1 || (d->cu_sharing < 0 && B > d->cu_count));
+  const bool hooked = scorer && scorer->cbl;  // a callback scorer: its own kernel instantiations (beam_core.h CB)
+  const bool occ2 = fixed && threads == 1024 && !d->profile && !hooked && (d->cu_sharing == 1 || (d->cu_sharing < 0 && B > d->cu_count));
   size_t lds = occ2 ? carve<0, true>(wtmp, nullptr, nullptr, ldims, &far_bytes) : carve<0>(wtmp, nullptr, nullptr, ldims, &far_bytes);
   bool big = false;
   int far_level = 1;
@@ -1339,6 +1340,12 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     if (big && far_level == 3) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 3, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 3, 0, false, 0, true>;
     else if (big) fn = far_level == 2 ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false, 0, true>)
                                  : (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 1, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 1, 0, false, 0, true>);
+    if (hooked) {
+      if (big) return fail(CTCD_EUNSUPPORTED, "a callback scorer with a beam this wide (its kernels exist for the layouts that keep the whole workspace in LDS)");
+      if (d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the scorer hook");
+      fn = fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, 3> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 3>)
+                 : (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 0, true, 0, 3> : (const void *)ctc_beam_decode_kernel<0, 0, 0, false, 0, 3>);
+    }
     if (d->profile && d->tl_armed) {  // (shape conditions checked above)
       if (!fixed) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels");
       fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true>;

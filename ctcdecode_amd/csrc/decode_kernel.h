@@ -808,7 +808,8 @@ __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <=
 // (fewer registers, replay rounds in HBM), two per CU together 1.4-1.5x faster: the library launches this build for
 // batches that outnumber the CUs and when the caller keeps several launches in flight (ctcd_set_cu_sharing).
 // LM: 0 = no scorer, 1 = any scorer, 2 = word model over at most 64 labels (the character-model and wide-dictionary
-// branches are not compiled in: beam_core.h WORDLM).
+// branches are not compiled in: beam_core.h WORDLM), 3 = any scorer behind the host-side hook (beam_core.h CB: the tables are a
+// cache of a callback's answers; a miss parks the utterance).
 template <int PROF, int BIG, int LAYOUT, bool PRUNED, int NT = 0, int LM = 0, bool OCC2 = false>
 __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -867,7 +868,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #else
   if (LM) lmv = &a.lm;
 #endif
-  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
+  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2, LM == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + ((size_t)b * a.T + f0) * a.V : nullptr, a.raw_log,
                                   PRUNED ? (const int *)nullptr : a.frames_ready);
@@ -905,7 +906,8 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(0, 0, 1, false, 1024, false, true, 0) X(0, 0, 1, true, 1024, false, true, 1) X(0, 0, 1, false, 1024, true, true, 10) X(0, 0, 1, true, 1024, true, true, 11) \
   X(0, 1, 0, false, 0, true, false, 6) X(0, 1, 0, true, 0, true, false, 7) X(0, 2, 0, false, 0, true, false, 8) X(0, 2, 0, true, 0, true, false, 9) \
   X(0, 3, 0, false, 0, false, false, 5) X(0, 3, 0, true, 0, false, false, 4) X(0, 3, 0, false, 0, true, false, 6) X(0, 3, 0, true, 0, true, false, 7) \
-  X(0, 1, 0, false, 1024, false, false, 9) X(0, 1, 0, true, 1024, false, false, 10) X(2, 1, 0, false, 1024, false, false, 11)
+  X(0, 1, 0, false, 1024, false, false, 9) X(0, 1, 0, true, 1024, false, false, 10) X(2, 1, 0, false, 1024, false, false, 11) \
+  X(0, 0, 1, false, 1024, 3, false, 8) X(0, 0, 1, true, 1024, 3, false, 9) X(0, 0, 0, false, 0, 3, false, 10) X(0, 0, 0, true, 0, 3, false, 4)
 #endif
 
 }  // namespace ctcdk

@@ -358,9 +358,9 @@ extern "C" int ctccore_decode_lm_cb_f32(const float *probs, const int32_t *seq_l
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, 0u};
       const float *rows = in + ((size_t)b * T + done) * V, *raw = probs + ((size_t)b * T + done) * V;
       int st;
-      if (wordlm) st = decode_utterance<true, false, true, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
+      if (wordlm) st = decode_utterance<true, false, true, false, false, false, true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
                                      (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss, &view, raw, log_input);
-      else st = decode_utterance<true, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
+      else st = decode_utterance<true, false, true, false, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
                                      (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss, &view, raw, log_input);
       if (st == ST_OK) break;
       if (st != ST_NEED_HOST) return -st;
