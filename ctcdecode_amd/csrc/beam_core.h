@@ -1453,8 +1453,9 @@ struct Decoder {
             float logp = child_logp(P, c, lp);
             if (LM && lm_scores(c)) logp = lm_apply(logp, lm_window(b, P, c));  // :120-137
             // :138-139.  (danger mode: the parent sits before the entry in `prefixes` -> its extension was added first)
-            if (CTC_RARE(danger != 0) && has_rep && w.apos[P] < w.apos[j]) nbcur = lse(logp, nbcur);
-            else nbcur = lse(nbcur, logp);
+            // (one call: the arguments trade places -- two inlined copies of the exact log_sum_exp sat here)
+            const bool parent_first = CTC_RARE(danger != 0) && has_rep && w.apos[P] < w.apos[j];
+            nbcur = lse(parent_first ? logp : nbcur, parent_first ? nbcur : logp);
           }
         }
         w.b_new[j] = bcur;
