@@ -486,6 +486,10 @@ struct Decoder {
   // boundary, the last frame, danger mode -- falls back to the histogram select, which first has to build its histogram
   // (rehistogram()): same survivors either way, by construction.
   static constexpr bool kSpec = IDENT && SMALLV && !LM && !LAZY && X::kSpecSelect;
+  // word models, fixed-layout class at 1024 threads, built-in tables: the n-gram query of a new entry's word runs beside phase B
+  // (step(): phase A2 / phase B)
+  static constexpr bool kLmOverlap = LM && WORDLM && SMALLV && !CB && !LAZY && X::kLmOverlap;
+  static constexpr uint32_t kLmSpaceDeferred = 0x80000000u;  // high gate word of an entry whose space child the settling wave scores
   // ONE thread (X::spec_thread) turns what a frame observed -- its K-th key, the size of its hot list -- into the next frame's
   // threshold SP_THR, which everyone reads behind phase A2's barrier.  The best key of the previous frame's survivors is
   // still in that frame's per-parity counters (P_NMAXKEY: they are reset during THIS frame's emission).
@@ -1309,12 +1313,18 @@ struct Decoder {
     const bool lm_job = LM && !lm_char_();
     const int lm_joff = (SMALLV && x.nt_is(1024)) ? kSmallK : nt >= 2 * ((n + 63) & ~63) ? ((n + 63) & ~63) : 0;
     int lm_jk = -1;
+    bool lm_defer = false;  // (kLmOverlap: the entry's n-gram query may run beside phase B -- see phase A2)
     ctclm::DictNode lm_jinfo;
     if (lm_job) {
       const int k = tid - lm_joff;
       if (k >= 0 && k < n) {
         const int fc = b.dfc[k], dnk = b.dn[k];
-        if (fc == kLmPending) { lm_jk = k; lm_jinfo = lm_dict[dnk]; }
+        if (fc == kLmPending) {
+          lm_jk = k; lm_jinfo = lm_dict[dnk];
+          // ... unless the entry has descendants in the beam (a revived node: its children's scores in phase B's entry part read
+          // the window of the word it spells -- path_trie.cpp:40-57 -- while the query would still be in flight)
+          if (kLmOverlap) lm_defer = !(k + 1 < n && b.lcp[k + 1] >= b.dep[k]);
+        }
       }
     }
     x.tick();
@@ -1399,8 +1409,18 @@ struct Decoder {
       else x.wave_add(&pv[P_NPIN], npin);
     }
 #endif
+    // Word models in the fixed-layout class (kLmOverlap): only HALF of a new entry's settling happens here -- its dictionary
+    // record, i.e. the gate of its children (path_trie.cpp:59-70), which phase B needs for every candidate.  The n-gram query
+    // of the word it spells (dependent global loads: two to three round trips, 2.6 k clocks on two waves while fourteen waited
+    // at this barrier) is needed by ONE candidate of phase B -- the entry's space child -- and runs beside phase B on the same two
+    // waves, which then score that child themselves (below).  The entry is marked in the high gate word (free: <= 32 labels),
+    // so that the child waves leave the slot alone; the mark comes off behind phase B's barrier.
+    const bool lm_ovl = kLmOverlap && lm_job;
     if (lm_job && tid >= lm_joff) {
-      if (lm_jk >= 0) lm_resolve_entry(b, lm_jk, lm_jinfo);
+      if (lm_jk >= 0) {
+        if (lm_ovl && lm_defer) { b.dmlo[lm_jk] = (int)lm_jinfo.mask_lo; b.dmhi[lm_jk] = (int)kLmSpaceDeferred; b.dfc[lm_jk] = (int)lm_jinfo.first_child; }
+        else lm_resolve_entry(b, lm_jk, lm_jinfo);
+      }
       for (int k = tid - lm_joff + (nt - lm_joff); k < n; k += nt - lm_joff)  // (workgroups with fewer threads than entries)
         if (b.dfc[k] == kLmPending) lm_resolve_entry(b, k, lm->dict[b.dn[k]]);
     }
@@ -1500,8 +1520,41 @@ struct Decoder {
 #endif
     }
     x.mark(1);
-    if (!split || tid >= n1) {
-      const int t2 = split ? tid - n1 : tid, nt2 = split ? nt - n1 : nt;
+    if (lm_ovl && tid >= n1 && tid < 2 * n1) {  // the two waves that settle the new entries: second half, and the space children
+      int ncand = 0;
+      if (lm_jk >= 0 && lm_defer) {
+        const int k = lm_jk;
+        double cond = ctclm::kOovScore;
+        uint32_t st2 = 0;
+        int cl2 = 0;
+        if (lm_jinfo.word != ctclm::kNoWord) {
+          st2 = (uint32_t)b.lmst[k];
+          cl2 = b.lmcl[k];
+          cond = lm_cond_(&st2, &cl2, lm_jinfo.word);
+        }
+        put_f64(cond, &b.spc_lo[k], &b.spc_hi[k]);
+        b.spst[k] = (int)st2; b.spcl[k] = cl2;
+        // the candidate (entry k, space): what a lane of the children's part computes for it (:108-139), once the window is known
+        const int r = rank_of_char(in, lm_space);
+        if (r >= 0) {
+          const int rn = r - ((brank >= 0 && r > brank) ? 1 : 0);
+          const float lp = w.clp[r], psc = b.score[k];
+          const uint32_t hw = w.hit[hit_word(k, rn)];
+          uint32_t live = 0u - (((hw >> (rn & 31)) & 1u) ^ 1u);
+          live &= 0u - (((lm_jinfo.mask_lo >> lm_space) & 1u) & (uint32_t)!cut(lp, psc));
+          float logp = lp + psc;  // (a new entry was made by a label that is not the space: never the repeat rule)
+          if (live) { logp = lm_apply(logp, cond); ++ncand; }
+          const uint32_t key = ord_f32(logp) & live;
+          const int sl = w.cstart[k] + rn;
+          w.skey[sl] = key;
+          if (!LAZY) w.sinfo[sl] = live ? mk_info(lm_space, T_CHILD, k) : kHoleInfo;
+          hist_add(wd, key);
+        }
+      }
+      x.wave_add(&pv[P_NCAND], ncand);
+    }
+    if ((!split || tid >= n1) && !(lm_ovl && tid < 2 * n1)) {
+      const int t2 = lm_ovl ? tid - 2 * n1 : split ? tid - n1 : tid, nt2 = lm_ovl ? nt - 2 * n1 : split ? nt - n1 : nt;
       const int sh = ceil_log2_u32((uint32_t)(Vnb > 1 ? Vnb : 1));
       const int lp2 = 1 << sh;                       // lanes per parent (power of two >= Vnb)
       int ncand = 0;
@@ -1542,6 +1595,7 @@ struct Decoder {
             const int pch = cur.pch;
             const float psc = cur.psc, pbp = cur.pbp;
             uint32_t live = 0u - (((hw >> (rn & 31)) & 1u) ^ 1u);  // all ones unless the child already exists
+            bool deferred = false;
             const float ext = lp + psc, rep = pbp > CTC_NEG_MAX ? lp + pbp : CTC_NEG_MAX;  // :110-118
             float logp = c == pch ? rep : ext;
             if (LM) {
@@ -1551,16 +1605,22 @@ struct Decoder {
               } else if (cut(lp, psc) || !lm_allows(b, i, c)) {
                 live = 0u;
               }
+              if (kLmOverlap) {
+                deferred = lm_ovl && c == lm_space && (uint32_t)b.dmhi[i] == kLmSpaceDeferred;
+                if (deferred) live = 0u;
+              }
               if (live && lm_scores(c)) logp = lm_apply(logp, lm_window(b, i, c));  // :120-137
               ncand += live ? 1 : 0;
             }
             const uint32_t k = (LM ? ord_f32(logp) : ord_f32_raw(logp)) & live;
             const int s = cs + rn;
-            w.skey[s] = k;
-            if (!LAZY) w.sinfo[s] = x.bitsel(live, ci, kHoleInfo);
+            if (!(kLmOverlap && deferred)) {  // (the space child of an entry whose word is still being looked up: scored by the settling wave)
+              w.skey[s] = k;
+              if (!LAZY) w.sinfo[s] = x.bitsel(live, ci, kHoleInfo);
+            }
             const bool hotk = kSpec && k >= thr;
             const auto tk = x.hot_issue(hotk, &w.vars[VAR_G]);
-            if (!kSpec) hist_add(wd, k);
+            if (!kSpec && !(kLmOverlap && deferred)) hist_add(wd, k);
             i += ng; ci += (uint32_t)ng;
             act = ci < ci_end;
             if (act) cur = fetch(i);
@@ -1600,6 +1660,7 @@ struct Decoder {
     //  select reads the flag right behind it)
     if (kSpec && tid < next_cnt) note_lp(next_val);
     x.sync();
+    if (lm_ovl && tid >= n1 && tid < 2 * n1 && lm_jk >= 0 && lm_defer) b.dmhi[lm_jk] = (int)lm_jinfo.mask_hi;  // (the mark comes off: the next reader is the emission, two barriers on)
     if (!small_vocab) {  // children that already exist leave a hole in their parent's group; then the histogram
       for (int j = tid; j < n; j += nt) {
         const int r = w.pinr[j] >= 0 ? w.pinr[j] : w.revr[j];

@@ -213,6 +213,11 @@ struct DevX {
 #else
   static constexpr bool kSpecSelect = true;
 #endif
+#if defined(CTC_NO_LM_OVERLAP)
+  static constexpr bool kLmOverlap = false;
+#else
+  static constexpr bool kLmOverlap = NT == 1024;  // (beam_core.h kLmOverlap: the geometry it assumes)
+#endif
   // (the ranking gives every hot key one lane of the first 128 or 256 threads)
   __device__ __forceinline__ bool spec_fits(int hot) const { return (hot <= 128 ? 128 : 256) <= nt(); }
   __device__ __forceinline__ int spec_thread() const { return nt() - 64; }  // lane 0 of the last wave keeps the prediction
