@@ -66,7 +66,7 @@ def test_library_builds_on_this_box(torch_mod, tmp_path):
     from ctcdecode_amd import _build
 
     if not os.environ.get("CTCD_TEST_BUILD_ON_BOX"):
-        pytest.skip("opt-in (CTCD_TEST_BUILD_ON_BOX=1): written at the very end of round 3 and not yet run to completion on a GPU box")
+        pytest.skip("opt-in (CTCD_TEST_BUILD_ON_BOX=1; run once per round: profiles/r04c_build_on_box.txt -- 8 s on the GPU box)")
     if not (shutil.which("hipcc") or os.path.exists(os.path.join(_build.ROCM, "bin", "hipcc"))):
         pytest.skip("no hipcc on this box")
     torch = torch_mod
