@@ -67,12 +67,50 @@ def parse():
     ap.add_argument("--backend", default="", help="torch.distributed backend (default nccl = RCCL; gloo when ranks share a device)")
     ap.add_argument("--min-shard", type=int, default=0, help="configs 2 / 4 (strong scaling): at least this many utterances per rank -- fill a GPU (256 = its CU count) "
                     "before adding ranks; the ranks left over get empty shards (ctcdecode_amd.distributed.shard_size)")
+    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run: two rocprofv3 --pmc child runs of this script (FETCH_SIZE, "
+                    "WRITE_SIZE: counters only, one per pass, as MI355X_MICROARCH.md prescribes) instead of the constant in --traffic-json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e and other_configs measurements (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes of the decode kernel from a rocprofv3 --pmc pass (tools/rocprof_summary.py)")
     return ap.parse_args()
+
+
+def measure_traffic(a):
+    """HBM bytes per launch of the headline decode kernel from rocprofv3's FETCH_SIZE / WRITE_SIZE (KiB per dispatch; separate
+    passes; the decode kernels read 4-16 B per lane, so FETCH_SIZE needs no 128-bit-load correction: DESIGN.md section 6), each
+    pass a child run of this script with the extras off.  Returns (bytes, note) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    total = 0.0
+    tmp = tempfile.mkdtemp(prefix="ctcd_pmc_")
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, c)
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--batch", str(a.batch), "--frames", str(a.frames), "--vocab", str(a.vocab),
+                   "--beam", str(a.beam), "--threads", str(a.threads)]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "ctc_beam_decode_kernel" in row["Kernel_Name"] and row["Counter_Name"] == c:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "rocprofv3 --pmc %s gave no rows for the decode kernel (rc %d)" % (c, r.returncode)
+            total += sum(vals) / len(vals) * 1024.0
+        return int(total), "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (mean over their launches)"
+    except Exception as e:  # (a profiler that is missing or hangs must not take the bench line with it)
+        return None, "rocprofv3 child run failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(lp_np, beam, target_s, lm=None):
@@ -500,6 +538,13 @@ def main():
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         except Exception:
             traffic = None
+    traffic_note = ("constant from profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command), not measured in this run" % traffic_src) if traffic else None
+    if a.pmc and rank == 0 and a.config == 1 and not use_dist:
+        measured, note = measure_traffic(a)
+        if measured:
+            traffic, traffic_note = measured, note
+        elif traffic_note:
+            traffic_note += "; --pmc: " + note
 
     if rank == 0:
         floor = sum(FRAME_FLOOR.values())
@@ -527,7 +572,7 @@ def main():
             "us_per_frame": round(kern_ms * 1e3 / T, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic if a.config == 1 else None,
-                         "traffic_source": ("constant from profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command), not measured in this run" % traffic_src) if traffic else None,
+                         "traffic_source": traffic_note,
                          "traffic_ratio": round(traffic / alg_bytes, 2) if traffic and a.config == 1 else None,
                          "memset_bytes_outside_kernel": 2 * B * K * T * 4 + 2 * B * K * 4,
                          "kernel": "ctc_beam_decode_kernel", "algorithmic_bytes_per_launch": alg_bytes},
