@@ -137,7 +137,8 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *w
  *   Results equal those of a scorer that knew every answer from the start (tests/test_gpu_lm.py: the built-in tables behind
  *   the callback give bit-identical output).  Accepted by ctcd_beam_decode_lm, ctcd_beam_decode_lm_host,
  *   ctcd_beam_decode_to_host and ctcd_stream_create_lm / ctcd_stream_decode; ctcd_beam_decode_compact refuses it.
- *   Not supported with it: rows that hold +-inf or overflow float32 sums (CTCD_EUNSUPPORTED).
+ *   Not supported with it (CTCD_EUNSUPPORTED): rows that hold +-inf or overflow float32 sums; beams whose workspace does not fit
+ *   one workgroup's LDS (the wide-beam layouts: beyond roughly beam_width * (candidates + 2) = 20 000 slots).
  * ctcd_scorer_cond_log10 evaluates any scorer in the callback's own form (so the built-in tables can sit behind one);
  * ctcd_scorer_callback_calls counts the callback invocations so far (= distinct windows cached). */
 typedef int (*ctcd_cond_log10_fn)(void *user, const char *const *words, int n, float *log10_prob);
