@@ -403,6 +403,11 @@ def test_scorer_hook_callback_decides_vocabulary_and_errors_propagate(torch_mod)
         dec2.decode(x)
     with pytest.raises(ValueError):
         ctcdecode_amd.CTCBeamDecoder(labels, scorer=sc2, model_path=TEST_ARPA)
+    # a beam whose workspace needs the wide-beam layouts: refused with a callback scorer (the built-in tables take it)
+    sc3 = ctcdecode_amd.CallbackScorer(lambda words: -1.0, ["a", "b"], 2, LABELS29)
+    wide = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc3, beam_width=500, log_probs_input=True)
+    with pytest.raises(NotImplementedError):
+        wide.decode(torch_mod.from_numpy(ou.synth_logprobs(1, 20, 29, 3)))
 
 
 def test_kenlm_scorer_matches_builtin_tables(torch_mod):
