@@ -546,11 +546,22 @@ struct DevX {
   __device__ __forceinline__ void mark_ge(int S, const uint32_t *skey, uint32_t tau, uint32_t *bitmap) {
     const int lane = (int)threadIdx.x & 63, nw = (nt() + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    for (int s0 = wave * 64; s0 < S; s0 += nw * 64) {
-      const int s = s0 + lane;
-      const uint32_t k = s < S ? skey[s] : 0u;
-      const unsigned long long m = CTC_BALLOT(k >= tau);
-      if (lane == 0) { bitmap[2 * (s0 >> 6)] = (uint32_t)m; bitmap[2 * (s0 >> 6) + 1] = (uint32_t)(m >> 32); }
+    // (four groups of 64 slots per trip: their keys are requested together -- one LDS round trip instead of four)
+    const int step = nw * 64;
+    for (int s0 = wave * 64; s0 < S; s0 += 4 * step) {
+      uint32_t k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + u * step + lane;
+        k[u] = s < S ? skey[s] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b0 = s0 + u * step;
+        if (b0 >= S) break;
+        const unsigned long long m = CTC_BALLOT(k[u] >= tau);
+        if (lane == 0) { bitmap[2 * (b0 >> 6)] = (uint32_t)m; bitmap[2 * (b0 >> 6) + 1] = (uint32_t)(m >> 32); }
+      }
     }
   }
   // out[r] = s for the r-th set bit s of the bitmap (ascending); one wave, the others wait at the closing barrier.

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--repeat", type=int, default=1, help="launches to average over (frame0 moves by 37 each)")
     ap.add_argument("--lm", default="", help="ARPA model: time the LM tier's kernel (labels _ ' space a..z)")
+    ap.add_argument("--all-paths", action="store_true", help="print the rows of every group of frames (by stamps per frame), not only the most frequent one")
     ap.add_argument("--kind", default="randn", help="randn | blank (+6 on the blank logit: nearly every frame takes the speculative select)")
     a = ap.parse_args()
     import numpy as np
@@ -108,6 +109,14 @@ def main():
                      "per_wave": [float(v) for v in acc[:, i]]})
         print("%2d %-52s max %5.0f  med %5.0f  min %5.0f | %s" % (i, lab[:52], acc[:, i].max(), np.median(acc[:, i]), acc[:, i].min(),
                                                                  " ".join("%4.0f" % v for v in acc[:, i])))
+    if a.all_paths:
+        for k, v in sorted(groups.items()):
+            if k == per:
+                continue
+            ac = np.mean(v, axis=0)
+            print("-- frames with %d stamps (%d of them): slowest wave / median wave per interval" % (k, len(v)))
+            for i in range(ac.shape[1]):
+                print("   %2d  max %5.0f  med %5.0f" % (i, ac[:, i].max(), np.median(ac[:, i])))
     per_group = {str(k): float(np.mean([g.sum(axis=1)[0] for g in v])) for k, v in groups.items()}
     print("clocks per frame by path (stamps per frame -> clocks, stamps included):", per_group)
     if a.out:
