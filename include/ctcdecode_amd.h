@@ -139,6 +139,8 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *w
  *   ctcd_beam_decode_to_host and ctcd_stream_create_lm / ctcd_stream_decode; ctcd_beam_decode_compact refuses it.
  *   Not supported with it (CTCD_EUNSUPPORTED): rows that hold +-inf or overflow float32 sums; beams whose workspace does not fit
  *   one workgroup's LDS (the wide-beam layouts: beyond roughly beam_width * (candidates + 2) = 20 000 slots).
+ *   Decodes that share one callback scorer are serialised (its cache is one object); a ctcd_stream_decode call that fails
+ *   half-way (the callback reported an error) leaves the streams of that call unusable: destroy them.
  * ctcd_scorer_cond_log10 evaluates any scorer in the callback's own form (so the built-in tables can sit behind one);
  * ctcd_scorer_callback_calls counts the callback invocations so far (= distinct windows cached). */
 typedef int (*ctcd_cond_log10_fn)(void *user, const char *const *words, int n, float *log10_prob);
