@@ -1405,14 +1405,10 @@ struct Decoder {
       npin += pr >= 0;
     }
     // (the other waves had no entry: skip the reduction; with at most one entry per thread the count is a ballot's population)
-#if defined(CTC_EXP_NO_FLAGCOUNT)
-    if (x.group() * x.lanes() < n) x.wave_add(&pv[P_NPIN], npin);
-#else
     if (x.group() * x.lanes() < n) {
       if (SMALLV && x.nt_is(1024)) x.wave_add_flag(&pv[P_NPIN], npin != 0);
       else x.wave_add(&pv[P_NPIN], npin);
     }
-#endif
     // Word models in the fixed-layout class (kLmOverlap): only HALF of a new entry's settling happens here -- its dictionary
     // record, i.e. the gate of its children (path_trie.cpp:59-70), which phase B needs for every candidate.  The n-gram query
     // of the word it spells (dependent global loads: two to three round trips, 2.6 k clocks on two waves while fourteen waited
@@ -1443,9 +1439,7 @@ struct Decoder {
     const int n1 = (SMALLV && x.nt_is(1024)) ? kSmallK : ((n + 63) & ~63) > 128 ? 128 : (n + 63) & ~63;
     const bool split = nt - n1 >= 128;
     if (!split || tid < n1) {
-#if defined(CTC_EXP_B1_PRIO)
-      x.template prio<CTC_EXP_B1_PRIO>();
-#endif
+      // (Measured and dropped: a raised wave priority for the entry part -- neutral.)
       const float lp_blank = brank >= 0 ? w.clp[brank] : CTC_NEG_MAX;
       int ncand = 0;
       for (int j = tid; j < n; j += (split ? n1 : nt)) {
@@ -1519,9 +1513,6 @@ struct Decoder {
         if (LM && CTC_RARE(upd_xn >= 0)) set_node_time(upd_xn, upd_xc, in.t, upd_xlp);
       }
       if (LM) x.wave_add(&pv[P_NCAND], ncand);
-#if defined(CTC_EXP_B1_PRIO)
-      x.template prio<0>();
-#endif
     }
     x.mark(1);
     if (lm_ovl && tid >= n1 && tid < 2 * n1) {  // the two waves that settle the new entries: second half, and the space children
