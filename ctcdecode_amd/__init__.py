@@ -201,6 +201,14 @@ class CTCBeamDecoder(object):
         that keeps several launches in flight; 0: never; -1 (default): when a batch has more utterances than the GPU has CUs."""
         _native.check(_native.lib.ctcd_set_cu_sharing(self._handle, int(mode)))
 
+    def set_subtree_search(self, mode=-1):
+        """Phase A1's four-subtrees-per-wave build of the north-star class kernel (include/ctcdecode_amd.h): -1 = chosen from the beam
+        shape the last checked launch reported (chain-shaped beams, i.e. blank-dominated rows: on), 0 / 1 = never / always."""
+        _native.check(_native.lib.ctcd_set_subtree_search(self._handle, int(mode)))
+
+    def last_subtree_search(self):
+        return int(_native.lib.ctcd_last_subtree_search(self._handle))
+
     def set_host_path(self, input_streaming=None, mirror_cap_labels=None):
         """Test hook for decode(): turn the streamed input off / on; shrink the host mirror of the compact results."""
         _native.check(_native.lib.ctcd_debug_set_host_path(self._handle, -1 if input_streaming is None else int(bool(input_streaming)),

@@ -163,6 +163,7 @@ enum {
   // (the first four are what every thread reads before phase B: one 16-byte group)
   VAR_SPEC = VAR_PAR0 + 2 * P_SIZE, SP_THR = 0, SP_WLOG, SP_ANCHOR, SP_PRED, SP_BEST, SP_MARGIN, SP_GAP, SP_ROWMAX,
   VAR_ROWMAX = VAR_SPEC + SP_ROWMAX,
+  VAR_QSTAT = VAR_SPEC + 9,   // entries of the launch's final beam with descendants in it (the shape statistic the host reads: chains or bushes)
   VAR_LMMISS = VAR_SPEC + 8,  // host-side scorer hook: this frame asked for something the cache does not hold (sticky within a launch)
   VAR_COUNT = VAR_SPEC + 12
 };
@@ -789,6 +790,7 @@ struct Decoder {
       reset_pvars(pvars(1));
       w.vars[VAR_DANGER] = lm_params_extreme() ? 1 : 0;
       w.vars[VAR_INTO] = 0;
+      w.vars[VAR_QSTAT] = 0;
       w.vars[VAR_LMMISS] = 0;
       w.apos[0] = 0; w.fin[0] = 0;
     }
@@ -834,6 +836,7 @@ struct Decoder {
       reset_pvars(pvars(1));
       w.vars[VAR_DANGER] = ss.hdr[SH_DANGER];
       w.vars[VAR_INTO] = 0;
+      w.vars[VAR_QSTAT] = 0;
       w.vars[VAR_LMMISS] = 0;
     }
     for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
@@ -844,6 +847,19 @@ struct Decoder {
     if (kSpec) x.sync();
     spec_reset(x.uni(ss.hdr[SH_FRAMES]), ss.hdr);
     x.sync_full();
+  }
+  // The shape statistic the host chooses phase A1's build by (X::kQuarters): how many entries of the beam the launch ends with
+  // have descendants in it -- one or two on random rows, about twenty on blank-dominated ones.  Once per launch, behind the last
+  // frame.  (Counted per frame -- in phase A1, where the number falls out of the search, or on an idle wave of the emission -- it
+  // cost random rows 1-2 % of the frame.)
+  CTC_HD void shape_stat() {
+    if (!(SMALLV && !LM)) return;
+    select_beams();
+    const Beam &b = w.cur;
+    int cnt = 0;
+    for (int j = x.tid(); j + 1 < st_n; j += x.nt()) cnt += b.lcp[j + 1] >= b.dep[j] ? 1 : 0;
+    if (cnt) x.atomic_add(&w.vars[VAR_QSTAT], cnt);
+    x.sync();
   }
   CTC_HD void save_state(const StreamState &ss, int frames) {
     const int tid = x.tid(), nt = x.nt(), K = d.K;
@@ -1353,7 +1369,9 @@ struct Decoder {
         }
         unsigned long long todo = x.ballot(internal);
         if (internal) x.count(EV_INTERNAL, 1);
-        if (LM && x.subtrees_by_quarters(todo, k0, grp, ngr, b.dep, b.lcp, n, w.e, w.anc, acnt)) todo = 0;
+        // (X::kQuarters: the build for chain-shaped beams without a scorer -- three or more interior entries in a wave, as blank-dominated rows
+        //  have them in most frames; by its mere presence the search costs random rows 3 % of the frame, so it is a build of its own)
+        if ((LM || (X::kQuarters && __builtin_popcountll(todo) >= 3)) && x.subtrees_by_quarters(todo, k0, grp, ngr, b.dep, b.lcp, n, w.e, w.anc, acnt)) todo = 0;
         while (todo) {
           const int kk = __builtin_ctzll(todo);
           todo &= todo - 1;
@@ -2367,6 +2385,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   if (ss) dec.save_state(*ss, t0 + len);
   int fs = ST_OK;
   if (!ss || ss->finish) fs = dec.finish(t0 + len > 0, t0 + len, outs, item);
+  dec.shape_stat();
   x.sync();
   x.mark(11);
   if (frames_ready != nullptr && x.uni(w.vars[VAR_INTO]) != 0) return ST_INPUT_TIMEOUT;

@@ -829,7 +829,13 @@ struct ctcd_decoder {
   bool no_fixed_layout = false;  // debugging: always use the run-time workspace layout
   Buf prof, dbg, tl;
   int tl_f0 = 0, tl_nf = 0;
+  int status_items = 0;          // items of the launch whose status words (and shape statistic) are in d->status
   bool tl_armed = false;
+  // phase A1's four-entries-per-wave subtree search (decode_kernel.h kQuarters): -1 = chosen per launch from the beam shape the
+  // last checked launch reported (chains: on), 0 / 1 = forced
+  int subtree_mode = -1;
+  bool subtree_on = false;       // the automatic choice for the next launch
+  int last_subtree_search = 0;   // what the last launch used
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // decode kernel | vocabulary-prune pass
   bool prune_timed = false;
   // streamed input of the host-tensor entry point: rows cross PCIe frame block by frame block while the kernel runs
@@ -1014,6 +1020,13 @@ int ctcd_set_cu_sharing(ctcd_decoder *d, int mode) {
   return CTCD_OK;
 }
 
+int ctcd_set_subtree_search(ctcd_decoder *d, int mode) {
+  if (!d || mode < -1 || mode > 1) return fail(CTCD_EINVAL, "subtree search mode must be -1 (automatic), 0 or 1");
+  d->subtree_mode = mode;
+  return CTCD_OK;
+}
+int ctcd_last_subtree_search(const ctcd_decoder *d) { return d ? d->last_subtree_search : -1; }
+
 int ctcd_set_threads(ctcd_decoder *d, int t) {
   if (!d || t < 0 || t > 1024 || (t && (t < 64 || (t & (t - 1))))) return fail(CTCD_EINVAL, "threads must be 0 (automatic) or a power of two in [64, 1024]");
   d->threads = t;
@@ -1156,7 +1169,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   const long long pool_stride = (long long)beam * T + 1;
   // per utterance: nodes (12 B each), then -- per utterance again -- express pointers and the time steps' high parts (4 B each)
   if (!sc && (rc = d->pool.ensure((size_t)B * pool_stride * (sizeof(PoolNode) + 2 * sizeof(int))))) return rc;
-  if ((rc = d->status.ensure((size_t)B * 4))) return rc;
+  if ((rc = d->status.ensure((size_t)B * 8))) return rc;  // [status words | beam-shape statistic]
   // every status word starts as -1 ("no result"): a workgroup that never ran cannot read back as ST_OK
   HIP_TRY(hipMemsetAsync(d->status.p, 0xff, (size_t)B * 4, stream));
   d->last_stream = stream;
@@ -1246,6 +1259,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     a.outs.m_hdr = co->m_hdr; a.outs.m_ent = co->m_ent; a.outs.m_done = co->m_done; a.outs.m_rag = co->m_rag; a.outs.m_cap = co->m_cap;
   }
   a.status = (int32_t *)d->status.p;
+  a.shape = a.status + B;
+  d->status_items = B;
   a.st_base = st_base; a.st_poolcap = st_cap; a.st_eos = st_eos; a.st_pool_off = (long long)stream_pool_offset(beam);
   a.raw = probs; a.raw_log = log_input;
   std::memset(&a.lm, 0, sizeof(a.lm));
@@ -1314,6 +1329,12 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 1, 0, true, 1024> : (const void *)ctc_beam_decode_kernel<0, 1, 0, false, 1024>;
   if (!d->profile && fixed && !big && threads == 1024)  // the usual case: workgroup size folded into the code
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
+  d->last_subtree_search = 0;
+  if (!d->profile && fixed && !big && threads == 1024 && !scorer && !occ2 && (d->subtree_mode == 1 || (d->subtree_mode < 0 && d->subtree_on))) {
+    // chain-shaped beams (blank-dominated rows: what acoustic models emit): the build whose phase A1 searches four subtrees per wave
+    fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<3, 0, 1, true, 1024> : (const void *)ctc_beam_decode_kernel<3, 0, 1, false, 1024>;
+    d->last_subtree_search = 1;
+  }
   if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, false, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
   if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes and for the first wide-beam layout
     if (threads != 1024) return fail(CTCD_EUNSUPPORTED, "barrier timeline: 1024 threads per workgroup (the product configuration)");
@@ -2177,10 +2198,23 @@ int ctcd_check_status(ctcd_decoder *d, int B) {
   if (B == 0) return CTCD_OK;
   CTC_ON_DEVICE(d->device);
   if (!d->status.p || d->status.cap < (size_t)B * 4) return fail(CTCD_EINVAL, "no decode of that many items has been launched");
-  std::vector<int32_t> st(B);
+  const bool with_shape = d->status.cap >= (size_t)B * 8 && d->status_items == B;
+  std::vector<int32_t> st((size_t)B * (with_shape ? 2 : 1));
   // ordered after the kernel on the stream it was launched on (a null-stream copy would not wait for a non-blocking stream)
-  HIP_TRY(hipMemcpyAsync(st.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, d->last_stream));
+  HIP_TRY(hipMemcpyAsync(st.data(), d->status.p, st.size() * 4, hipMemcpyDeviceToHost, d->last_stream));
   HIP_TRY(hipStreamSynchronize(d->last_stream));
+  if (with_shape) {
+    // The beam shape the launch ended with: entries of an item's final beam that have descendants in it (x 16), averaged over the
+    // items.  Random rows: 1-2; blank-dominated rows: ~20.  The next launch's phase A1 is chosen by it (hysteresis 4 .. 8).
+    long long sum = 0, cnt = 0;
+    for (int b = 0; b < B; ++b)
+      if (st[B + b] > 0 || st[b] == ST_OK) { sum += st[B + b]; ++cnt; }
+    if (cnt) {
+      const double per_frame = (double)sum / (double)cnt / 16.0;
+      if (per_frame >= 8.0) d->subtree_on = true;
+      else if (per_frame <= 4.0) d->subtree_on = false;
+    }
+  }
   for (int b = 0; b < B; ++b)
     if (st[b] != ST_OK) {
       if (st[b] == ST_INPUT_TIMEOUT) d->input_timed_out = true;

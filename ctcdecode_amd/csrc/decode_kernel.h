@@ -46,6 +46,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 // FAR: part of the workspace lives in HBM (BIG layout): every barrier must then also drain global memory traffic.
+// PROF: 3 = product build with the four-entries-per-wave subtree search of phase A1 (kQuarters: chain-shaped beams);
 // PROF: 0 = product build; 1 = per-phase timers (mark) and the beam dump; 2 = barrier timeline only (no timers: the
 // timers' mutable state would put this object into scratch memory and distort the timeline).
 // NT: the workgroup size when it is known at compile time (0 = read blockDim): wave counts, the role split of a frame
@@ -213,6 +214,7 @@ struct DevX {
 #else
   static constexpr bool kSpecSelect = true;
 #endif
+  static constexpr bool kQuarters = PROF == 3;  // (beam_core.h phase A1)
 #if defined(CTC_NO_LM_OVERLAP)
   static constexpr bool kLmOverlap = false;
 #else
@@ -784,6 +786,7 @@ struct KernelArgs {
   const uint64_t *tables;   // 64 words (exact_math.h)
   OutRefs outs;             // result tensors; read through the kernel-argument segment at the end of an utterance
   int32_t *status;          // [B]
+  int32_t *shape;           // [B] or null: 16 x (entries of the item's final beam with descendants in it) -- chains or bushes
   long long *prof;          // [B, 16] phase timers (profiling build of the kernel only)
   int *dbg;                 // profiling build: beam of item 0 after every frame, [T][1 + 4K] (or null)
   long long *tl;            // profiling build: barrier timeline of item 0, [waves][tl_cap] (or null)
@@ -889,6 +892,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + ((size_t)b * a.T + f0) * a.V : nullptr, a.raw_log,
                                   PRUNED ? (const int *)nullptr : a.frames_ready);
   if (threadIdx.x == 0) {
+    if (a.shape) a.shape[b] = 16 * w.vars[ctcbeam::VAR_QSTAT];
     a.status[b] = st;
     if (a.frames_done && a.st_base) a.frames_done[b] = ss.hdr[SH_FRAMES];  // (written by this thread in save_state)
   }
@@ -923,7 +927,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(0, 1, 0, false, 0, true, false, 6) X(0, 1, 0, true, 0, true, false, 7) X(0, 2, 0, false, 0, true, false, 8) X(0, 2, 0, true, 0, true, false, 9) \
   X(0, 3, 0, false, 0, false, false, 5) X(0, 3, 0, true, 0, false, false, 4) X(0, 3, 0, false, 0, true, false, 6) X(0, 3, 0, true, 0, true, false, 7) \
   X(0, 1, 0, false, 1024, false, false, 9) X(0, 1, 0, true, 1024, false, false, 10) X(2, 1, 0, false, 1024, false, false, 11) \
-  X(0, 0, 1, false, 1024, 3, false, 8) X(0, 0, 1, true, 1024, 3, false, 9) X(0, 0, 0, false, 0, 3, false, 10) X(0, 0, 0, true, 0, 3, false, 4)
+  X(3, 0, 1, false, 1024, false, false, 1) X(3, 0, 1, true, 1024, false, false, 2) X(0, 0, 1, false, 1024, 3, false, 8) X(0, 0, 1, true, 1024, 3, false, 9) X(0, 0, 0, false, 0, 3, false, 10) X(0, 0, 0, true, 0, 3, false, 4)
 #endif
 
 }  // namespace ctcdk

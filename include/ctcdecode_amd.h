@@ -236,6 +236,14 @@ int ctcd_set_threads(ctcd_decoder *dec, int threads_per_workgroup); /* 0 = autom
  * workgroup runs ~7 % slower in it, two on a CU together 1.4-1.5x faster.  mode = -1 (default): used when a batch has
  * more utterances than the device has CUs; 1: always (a serving loop that keeps several launches in flight); 0: never. */
 int ctcd_set_cu_sharing(ctcd_decoder *dec, int mode);
+/* The north-star class of shapes (beam <= 128, <= 32 labels, no scorer) has a second build of its kernel whose phase A1 settles
+ * four subtrees per wavefront at once: beams shaped like chains -- what blank-dominated rows, i.e. real acoustic posteriors,
+ * produce: some twenty entries with descendants in the beam per frame -- decode 7 % faster with it, bushy beams (random rows:
+ * one or two) 3 % slower.  mode -1 (default): chosen per launch from the shape statistic of the last launch whose status was
+ * checked (ctcd_check_status; the *_host / to_host entries check); 0 / 1: never / always.  Results are identical in both
+ * builds.  ctcd_last_subtree_search: which build the last launch used (0 / 1). */
+int ctcd_set_subtree_search(ctcd_decoder *dec, int mode);
+int ctcd_last_subtree_search(const ctcd_decoder *dec);
 int ctcd_workgroup_lds_bytes(int beam, int V, int cutoff_top_n, double cutoff_prob); /* LDS one utterance needs (default build) */
 const char *ctcd_last_error(void);
 const char *ctcd_version(void);

@@ -57,6 +57,7 @@ struct HostX {
   void tick() {}
   // speculative select (beam_core.h Decoder::kSpec), sequentially: the same contract as the device policy's
   static constexpr bool kSpecSelect = true;
+  static constexpr bool kQuarters = false;
   static constexpr bool kLmOverlap = false;  // (a split of the workgroup's waves: nothing to overlap with one thread)
   bool spec_fits(int) const { return true; }
   void hot_append(bool hot, uint32_t key, int slot, uint32_t *hk, int *hs, int *cnt) {

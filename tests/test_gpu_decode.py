@@ -944,3 +944,38 @@ def test_async_compact_decode_tickets(torch_mod):
         want = ou.decode(lps[j], sl, beam=K)
         got = dict(tokens=out.cpu().numpy(), timesteps=ts.cpu().numpy(), scores=sc.cpu().numpy(), lens=ln.cpu().numpy())
         ou.assert_same(_with_nres(got, want), want, "ticket %d" % j)
+
+
+def test_subtree_search_build_is_chosen_by_beam_shape_and_changes_nothing(torch_mod):
+    """The second build of the north-star class kernel (phase A1 settles four subtrees per wave: ctcd_set_subtree_search): same
+    results bit for bit when forced on random, blank-dominated and tie-heavy rows; chosen automatically after a checked launch
+    that saw chain-shaped beams (blank-dominated rows), dropped again after one that saw bushy ones (random rows)."""
+    import ctcdecode_amd
+
+    V, K = 29, 100
+    labels = [str(i) for i in range(V)]
+    rows = {"randn": ou.synth_logprobs(6, 300, V, 11), "blank": ou.synth_logprobs(6, 300, V, 12, blank_bias=6.0),
+            "quant": ou.synth_logprobs(6, 200, V, 13, quant=0.5, blank_bias=2.0)}
+    for name, lp in rows.items():
+        x = torch_mod.from_numpy(lp).cuda()
+        outs = []
+        for mode in (0, 1):
+            dec = ctcdecode_amd.CTCBeamDecoder(labels, beam_width=K, log_probs_input=True)
+            dec.set_subtree_search(mode)
+            outs.append([t.cpu().numpy() for t in dec.decode_device(x)])
+            assert dec.last_subtree_search() == mode
+        for a, b in zip(*outs):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+        want = ou.decode(lp, beam=K, which="restated")
+        got = dict(tokens=outs[1][0], scores=outs[1][1], timesteps=outs[1][2], lens=outs[1][3])
+        ou.assert_same(_with_nres(got, want), want, "subtree-search build, " + name)
+    dec = ctcdecode_amd.CTCBeamDecoder(labels, beam_width=K, log_probs_input=True)
+    xb, xr = torch_mod.from_numpy(rows["blank"]).cuda(), torch_mod.from_numpy(rows["randn"]).cuda()
+    dec.decode_device(xb)
+    assert dec.last_subtree_search() == 0          # nothing known yet
+    dec.decode_device(xb)
+    assert dec.last_subtree_search() == 1          # the first launch reported chains
+    dec.decode_device(xr)
+    assert dec.last_subtree_search() == 1
+    dec.decode_device(xr)
+    assert dec.last_subtree_search() == 0          # ... and that one bushes
