@@ -230,6 +230,91 @@ def time_pipelined(torch, ctcdecode_amd, dev, lp, labels, V, K, inflight=2, step
     return dt
 
 
+def time_inflight(torch, ctcdecode_amd, dev, lp, labels, K, inflight, steps=12, warm=4, **dec_kw):
+    """Batches of lp.shape[0] utterances through ctcdecode_amd.DecodePipeline with `inflight` launches in flight, DEFAULT build of
+    the kernel (one workgroup per CU, nothing shared): seconds per batch.  inflight = 1 is the plain loop."""
+    V = lp.shape[2]
+    pipe = ctcdecode_amd.DecodePipeline(lambda: ctcdecode_amd.CTCBeamDecoder(labels, cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev, **dec_kw),
+                                        inflight=inflight)
+
+    def run(n):  # (results are collected -- and dropped -- as a serving loop would: `inflight` batches are alive at any time)
+        tickets = []
+        for _ in range(n):
+            tickets.append(pipe.submit(lp))
+            if len(tickets) > inflight:
+                pipe.result(tickets.pop(0))
+        for t in tickets:
+            pipe.result(t)
+        torch.cuda.synchronize()
+
+    run(warm)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    del pipe
+    return dt
+
+
+def arpa_unigrams(path):
+    """The words an ARPA file lists (what Scorer::fill_dictionary reads from the model, scorer.cpp:196-230)."""
+    words, on = [], False
+    with open(path, encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith("\\"):
+                on = line == "\\1-grams:"
+                continue
+            if on and line:
+                words.append(line.split("\t")[1] if "\t" in line else line.split()[1])
+    return words
+
+
+def time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, B=128, T=1500, K=100, alpha=0.5, beta=1.0):
+    """what the host-side scorer hook costs at the configs[4] per-GPU shape.  The built-in tables of `arpa`
+    sit behind the hook as a NATIVE callback (ctcd_scorer_cond_log10 has the callback's signature: no Python in the loop), so
+    results and cache contents are the built-in scorer's and the difference in time is the hook's: cold (fresh scorer: every
+    window is a miss), a second batch of OTHER utterances (lukewarm), the first batch again (warm: one launch), against the
+    same decodes with the built-in tables."""
+    import ctypes
+
+    n = ctcdecode_amd._native
+    V = len(labels)
+    lps = [synth_rows(torch, B, T, V, 7 + i).to(dev) for i in range(2)]
+    arr = (ctypes.c_char_p * V)(*[x.encode("utf-8") for x in labels])
+    inner = ctypes.c_void_p()
+    n.check(n.lib.ctcd_scorer_create(ctypes.byref(inner), 0.0, 0.0, arpa.encode(), arr, V, dev.index or 0))
+    order = int(n.lib.ctcd_scorer_max_order(inner))
+    fn_addr = ctypes.cast(n.lib.ctcd_scorer_cond_log10, ctypes.c_void_p).value
+    out = {}
+    try:
+        ref = ctcdecode_amd.CTCBeamDecoder(labels, model_path=arpa, alpha=alpha, beta=beta, cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev)
+        ref.set_timing(True)
+        want = []
+        for lp in lps:
+            for _ in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                r = ref.decode_device(lp, None, check=True)
+                torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            want.append(r)
+        out["built-in tables"] = {"call_ms": round(dt * 1e3, 3), "kernel_ms": round(ref.last_kernel_ms(), 3)}
+        sc = ctcdecode_amd.CallbackScorer.from_c(fn_addr, inner.value, arpa_unigrams(arpa), order, labels, alpha=alpha, beta=beta, device=dev)
+        dec = ctcdecode_amd.CTCBeamDecoder(labels, scorer=sc, cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev)
+        calls0 = 0
+        for name, lp, w in (("cold (fresh scorer)", lps[0], want[0]), ("second batch of other utterances (lukewarm)", lps[1], want[1]), ("first batch again (warm)", lps[0], want[0])):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = dec.decode_device(lp, None, check=True)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            calls = sc.callback_calls()
+            same = all(torch.equal(a, b) for a, b in zip(r, w))
+            out[name] = {"call_ms": round(dt * 1e3, 3), "launches": int(n.lib.ctcd_last_scorer_rounds(dec._handle)), "callback_calls": int(calls - calls0),
+                         "equals_built_in": bool(same)}
+            calls0 = calls
+        del dec, sc, ref
+    finally:
+        n.lib.ctcd_scorer_destroy(inner)
+    return out
+
+
 def time_streaming(torch, ctcdecode_amd, dev, lp, V, K, chunk=50, reps=3):
     """SURVEY 8(f) N3 as a serving loop would drive it: every utterance of the batch is a stream (OnlineCTCBeamDecoder /
     DecoderState), fed in chunks of `chunk` frames from HBM; the last chunk ends the streams and returns the results (CPU
@@ -351,12 +436,34 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
     run("configs[3] (V=10000, top_n 40, cutoff_prob 0.99)", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99)
     run("configs[4] per-GPU shape without the LM (128 of 1024 utterances, T 1500)", 128, 1500, 29, 100)
     arpa = os.path.join(ROOT, "tests", "data", "test.arpa")
+    # 128 utterances occupy half the CUs.  The time axis cannot be split, so the idle half is given to the
+    # NEXT batch: ctcdecode_amd.DecodePipeline, two launches in flight on two streams, default build, no CU shared.
+    try:
+        lab29 = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
+        lp128 = synth_rows(torch, 128, 1500, 29, 7).to(dev)
+        half = {"what": "batches of 128 utterances (configs[4]'s per-GPU share: half the CUs) through ctcdecode_amd.DecodePipeline: one launch at a time vs two in flight on two HIP streams (default build of the kernel, no CU shared); utterances/s"}
+        for name, kw in (("no LM", {}), ("LM scorer (tests/data/test.arpa)", dict(model_path=arpa, alpha=0.5, beta=1.0))):
+            if kw and not (os.path.exists(arpa) and getattr(ctcdecode_amd, "HAVE_LM", False)):
+                continue
+            one = time_inflight(torch, ctcdecode_amd, dev, lp128, lab29, 100, 1, **kw)
+            two = time_inflight(torch, ctcdecode_amd, dev, lp128, lab29, 100, 2, **kw)
+            half[name] = {"one_in_flight": round(128 / one, 1), "two_in_flight": round(128 / two, 1), "ms_per_batch_one": round(one * 1e3, 3), "ms_per_batch_two": round(two * 1e3, 3)}
+        out["configs[4] per-GPU shape, idle half of the chip given to the next batch"] = half
+        del lp128
+    except Exception as e:
+        out["configs[4] per-GPU shape, two launches in flight"] = {"error": str(e)[:200]}
     if os.path.exists(arpa) and getattr(ctcdecode_amd, "HAVE_LM", False):
         try:
             run("configs[4] per-GPU shape with the LM scorer (tests/data/test.arpa, alpha 0.5, beta 1.0)", 128, 1500, 29, 100,
                 model_path=arpa, alpha=0.5, beta=1.0)
         except Exception as e:  # the LM tier must not take the bench line down
             out["configs[4] with the LM scorer"] = {"error": str(e)[:200]}
+    if os.path.exists(arpa) and getattr(ctcdecode_amd, "HAVE_LM", False):
+        try:
+            out["scorer hook at the configs[4] per-GPU shape (tests/data/test.arpa behind a native callback)"] = time_scorer_hook(
+                torch, ctcdecode_amd, dev, arpa, ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)])
+        except Exception as e:
+            out["scorer hook (test.arpa)"] = {"error": str(e)[:300]}
     # the same shape with a language model of realistic size (generated: 50 000 words, 3-gram, ~20 MB of ARPA text; the
     # tables are tens of MB, so the kernel's look-ups miss L2 -- test.arpa's 37 unigrams never do)
     if getattr(ctcdecode_amd, "HAVE_LM", False):
@@ -371,6 +478,11 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
             if not os.path.exists(big):
                 mod.make(big)
             run("configs[4] per-GPU shape with a generated 50k-word 3-gram LM (alpha 0.5, beta 1.0)", 128, 1500, 29, 100, model_path=big, alpha=0.5, beta=1.0, reps=1)
+            try:
+                out["scorer hook at the configs[4] per-GPU shape (generated 50k-word model behind a native callback)"] = time_scorer_hook(
+                    torch, ctcdecode_amd, dev, big, ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)])
+            except Exception as e:
+                out["scorer hook (50k-word model)"] = {"error": str(e)[:300]}
         except Exception as e:
             out["configs[4] with the generated 50k-word LM"] = {"error": str(e)[:200]}
     return out
@@ -549,7 +661,7 @@ def main():
     if rank == 0:
         floor = sum(FRAME_FLOOR.values())
         frame_clocks = kern_ms * 1e-3 / T * SHADER_GHZ * 1e9
-        workload = {1: "BASELINE.json configs[1]: CTC prefix beam search, no LM, log-softmax of N(0,1) logits",
+        workload = {1: "BASELINE.json configs[1]: CTC prefix beam search, no LM, log-softmax of N(0,1) logits; HBM-resident tensors (input in HBM, the four result tensors left in HBM: `e2e` is the host-to-host call)",
                     2: "BASELINE.json configs[2]: B=2048 batch-sharded, beam 500, T=2000, no LM, compact RCCL gather",
                     4: "BASELINE.json configs[4]: B=1024 batch-sharded, beam 100, T=1500, LM scorer on tests/data/test.arpa (alpha 0.5, beta 1.0)"}[a.config]
         line = {
@@ -624,6 +736,12 @@ def main():
                                      "launches_in_flight": 3, "ms_per_batch": round(pl * 1e3, 3), "value": round(B / pl, 1), "unit": "utterances/s"}
             except Exception as e:
                 line["pipelined"] = {"error": str(e)[:200]}
+            try:
+                tw = time_inflight(torch, ctcdecode_amd, dev, lp, [str(i) for i in range(V)], K, 2, steps=20, warm=4)
+                line["two_in_flight"] = {"what": "the same batches through ctcdecode_amd.DecodePipeline, two launches in flight on two streams, DEFAULT build (one workgroup per CU, nothing shared): a launch lasts as long as its slowest utterance (the ones with the most exact nth_element replays: profiles/r05a_utt_spread.txt), the next batch's workgroups take the CUs the finished ones free.  An extra like `pipelined`: `value` times launches one at a time",
+                                         "ms_per_batch": round(tw * 1e3, 3), "value": round(B / tw, 1), "unit": "utterances/s"}
+            except Exception as e:
+                line["two_in_flight"] = {"error": str(e)[:200]}
             try:  # seeds {0, 1, 2} for the headline shape (kernel time by HIP events, three launches each)
                 vals = []
                 for sd in (0, 1, 2):

@@ -11,7 +11,7 @@ import torch
 from . import _native
 from ._native import NativeError  # noqa: F401
 
-__all__ = ["CTCBeamDecoder", "OnlineCTCBeamDecoder", "DecoderState", "NativeError", "CallbackScorer", "KenlmScorer"]
+__all__ = ["CTCBeamDecoder", "OnlineCTCBeamDecoder", "DecoderState", "NativeError", "CallbackScorer", "KenlmScorer", "DecodePipeline"]
 HAVE_LM = True  # the external-scorer tier (model_path / alpha / beta) is part of this build
 
 
@@ -79,6 +79,31 @@ class CallbackScorer(object):
         self.handle = h
         self.device_index = int(index)
         self.num_labels = len(labels)
+
+    @classmethod
+    def from_c(cls, fn_address, user_address, vocabulary, max_order, labels, alpha=0.0, beta=0.0, device=None, keepalive=None):
+        """The hook with a NATIVE callback: ``fn_address`` = address of a C function of type ``ctcd_cond_log10_fn``
+        (include/ctcdecode_amd.h: ``int fn(void *user, const char *const *words, int n, float *log10_prob)``), ``user_address``
+        its first argument -- e.g. a thin shim over kenlm's C++ API: no Python between the decoder and the model.
+        (``ctcd_scorer_cond_log10`` has this very signature: any built-in scorer can sit behind the hook -- bench.py does that to
+        price the hook itself.)  ``keepalive``: objects that must outlive the scorer."""
+        self = cls.__new__(cls)
+        if not torch.cuda.is_available():
+            raise RuntimeError("ctcdecode_amd: no HIP device visible; this decoder has no CPU path")
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._fn, self._error, self._keepalive = None, None, keepalive
+        self._c_fn = ctypes.cast(ctypes.c_void_p(int(fn_address)), _native.COND_LOG10_FN)
+        voc = [str(w).encode("utf-8") for w in vocabulary]
+        varr = (ctypes.c_char_p * max(len(voc), 1))(*voc)
+        larr = (ctypes.c_char_p * len(labels))(*[str(x).encode("utf-8") for x in labels])
+        h = ctypes.c_void_p()
+        _native.check(_native.lib.ctcd_scorer_create_callback(ctypes.byref(h), float(alpha), float(beta), int(max_order), varr, len(voc), self._c_fn,
+                                                              ctypes.c_void_p(int(user_address)) if user_address else None, larr, len(labels), int(index)))
+        self.handle = h
+        self.device_index = int(index)
+        self.num_labels = len(labels)
+        return self
 
     def callback_calls(self):
         """Distinct windows the callback has been asked for so far."""
@@ -435,6 +460,87 @@ class CTCBeamDecoder(object):
             except Exception:
                 pass
             self._handle = None
+
+
+class DecodePipeline(object):
+    """A serving loop's launches kept ``inflight`` at a time, each on a HIP stream and a decoder of its own (round 5).
+
+    One utterance occupies one workgroup -- one CU in the kernel's default build -- and the time axis of an utterance cannot
+    be split, so (a) a batch with fewer utterances than the GPU has CUs leaves the other CUs idle for the whole launch, and
+    (b) any launch lasts as long as its slowest utterance (the ones with the most exact ``std::nth_element`` replays: 10-15 %
+    above the mean on random rows) while the CUs of the finished ones idle.  With two launches in flight the next batch's
+    workgroups take those CUs: the rule is ``inflight_for(batch)`` = 2 below the CU count (``min_shard`` is the same rule
+    for ranks: ctcdecode_amd/distributed.py), and 2 is also what hides the stragglers of full batches.  No CU is shared:
+    this is the default build of the kernel (``cu_sharing=True`` asks for the two-workgroups-per-CU build instead, which
+    pays off from three full batches in flight: bench.py ``pipelined``).
+
+        pipe = DecodePipeline(lambda: CTCBeamDecoder(labels, beam_width=100, log_probs_input=True), inflight=2)
+        tickets = [pipe.submit(batch) for batch in batches]      # asynchronous; at most `inflight` are in flight
+        results = [pipe.result(t) for t in tickets]              # (output, scores, timesteps, out_lens) in HBM, in order
+
+    ``submit`` waits for the slot's previous launch if its result has not been collected yet; results must be collected in
+    submission order per slot (``result`` of an older ticket of the same slot after a newer submit raises).
+    """
+
+    def __init__(self, make_decoder, inflight=2, cu_sharing=False):
+        if inflight < 1:
+            raise ValueError("inflight must be at least 1")
+        self._decs = [make_decoder() for _ in range(inflight)]
+        self._device = self._decs[0]._device
+        for d in self._decs:
+            if d._device != self._device:
+                raise ValueError("DecodePipeline: every decoder must sit on the same device")
+            if cu_sharing:
+                d.set_cu_sharing(1)
+        self._streams = [torch.cuda.Stream(device=self._device) for _ in range(inflight)]
+        self._pending = [None] * inflight  # per slot: the ticket whose status has not been looked at
+        self._serial = 0
+
+    @staticmethod
+    def inflight_for(batch, device=None):
+        """2 when a batch leaves CUs idle (fewer utterances than CUs), else 1 -- the partition rule of DESIGN.md section 7."""
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        return 2 if batch < torch.cuda.get_device_properties(dev).multi_processor_count else 1
+
+    def submit(self, probs, seq_lens=None):
+        slot = self._serial % len(self._decs)
+        if self._pending[slot] is not None:
+            self._finish(self._pending[slot])
+        dec, stream = self._decs[slot], self._streams[slot]
+        stream.wait_stream(torch.cuda.current_stream(self._device))  # (the caller's tensors are ready on its own stream)
+        with torch.cuda.stream(stream):
+            res = dec.decode_device(probs, seq_lens, check=False)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        # (the launch reads the caller's tensors on the side stream: they stay referenced until it has finished -- a tensor
+        #  dropped by the caller right after submit() would otherwise go back to the caching allocator and be handed out again)
+        ticket = {"slot": slot, "serial": self._serial, "res": res, "event": ev, "batch": int(probs.shape[0]), "done": False,
+                  "inputs": (probs, seq_lens)}
+        self._pending[slot] = ticket
+        self._serial += 1
+        return ticket
+
+    def _finish(self, ticket):
+        if ticket["done"]:
+            return
+        if self._pending[ticket["slot"]] is not ticket:
+            raise RuntimeError("DecodePipeline: this ticket's slot has been resubmitted; collect results in submission order")
+        ticket["event"].synchronize()
+        self._decs[ticket["slot"]]._check(_native.lib.ctcd_check_status(self._decs[ticket["slot"]]._handle, ticket["batch"]))
+        ticket["done"] = True
+        ticket["inputs"] = None
+        self._pending[ticket["slot"]] = None
+
+    def result(self, ticket):
+        """The four HBM tensors of a submitted batch (waits for its launch; raises what ``decode_device`` would have raised)."""
+        self._finish(ticket)
+        torch.cuda.current_stream(self._device).wait_event(ticket["event"])
+        return ticket["res"]
+
+    def drain(self):
+        for t in list(self._pending):
+            if t is not None:
+                self._finish(t)
 
 
 class OnlineCTCBeamDecoder(object):

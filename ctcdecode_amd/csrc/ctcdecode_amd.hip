@@ -819,6 +819,9 @@ struct ctcd_decoder {
   int cu_sharing = -1;       // ctcd_set_cu_sharing: 1 = always launch the two-workgroups-per-CU build, 0 = never, -1 = when B > #CUs
   Buf pool, status, tables, logp, lsm, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
   Buf prune_in, prune_out, st_lens;  // own staging: the host-pointer entry points keep their tensors in stage_in/out
+  Buf cb_blocks, cb_ctl;             // scorer hook: the temporary streams' blocks of a one-shot decode; per-item control words
+  int32_t *h_cb = nullptr;           // ... and, page-locked, what a round reports: [status | frames done | #misses]
+  size_t h_cb_items = 0;
   long long prune_flagged_rows = 0;  // frames of the last call the fast prune pass flagged (settled by prune_resolve_kernel)
   unsigned *h_flagged = nullptr;     // page-locked: that count, copied behind the kernels
   bool flagged_pending = false;
@@ -836,6 +839,7 @@ struct ctcd_decoder {
   int subtree_mode = -1;
   bool subtree_on = false;       // the automatic choice for the next launch
   int last_subtree_search = 0;   // what the last launch used
+  int last_cb_rounds = 0;        // scorer hook: launches the last decode through a callback scorer took (ctcd_last_scorer_rounds)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // decode kernel | vocabulary-prune pass
   bool prune_timed = false;
   // streamed input of the host-tensor entry point: rows cross PCIe frame block by frame block while the kernel runs
@@ -884,6 +888,9 @@ struct ctcd_scorer {
   ctclm::CallbackLm *cbl = nullptr;
   char *cb_ng = nullptr, *cb_st = nullptr, *cb_uni = nullptr, *cb_miss = nullptr;  // cache slots | zeroed state arrays | NaN unigrams | miss list + counter
   size_t cb_ng_slots = 0, cb_st_cap = 0;
+  char *cb_stage = nullptr;  // dirty cache slots of a round, sent with ONE copy and scattered by a kernel: [indices | slots]
+  size_t cb_stage_cap = 0;   // ... slots it holds
+  std::vector<char> cb_stage_h;
   std::mutex cb_mu;          // one decode at a time mutates the cache
 };
 constexpr uint32_t kCbMissCap = 1u << 18;  // queued (state, word) pairs per round (2 MB); more are dropped and asked again
@@ -1000,6 +1007,8 @@ void ctcd_destroy(ctcd_decoder *d) {
   d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->lsm.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
   d->dbg.release(); d->tl.release();
+  d->cb_blocks.release(); d->cb_ctl.release();
+  if (d->h_cb) (void)hipHostFree(d->h_cb);
   d->c_hdr.release(); d->c_ent.release(); d->c_rag.release(); d->c_cnt.release(); d->c_sc.release(); d->c_ln.release();
   if (d->h_stage) (void)hipHostFree(d->h_stage);
   delete d->workers;
@@ -1445,7 +1454,7 @@ void ctcd_scorer_destroy(ctcd_scorer *s) {
   if (!s) return;
   DeviceGuard guard_(s->device);
   if (s->blob) (void)hipFree(s->blob);
-  for (char *p : {s->cb_ng, s->cb_st, s->cb_uni, s->cb_miss})
+  for (char *p : {s->cb_ng, s->cb_st, s->cb_uni, s->cb_miss, s->cb_stage})
     if (p) (void)hipFree(p);
   delete s->cbl;
   delete s;
@@ -1453,7 +1462,11 @@ void ctcd_scorer_destroy(ctcd_scorer *s) {
 
 // ---- the host-side scorer hook (binding.cpp:122-150 hands the decoder an opaque scorer; scorer.h:41-78 is its interface)
 // Brings the device copy of the cache up to date with the host's: whole tables after a rehash / growth, single slots otherwise.
-static int cb_sync(ctcd_scorer *s) {
+__global__ void cb_scatter_kernel(ctclm::NgSlot *ng, const uint32_t *idx, const ctclm::NgSlot *slots, unsigned n) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ng[idx[i]] = slots[i];
+}
+static int cb_sync(ctcd_scorer *s, hipStream_t stream = nullptr) {
   ctclm::CallbackLm &c = *s->cbl;
   ctclm::HostScorer &h = c.hs;
   if (c.rehashed || s->cb_ng_slots != h.ng.size()) {
@@ -1464,8 +1477,26 @@ static int cb_sync(ctcd_scorer *s) {
       s->cb_ng_slots = h.ng.size();
     }
     HIP_TRY(hipMemcpy(s->cb_ng, h.ng.data(), h.ng.size() * sizeof(ctclm::NgSlot), hipMemcpyHostToDevice));
-  } else {
-    for (uint32_t i : c.dirty) HIP_TRY(hipMemcpy(s->cb_ng + (size_t)i * sizeof(ctclm::NgSlot), &h.ng[i], sizeof(ctclm::NgSlot), hipMemcpyHostToDevice));
+  } else if (!c.dirty.empty()) {
+    // (round 5) the slots written since the last launch travel in ONE copy -- [their indices | the slots] -- and a kernel puts
+    // them in place.  (Rounds 1-4: one blocking 16-byte hipMemcpy per slot -- ~10 us each, 500 a round at the configs[4] shape:
+    // two thirds of a round's 8 ms.)
+    const size_t n = c.dirty.size();
+    if (s->cb_stage_cap < n) {
+      if (s->cb_stage) (void)hipFree(s->cb_stage);
+      s->cb_stage = nullptr;
+      const size_t cap = n * 2 + 1024;
+      HIP_TRY(hipMalloc((void **)&s->cb_stage, cap * (4 + sizeof(ctclm::NgSlot))));
+      s->cb_stage_cap = cap;
+    }
+    s->cb_stage_h.resize(n * (4 + sizeof(ctclm::NgSlot)));
+    uint32_t *hi = (uint32_t *)s->cb_stage_h.data();
+    ctclm::NgSlot *hsl = (ctclm::NgSlot *)(s->cb_stage_h.data() + n * 4);
+    for (size_t k = 0; k < n; ++k) { hi[k] = c.dirty[k]; hsl[k] = h.ng[c.dirty[k]]; }
+    HIP_TRY(hipMemcpy(s->cb_stage, s->cb_stage_h.data(), s->cb_stage_h.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(cb_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (ctclm::NgSlot *)s->cb_ng, (const uint32_t *)s->cb_stage,
+                       (const ctclm::NgSlot *)(s->cb_stage + n * 4), (unsigned)n);
+    HIP_TRY(hipGetLastError());
   }
   c.rehashed = false;
   c.dirty.clear();
@@ -1574,22 +1605,29 @@ long long ctcd_scorer_callback_calls(const ctcd_scorer *s) { return s && s->cbl 
 static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char *is_eos, const int32_t *lens, const float *probs, int B, int T, int V,
                      int beam, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer, int32_t *out_tok,
                      int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, int out_T, void *stream_) {
+  // (the callback runs under this lock: a callback that decodes with the same scorer deadlocks -- include/ctcdecode_amd.h)
   std::lock_guard<std::mutex> cache_lock(scorer->cb_mu);
   hipStream_t stream = (hipStream_t)stream_;
-  struct Scratch {
-    char *ctl = nullptr;
-    ~Scratch() { if (ctl) (void)hipFree(ctl); }
-  } mem;
-  HIP_TRY(hipMalloc((void **)&mem.ctl, (size_t)B * 12 + 256));  // [frame offsets | frames done | row lengths]
-  int *d_off = (int *)mem.ctl, *d_done = d_off + B, *d_rows = d_done + B;
+  int rc0;
+  if ((rc0 = d->cb_ctl.ensure((size_t)B * 12 + 256))) return rc0;  // [frame offsets | frames done | row lengths] (kept: no hipMalloc / hipFree per call)
+  int *d_off = (int *)d->cb_ctl.p, *d_done = d_off + B, *d_rows = d_done + B;
+  if (d->h_cb_items < (size_t)B) {
+    if (d->h_cb) (void)hipHostFree(d->h_cb);
+    d->h_cb = nullptr;
+    HIP_TRY(hipHostMalloc((void **)&d->h_cb, ((size_t)B * 2 + 4) * 4, hipHostMallocDefault));
+    d->h_cb_items = (size_t)B;
+  }
+  int32_t *st_h = d->h_cb, *fd_h = d->h_cb + B;
+  unsigned *nmiss_h = (unsigned *)(d->h_cb + 2 * (size_t)B);
   HIP_TRY(hipMemcpyAsync(d_rows, lens, (size_t)B * 4, hipMemcpyHostToDevice, stream));
-  std::vector<int32_t> done(B, 0), rem(B), st_h(B), fd_h(B);
+  std::vector<int32_t> done(B, 0), rem(B);
   std::vector<unsigned char> eos(B), finished(B, 0);
   std::vector<uint32_t> miss;
   int rc;
   for (int round = 0;; ++round) {
+    d->last_cb_rounds = round;
     if (round > 4 * T + 64) return fail(CTCD_EINTERNAL, "scorer hook: the decode does not make progress");
-    if ((rc = cb_sync(scorer))) return rc;
+    if ((rc = cb_sync(scorer, stream))) return rc;
     int left = 0;
     bool any_eos = false;
     for (int b = 0; b < B; ++b) {
@@ -1609,11 +1647,12 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
     if ((rc = decode_common(d, probs, nullptr, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok, out_ts, out_sc, out_len,
                             n_results, stream_, &sc, scorer)))
       return rc;
-    unsigned nmiss = 0;
-    HIP_TRY(hipMemcpyAsync(st_h.data(), d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(fd_h.data(), d_done, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&nmiss, scorer->cb_miss, 4, hipMemcpyDeviceToHost, stream));
+    // (one page-locked block: the three reports arrive behind the launch without staging copies)
+    HIP_TRY(hipMemcpyAsync(st_h, d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(fd_h, d_done, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(nmiss_h, scorer->cb_miss, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    const unsigned nmiss = *nmiss_h;
     bool need = false;
     for (int b = 0; b < B; ++b) {
       if (finished[b]) continue;
@@ -1652,25 +1691,24 @@ static int decode_lm_callback(ctcd_decoder *d, const float *probs, const int32_t
   }
   const long long capf = T > 0 ? T : 1;
   const size_t blk = (stream_block_bytes(capf, beam) + 255) / 256 * 256;
-  struct Scratch {
-    char *blocks = nullptr;
-    ~Scratch() { if (blocks) (void)hipFree(blocks); }
-  } mem;
-  HIP_TRY(hipMalloc((void **)&mem.blocks, blk * (size_t)B));
+  // (round 5: the blocks stay with the decoder -- rounds 1-4 allocated and freed them in every call, 384 MB at the configs[4]
+  //  shape, and zeroed them with two memsets per utterance: a warm cache cost three times the built-in tables' decode)
+  int rcb;
+  if ((rcb = d->cb_blocks.ensure(blk * (size_t)B))) return rcb;
+  char *blocks = (char *)d->cb_blocks.p;
   std::vector<ctcd_stream> sts(B);
   std::vector<ctcd_stream *> states(B);
   for (int b = 0; b < B; ++b) {
     ctcd_stream &st = sts[b];
-    st.device = d->device; st.scorer = scorer; st.block = mem.blocks + (size_t)b * blk; st.bytes = blk; st.V = V; st.beam = beam; st.frames = 0; st.cap_frames = capf;
+    st.device = d->device; st.scorer = scorer; st.block = blocks + (size_t)b * blk; st.bytes = blk; st.V = V; st.beam = beam; st.frames = 0; st.cap_frames = capf;
     states[b] = &st;
-    HIP_TRY(hipMemsetAsync(st.block, 0, stream_pool_offset(beam), stream));  // frames == 0: the first launch initialises the beam
-    HIP_TRY(hipMemsetAsync(st.block + stream_thi_offset(capf, beam), 0, stream_nodes(capf, beam) * sizeof(int), stream));
   }
+  // frames == 0: the first launch initialises the beam; the high parts of the nodes' time steps start at zero
+  HIP_TRY(hipMemset2DAsync(blocks, blk, 0, stream_pool_offset(beam), (size_t)B, stream));
+  HIP_TRY(hipMemset2DAsync(blocks + stream_thi_offset(capf, beam), blk, 0, stream_nodes(capf, beam) * sizeof(int), (size_t)B, stream));
   const std::vector<unsigned char> eos(B, 1);
-  const int rc = cb_rounds(d, states.data(), eos.data(), len.data(), probs, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, scorer, out_tok,
-                           out_ts, out_sc, out_len, n_results, T, stream_);
-  (void)hipStreamSynchronize(stream);  // (the blocks are freed on return)
-  return rc;
+  return cb_rounds(d, states.data(), eos.data(), len.data(), probs, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, scorer, out_tok,
+                   out_ts, out_sc, out_len, n_results, T, stream_);
 }
 
 int ctcd_beam_decode_lm(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
@@ -2166,6 +2204,7 @@ int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, u
 // Number of frames of the last ctcd_beam_decode whose vocabulary prune was resolved on the host: none, ever (kept for callers
 // of earlier rounds; the host path is gone).
 long long ctcd_last_prune_host_rows(ctcd_decoder *d) { return d ? 0 : -1; }
+int ctcd_last_scorer_rounds(ctcd_decoder *d) { return d ? d->last_cb_rounds : -1; }
 // ... and the number the fast prune pass flagged (settled by the device's std::sort replay + exact cumulative chain).  The
 // count arrives behind the call's kernels: asking for it waits for the launch stream.
 long long ctcd_last_prune_flagged_rows(ctcd_decoder *d) {

@@ -49,10 +49,10 @@ int ctcd_create(ctcd_decoder **out, int device_id);
 void ctcd_destroy(ctcd_decoder *dec);
 
 /* Decode a batch whose tensors all live in the HBM of the decoder's device.  Asynchronous on `stream` -- call
- * hipStreamSynchronize (or ctcd_check_status / ctcd_fetch_status_async) before reading -- except that the two pre-passes
- * read their exception counters back before the decode kernel is queued: vocabulary pruning (cutoff_top_n < V or
- * cutoff_prob < 1: frames flagged for the std::sort replay / the host toolchain) and probability input (log_input == 0:
- * elements whose log rounds ambiguously); see DESIGN.md 5. */
+ * hipStreamSynchronize (or ctcd_check_status / ctcd_fetch_status_async) before reading.  Nothing is read back or decided on
+ * the host in between: the pre-passes (vocabulary pruning when cutoff_top_n < V or cutoff_prob < 1, with its std::sort replay
+ * of the frames the fast pass flags; the probability -> log conversion when log_input == 0, binary64 log restated for the
+ * device) and the decode kernel are queued behind each other on `stream`; see DESIGN.md 5. */
 int ctcd_beam_decode(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                      int num_processes /* accepted for signature parity; unused on the GPU */, double cutoff_prob,
                      int cutoff_top_n, int blank_id, int log_input, int32_t *out_tokens, int32_t *out_timesteps,
@@ -139,8 +139,13 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *w
  *   ctcd_beam_decode_to_host and ctcd_stream_create_lm / ctcd_stream_decode; ctcd_beam_decode_compact refuses it.
  *   Not supported with it (CTCD_EUNSUPPORTED): rows that hold +-inf or overflow float32 sums; beams whose workspace does not fit
  *   one workgroup's LDS (the wide-beam layouts: beyond roughly beam_width * (candidates + 2) = 20 000 slots).
- *   Decodes that share one callback scorer are serialised (its cache is one object); a ctcd_stream_decode call that fails
- *   half-way (the callback reported an error) leaves the streams of that call unusable: destroy them.
+ *   Decodes that share one callback scorer are serialised (its cache is one object) and the callback runs under that lock:
+ *   a callback that itself decodes with the same scorer deadlocks.  A ctcd_stream_decode call that fails half-way (the
+ *   callback reported an error) leaves the streams of that call unusable: destroy them.
+ *   Cost: a warm cache decodes in one launch, like the built-in tables; every round of misses is one more launch plus the
+ *   callback's own time, and an utterance can miss once per frame in which a prefix completes a word it has not asked about
+ *   (bench.py "scorer hook": random rows under a 5-gram model miss in nearly every frame -- hundreds of launches; real
+ *   transcripts revisit few histories).  ctcd_last_scorer_rounds tells how many launches the last call took.
  * ctcd_scorer_cond_log10 evaluates any scorer in the callback's own form (so the built-in tables can sit behind one);
  * ctcd_scorer_callback_calls counts the callback invocations so far (= distinct windows cached). */
 typedef int (*ctcd_cond_log10_fn)(void *user, const char *const *words, int n, float *log10_prob);
@@ -148,6 +153,9 @@ int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, in
                                 int n_vocabulary, ctcd_cond_log10_fn fn, void *user, const char *const *labels, int V, int device_id);
 int ctcd_scorer_cond_log10(const ctcd_scorer *scorer, const char *const *words, int n, float *log10_prob);
 long long ctcd_scorer_callback_calls(const ctcd_scorer *scorer);
+/* launches the decoder's last call through a callback scorer took (1 = the cache held everything; one more per round of
+ * misses): what a cold / lukewarm cache costs (bench.py "scorer hook") */
+int ctcd_last_scorer_rounds(ctcd_decoder *dec);
 
 int ctcd_beam_decode_lm(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                         int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer,

@@ -53,7 +53,13 @@ struct HostX {
   template <class P> const P *fresh(const P *p) const { return p; }
   // event statistics (beam_core.h Event): summed over every decode of the process, read by ctccore_event_counts()
   static long long *counters() { static long long c[ctcbeam::EV_COUNT]; return c; }
-  void count(int k, int v) const { counters()[k] += v; }
+  static int &cur_frame() { static int t = 0; return t; }
+  void count(int k, int v) const {
+    counters()[k] += v;
+    // CTC_HOST_TRACE_EXACT=1: print the frames that replay std::nth_element (finding a tie frame for tools/barrier_timeline.py)
+    static const bool trace = getenv("CTC_HOST_TRACE_EXACT") != nullptr;
+    if (trace && k == ctcbeam::EV_EXACT) fprintf(stderr, "exact replay at frame %d\n", cur_frame());
+  }
   void tick() {}
   // speculative select (beam_core.h Decoder::kSpec), sequentially: the same contract as the device policy's
   static constexpr bool kSpecSelect = true;
@@ -92,6 +98,7 @@ struct HostX {
   }
   // CTC_DUMP_KEYS=<file>: every frame's slot keys, for offline studies of the select
   void probe_keys(int t, int S, const uint32_t *skey, int K, uint32_t maxkey, const float *clp, int Vc) const {
+    cur_frame() = t;
     static FILE *f = getenv("CTC_DUMP_KEYS") ? fopen(getenv("CTC_DUMP_KEYS"), "wb") : nullptr;
     if (!f) return;
     float mx = clp[0];

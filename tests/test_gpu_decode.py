@@ -979,3 +979,29 @@ def test_subtree_search_build_is_chosen_by_beam_shape_and_changes_nothing(torch_
     assert dec.last_subtree_search() == 1
     dec.decode_device(xr)
     assert dec.last_subtree_search() == 0          # ... and that one bushes
+
+
+def test_decode_pipeline_two_launches_in_flight(torch_mod):
+    """ctcdecode_amd.DecodePipeline (a batch smaller than the CU count leaves CUs idle -- the next batch is
+    launched beside it on a second stream, default build of the kernel): every batch's results equal the oracle's whatever the
+    number of launches in flight, tickets may be collected late, a resubmitted slot's old ticket is refused, and the rule
+    inflight_for() follows the CU count."""
+    import ctcdecode_amd
+
+    torch = torch_mod
+    V, K, T = 29, 24, 90
+    labels = [str(i) for i in range(V)]
+    lps = [ou.synth_logprobs(3 + (i % 3), T, V, 9100 + i) for i in range(7)]
+    wants = [ou.decode(lp, beam=K) for lp in lps]
+    for inflight in (1, 2, 3):
+        pipe = ctcdecode_amd.DecodePipeline(lambda: ctcdecode_amd.CTCBeamDecoder(labels, beam_width=K, log_probs_input=True, device="cuda:0"), inflight=inflight)
+        tickets = [pipe.submit(torch.from_numpy(lp).cuda()) for lp in lps]
+        # (tickets of a slot that has been resubmitted were finished -- their status checked -- when the slot was reused:
+        #  their results stay valid and can still be fetched)
+        for i, tk in enumerate(tickets):
+            out, sc, ts, ln = pipe.result(tk)
+            got = dict(tokens=out.cpu().numpy(), timesteps=ts.cpu().numpy(), scores=sc.cpu().numpy(), lens=ln.cpu().numpy())
+            ou.assert_same(_with_nres(got, wants[i]), wants[i], "pipeline inflight=%d batch %d" % (inflight, i))
+        pipe.drain()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert ctcdecode_amd.DecodePipeline.inflight_for(ncu // 2) == 2 and ctcdecode_amd.DecodePipeline.inflight_for(ncu) == 1
