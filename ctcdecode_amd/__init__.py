@@ -5,6 +5,7 @@ ctcdecode/__init__.py:6-123 of the reference; the prefix beam search itself runs
 (one workgroup per utterance, beam in LDS) behind the C ABI in include/ctcdecode_amd.h.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -605,9 +606,11 @@ class OnlineCTCBeamDecoder(object):
         K = self._beam_width
         # (a serving loop calls this once per chunk with the same states: the per-call host work is kept small -- the array of
         #  state handles is rebuilt only when the list changes, nothing is allocated or read back unless a stream ends)
+        # (the cache holds WEAK references: a strong list kept ended streams' HBM blocks alive until the next call with other
+        #  states, and tied decoder and states into a cycle of objects with finalisers -- ADVICE r4)
         cache = getattr(self, "_ptr_cache", None)
-        if cache is None or len(cache[0]) != B or any(a is not b for a, b in zip(cache[0], states)):
-            cache = (list(states), (ctypes.c_void_p * max(B, 1))(*[st._ptr(self) for st in states]))
+        if cache is None or len(cache[0]) != B or any(r() is not st for r, st in zip(cache[0], states)):
+            cache = ([weakref.ref(st) for st in states], (ctypes.c_void_p * max(B, 1))(*[st._ptr(self) for st in states]))
             self._ptr_cache = cache
         ptrs = cache[1]
         any_eos = any(is_eos_s)
@@ -634,6 +637,8 @@ class OnlineCTCBeamDecoder(object):
                 output.data_ptr(), timesteps.data_ptr(), scores.data_ptr(), out_len.data_ptr(), nres.data_ptr(), out_T, stream))
             if check or any_eos:
                 _native.check(_native.lib.ctcd_check_status(self._handle, B))
+        if any_eos:
+            self._ptr_cache = None  # (ended streams are not decoded again: the next call brings other states)
         if not any_eos:  # nothing ended: no results (binding.cpp:186-205 sizes them to the most results of any item: none)
             return (torch.zeros((B, 0, 0), dtype=torch.int32), torch.zeros((B, K), dtype=torch.float32),
                     torch.zeros((B, 0, 0), dtype=torch.int32), torch.zeros((B, K), dtype=torch.int32))

@@ -2065,7 +2065,15 @@ struct Decoder {
             total += lm_cond_(&st, &cl, lm->w_bos);
           } else if (partial) {
             total += wcond;
-            if (word_here) { st = (uint32_t)b.spst[a]; cl = b.spcl[a]; } else { st = 0; cl = 0; }
+            if (word_here) { st = (uint32_t)b.spst[a]; cl = b.spcl[a]; }
+            else {
+              // the word is not in the vocabulary: the window of "</s>" starts behind it.  (Orders above 1: an unknown word
+              // inside the window makes it OOV without a query.  A callback scorer of order 1 -- windows of one word, no
+              // history -- does query: from ITS empty history, lm->s0; state 0 is the built-in automaton's and never a key of
+              // the callback's cache: ADVICE r4.)
+              st = (lm_cb && lm->clean0 == 0) ? lm->s0 : 0u;
+              cl = 0;
+            }
           }
           total += lm_cond_(&st, &cl, lm->w_eos);
           double ap = (double)e;

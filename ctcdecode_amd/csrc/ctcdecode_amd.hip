@@ -1103,7 +1103,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
 
   // outputs: everything outside the valid region is defined as 0
   const size_t kt = co ? 0 : (size_t)B * beam * out_T;
-  if (co) {
+  if (co && !(sc && sc->no_clear)) {  // (resumed launches of the scorer hook: the records of items that finished earlier stay)
     HIP_TRY(hipMemsetAsync(co->count, 0, 4, stream));
     HIP_TRY(hipMemsetAsync(co->hdr, 0, (size_t)B * 16, stream));
   }
@@ -1236,6 +1236,10 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     HIP_TRY(hipLaunchKernel(pfn, dim3(blocks_launch), dim3(wpb * 64), pargs, psm_launch, stream));
     HIP_TRY(hipGetLastError());
     if (d->timing) { HIP_TRY(hipEventRecord(d->ev3, stream)); d->prune_timed = true; }
+    // (prune_resolve_kernel keeps positions and counters in 16 bits: the refusal of pruning with more than 32767 labels above is
+    //  what guarantees they fit -- said here, next to the launch, so that the two cannot drift apart: ADVICE r4)
+    static_assert(kResolveMaxV >= 32767, "prune_resolve_kernel's 16-bit positions must cover every vocabulary the prune pass accepts");
+    if (V > kResolveMaxV) return fail(CTCD_EUNSUPPORTED, "vocabulary pruning: too many labels for the std::sort replay's 16-bit positions");
     hipLaunchKernelGGL(prune_resolve_kernel, dim3(rblocks), dim3(kResolveThreads), in_lds ? rbytes : 0, stream, pa, in_lds ? (char *)nullptr : (char *)d->prune_in.p, rstride);
     HIP_TRY(hipGetLastError());
     // (statistics only: the number of flagged frames travels to page-locked memory behind the kernels; whoever asks for it
@@ -1604,7 +1608,7 @@ long long ctcd_scorer_callback_calls(const ctcd_scorer *s) { return s && s->cbl 
 // own time; a warm cache needs one launch.
 static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char *is_eos, const int32_t *lens, const float *probs, int B, int T, int V,
                      int beam, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer, int32_t *out_tok,
-                     int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, int out_T, void *stream_) {
+                     int32_t *out_ts, float *out_sc, int32_t *out_len, int32_t *n_results, int out_T, void *stream_, const CompactOut *co = nullptr) {
   // (the callback runs under this lock: a callback that decodes with the same scorer deadlocks -- include/ctcdecode_amd.h)
   std::lock_guard<std::mutex> cache_lock(scorer->cb_mu);
   hipStream_t stream = (hipStream_t)stream_;
@@ -1645,7 +1649,7 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
     sc.frames_done = d_done;
     sc.row_lens = d_rows;
     if ((rc = decode_common(d, probs, nullptr, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok, out_ts, out_sc, out_len,
-                            n_results, stream_, &sc, scorer)))
+                            n_results, stream_, &sc, scorer, co)))
       return rc;
     // (one page-locked block: the three reports arrive behind the launch without staging copies)
     HIP_TRY(hipMemcpyAsync(st_h, d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
@@ -1678,7 +1682,7 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
 // ... for a whole batch: temporary streams in one allocation, a block per utterance sized for all T frames
 static int decode_lm_callback(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam, double cutoff_prob,
                               int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer, int32_t *out_tok, int32_t *out_ts,
-                              float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
+                              float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_, const CompactOut *co = nullptr) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   if (B <= 0 || T < 0 || beam <= 0 || beam > kMaxBeam) return B == 0 ? CTCD_OK : fail(CTCD_EINVAL, "bad arguments");
   CTC_ON_DEVICE(d->device);
@@ -1708,7 +1712,7 @@ static int decode_lm_callback(ctcd_decoder *d, const float *probs, const int32_t
   HIP_TRY(hipMemset2DAsync(blocks + stream_thi_offset(capf, beam), blk, 0, stream_nodes(capf, beam) * sizeof(int), (size_t)B, stream));
   const std::vector<unsigned char> eos(B, 1);
   return cb_rounds(d, states.data(), eos.data(), len.data(), probs, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, scorer, out_tok,
-                   out_ts, out_sc, out_len, n_results, T, stream_);
+                   out_ts, out_sc, out_len, n_results, T, stream_, co);
 }
 
 int ctcd_beam_decode_lm(ctcd_decoder *d, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
@@ -1832,8 +1836,12 @@ int ctcd_beam_decode_compact(ctcd_decoder *d, const float *probs, const int32_t 
                              ctcd_scorer *scorer, int32_t *c_hdr, int32_t *c_ent, uint32_t *c_labels, uint32_t *c_count,
                              long long label_capacity, float *out_sc, int32_t *out_len, int32_t *n_results, void *stream_) {
   if (!c_hdr || !c_ent || !c_labels || !c_count || label_capacity <= 0) return fail(CTCD_EINVAL, "compact buffers missing");
-  if (scorer && scorer->cbl) return fail(CTCD_EUNSUPPORTED, "compact results with a callback scorer (decode into the padded tensors: ctcd_beam_decode_lm)");
   CompactOut co{c_hdr, c_ent, c_labels, c_count, (unsigned)std::min<long long>(label_capacity, 0xFFFFFFFFLL)};
+  // (round 5) a callback scorer: launch after launch like the padded form; an utterance hands its compact records over in the
+  // launch it finishes in, the buffers and their bump allocator carry over from launch to launch
+  if (scorer && scorer->cbl)
+    return decode_lm_callback(d, probs, seq_lens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, scorer, nullptr, nullptr, out_sc, out_len,
+                              n_results, stream_, &co);
   return decode_common(d, probs, seq_lens, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, out_sc,
                        out_len, n_results, stream_, nullptr, scorer, &co);
 }

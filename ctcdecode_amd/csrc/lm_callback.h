@@ -134,6 +134,11 @@ struct CallbackLm {
     ++queries;
     if (rc < 0) return hs.fail("scorer hook: the callback reported an error");
     if (rc == 0 && !(p10 == p10)) return hs.fail("scorer hook: the callback returned NaN");
+    // (an out-of-vocabulary answer is cached as -inf: a callback that reports a probability of zero that way must say
+    //  "out of vocabulary" -- return 1 -- or a finite floor instead; silently turning its -inf into OOV_SCORE would not be what
+    //  the reference computes from it -- ADVICE r4)
+    if (rc == 0 && (p10 > std::numeric_limits<float>::max() || p10 < -std::numeric_limits<float>::max()))
+      return hs.fail("scorer hook: the callback returned an infinite log-probability (return 1 for windows with unknown words, a finite value otherwise)");
     if (rc != 0) p10 = -std::numeric_limits<float>::infinity();
     NgSlot s;
     s.state = state; s.word = word;

@@ -127,7 +127,8 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *w
  *   fn(user, words, n, &log10_prob): the window's n = max_order words, oldest first, "<s>"-padded as make_ngram pads them;
  *     store log10 p(words[n-1] | words[0..n-2]) as float32 -- what kenlm's BaseScore returns, the decoder applies the
  *     reference's conversion p / NUM_FLT_LOGE (scorer.cpp:92) -- and return 0; return 1 if the window holds a word the model
- *     does not know (the reference's OOV_SCORE, scorer.cpp:86-88); return < 0 to fail the decode.  Must be a pure function
+ *     does not know (the reference's OOV_SCORE, scorer.cpp:86-88); return < 0 to fail the decode.  The value must be
+ *     finite (NaN or +-inf with return code 0 fails the decode: -inf is how the cache marks an OOV answer).  Must be a pure function
  *     of the words: answers are cached on the device ((history, word) -> log10 prob, the same tables the built-in scorer
  *     queries inside the kernel) and each distinct window is asked for once per scorer.  Called on the thread that calls
  *     the decode, between kernel launches: a launch runs until an utterance needs a window that is not cached, parks that
@@ -136,7 +137,8 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *w
  *     dictionary of a word model; all entries single characters <=> character model (scorer.cpp:65-71).
  *   Results equal those of a scorer that knew every answer from the start (tests/test_gpu_lm.py: the built-in tables behind
  *   the callback give bit-identical output).  Accepted by ctcd_beam_decode_lm, ctcd_beam_decode_lm_host,
- *   ctcd_beam_decode_to_host and ctcd_stream_create_lm / ctcd_stream_decode; ctcd_beam_decode_compact refuses it.
+ *   ctcd_beam_decode_to_host, ctcd_beam_decode_compact (since round 5: the compact multi-GPU gather works with it) and
+ *   ctcd_stream_create_lm / ctcd_stream_decode.
  *   Not supported with it (CTCD_EUNSUPPORTED): rows that hold +-inf or overflow float32 sums; beams whose workspace does not fit
  *   one workgroup's LDS (the wide-beam layouts: beyond roughly beam_width * (candidates + 2) = 20 000 slots).
  *   Decodes that share one callback scorer are serialised (its cache is one object) and the callback runs under that lock:

@@ -370,7 +370,8 @@ def test_scorer_hook_batch_with_pruning_and_streaming(torch_mod):
 
 def test_scorer_hook_callback_decides_vocabulary_and_errors_propagate(torch_mod):
     """The callback -- not the tables -- decides what is out of vocabulary (None -> the reference's OOV_SCORE); an exception inside
-    it fails the decode and is re-raised; the compact entry point refuses a callback scorer."""
+    it fails the decode and is re-raised; the compact entry point gives the padded form's results (round 5); an infinite
+    answer is refused."""
     import ctcdecode_amd
 
     labels = ["_", "a", "b", " "]
@@ -388,8 +389,17 @@ def test_scorer_hook_callback_decides_vocabulary_and_errors_propagate(torch_mod)
     # host build of the same core in tests/test_lm.py; here: determinism + the warm cache giving the same answer)
     out2, scs2, _, _ = dec.decode(x)
     assert np.array_equal(scs.numpy().view(np.uint32), scs2.numpy().view(np.uint32)) and np.array_equal(out.numpy(), out2.numpy())
-    with pytest.raises(NotImplementedError):
-        dec.decode_compact(x)
+    # (round 5) the compact result form takes a callback scorer too: same results as the padded form
+    hdr, ent, labs, csc, cln = dec.decode_compact(x)
+    cout, cts = dec.expand_compact(hdr, ent, labs, x.shape[1])
+    assert np.array_equal(cout.cpu().numpy(), out.numpy()) and np.array_equal(csc.cpu().numpy().view(np.uint32), scs.numpy().view(np.uint32))
+    assert np.array_equal(cln.cpu().numpy(), ln.numpy()) and np.array_equal(cts.cpu().numpy(), ts.numpy())
+
+    # a callback must answer with a finite value (or None): -inf is how the cache marks "out of vocabulary" 
+    sc_inf = ctcdecode_amd.CallbackScorer(lambda words: float("-inf"), ["a", "aa"], 2, labels)
+    dec_inf = ctcdecode_amd.CTCBeamDecoder(labels, scorer=sc_inf, beam_width=8, log_probs_input=True)
+    with pytest.raises(Exception, match="infinite"):
+        dec_inf.decode(x)
 
     class Boom(Exception):
         pass
@@ -424,3 +434,46 @@ def test_kenlm_scorer_matches_builtin_tables(torch_mod):
     got = [t.numpy() for t in dec.decode(x)]
     for g, w in zip(got, want):
         assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+
+
+def test_scorer_hook_compact_results_cold_cache_and_order_one(torch_mod):
+    """Round 5: (a) decode_compact through a callback scorer with a COLD cache -- utterances finish in different launches, their
+    compact records accumulate across the launches -- equals the built-in scorer's compact results item by item; (b) an order-1
+    word model behind the hook (the "</s>" window of a prefix that ends in a non-word) equals the built-in tables."""
+    import ctcdecode_amd
+
+    B, T, V, K = 12, 70, 29, 24
+    lp = ou.synth_logprobs(B, T, V, 515, blank_bias=1.0)
+    lp[:, :, LABELS29.index(" ")] += np.float32(1.5)
+    m = lp.max(-1, keepdims=True)
+    lp = (lp - (m + np.log(np.exp(lp - m).sum(-1, keepdims=True)))).astype(np.float32)
+    sl = np.random.default_rng(6).integers(0, T + 1, size=B).astype(np.int32)
+    x, xs = torch_mod.from_numpy(lp), torch_mod.from_numpy(sl)
+    inner = _BuiltinBehindCallback(dict(labels=LABELS29, lm_path=TEST_ARPA))
+    try:
+        ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.7, beta=0.9, beam_width=K, cutoff_top_n=V, log_probs_input=True)
+        want = [t.cpu().numpy() for t in ref.decode_device(x, xs)]
+        sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, LABELS29, alpha=0.7, beta=0.9)
+        dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc, beam_width=K, cutoff_top_n=V, log_probs_input=True)
+        hdr, ent, labs, csc, cln = dec.decode_compact(x, xs)
+        assert sc.callback_calls() > 0 and int(ctcdecode_amd._native.lib.ctcd_last_scorer_rounds(dec._handle)) > 1
+        cout, cts = dec.expand_compact(hdr, ent, labs, T)
+        for g, w in zip((cout, csc, cts, cln), want):
+            assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
+    finally:
+        inner.close()
+    arpa1 = os.path.join(gu.DATA_DIR, "unigram_bo.arpa")
+    labs4 = ["_", " ", "a", "b"]
+    inner = _BuiltinBehindCallback(dict(labels=labs4, lm_path=arpa1))
+    try:
+        lp4 = ou.synth_logprobs(6, 40, 4, 77, blank_bias=1.0)
+        ref = ctcdecode_amd.CTCBeamDecoder(labs4, model_path=arpa1, alpha=0.8, beta=0.5, beam_width=16, log_probs_input=True)
+        want = [t.numpy() for t in ref.decode(torch_mod.from_numpy(lp4))]
+        sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, labs4, alpha=0.8, beta=0.5)
+        assert inner.order == 1
+        dec = ctcdecode_amd.CTCBeamDecoder(labs4, scorer=sc, beam_width=16, log_probs_input=True)
+        got = [t.numpy() for t in dec.decode(torch_mod.from_numpy(lp4))]
+        for g, w in zip(got, want):
+            assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    finally:
+        inner.close()

@@ -374,3 +374,19 @@ def test_scorer_hook_random_sweep():
         a = ou.decode_core_host_lm(lp, alpha, beta, arpa, labs, seq_lens=sl, beam=K, cutoff_top_n=V, threads=1)
         b = ou.decode_core_host_lm_cb(lp, alpha, beta, arpa, labs, seq_lens=sl, beam=K)
         ou.assert_same(b, a, "it %d %s" % (it, os.path.basename(arpa)))
+
+
+def test_scorer_hook_order_one_word_model():
+    """a callback scorer of order 1 (windows of one word, no history) over a WORD model -- a prefix that ends in a
+    partial non-word scores its "</s>" window from the callback's empty history, not from the built-in automaton's state 0
+    (which is never a key of the callback's cache: the decode used to fail with "a query that cannot exist")."""
+    arpa = os.path.join(gu.DATA_DIR, "unigram_bo.arpa")
+    labs = ["_", " ", "a", "b"]
+    rng = np.random.default_rng(5)
+    for it in range(12):
+        T, K = int(rng.integers(1, 50)), int(rng.choice([1, 4, 12, 30]))
+        lp = ou.synth_logprobs(2, T, len(labs), 300 + it, blank_bias=float(rng.choice([0.0, 2.0])))
+        alpha, beta = float(rng.choice([0.5, 1.3])), float(rng.choice([0.0, 1.0, -0.7]))
+        a = ou.decode_core_host_lm(lp, alpha, beta, arpa, labs, beam=K, cutoff_top_n=len(labs), threads=1)
+        b = ou.decode_core_host_lm_cb(lp, alpha, beta, arpa, labs, beam=K)
+        ou.assert_same(b, a, "order-1 hook, case %d" % it)
