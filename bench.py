@@ -67,8 +67,10 @@ def parse():
     ap.add_argument("--backend", default="", help="torch.distributed backend (default nccl = RCCL; gloo when ranks share a device)")
     ap.add_argument("--min-shard", type=int, default=0, help="configs 2 / 4 (strong scaling): at least this many utterances per rank -- fill a GPU (256 = its CU count) "
                     "before adding ranks; the ranks left over get empty shards (ctcdecode_amd.distributed.shard_size)")
-    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run: two rocprofv3 --pmc child runs of this script (FETCH_SIZE, "
-                    "WRITE_SIZE: counters only, one per pass, as MI355X_MICROARCH.md prescribes) instead of the constant in --traffic-json")
+    ap.add_argument("--pmc", action="store_true", default=True, help="(default since round 5) measure roofline.traffic in this run: two rocprofv3 --pmc child runs of "
+                    "tools/pmc_child.py (FETCH_SIZE, WRITE_SIZE: counters only, one per pass, as MI355X_MICROARCH.md prescribes; ~8 s each, outside the "
+                    "timed region); the constant in --traffic-json is the fallback when the profiler is missing or fails")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="use the committed constant (--traffic-json) for roofline.traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e and other_configs measurements (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
@@ -86,6 +88,8 @@ def measure_traffic(a):
     import shutil
     import tempfile
 
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this run is itself being profiled: no nested counter passes"
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
@@ -94,10 +98,10 @@ def measure_traffic(a):
     try:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, c)
-            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--batch", str(a.batch), "--frames", str(a.frames), "--vocab", str(a.vocab),
-                   "--beam", str(a.beam), "--threads", str(a.threads)]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            # (the child decodes the same batch -- same generator, same seed -- four times and does nothing else: tools/pmc_child.py)
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "pmc_child.py"), str(a.batch or 256), str(a.frames or 1000), str(a.vocab), str(a.beam or 100), str(a.threads)]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             vals = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -269,7 +273,34 @@ def arpa_unigrams(path):
     return words
 
 
-def time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, B=128, T=1500, K=100, alpha=0.5, beta=1.0):
+def synth_transcript_rows(torch, B, T, labels, words, seed, boost=7.0):
+    """Rows that look like the posteriors of an acoustic model reading sentences: every utterance spells a random sequence of
+    the vocabulary's words (each label held for 2-4 frames, blanks between repeated letters and now and then elsewhere, a space
+    between words) with +`boost` on the intended label over N(0,1) logits.  The beam then follows word sequences, as it does on
+    speech -- N(0,1) rows make it wander through every word history there is."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    idx = {c: i for i, c in enumerate(labels)}
+    usable = [w for w in words if w and all(c in idx for c in w) and " " not in w]
+    lg = torch.randn((B, T, len(labels)), generator=g)
+    for b in range(B):
+        t, prev = 0, None
+        while t < T:
+            w = usable[int(torch.randint(0, len(usable), (1,), generator=g))] + " "
+            for c in w:
+                if c == prev or int(torch.randint(0, 4, (1,), generator=g)) == 0:  # a blank between equal letters, sometimes elsewhere
+                    n = int(torch.randint(1, 3, (1,), generator=g))
+                    lg[b, t:t + n, 0] += boost
+                    t += n
+                n = int(torch.randint(2, 5, (1,), generator=g))
+                lg[b, t:t + n, idx[c]] += boost
+                t += n
+                prev = c
+                if t >= T:
+                    break
+    return lg.log_softmax(-1)
+
+
+def time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, B=128, T=1500, K=100, alpha=0.5, beta=1.0, transcripts=False):
     """what the host-side scorer hook costs at the configs[4] per-GPU shape.  The built-in tables of `arpa`
     sit behind the hook as a NATIVE callback (ctcd_scorer_cond_log10 has the callback's signature: no Python in the loop), so
     results and cache contents are the built-in scorer's and the difference in time is the hook's: cold (fresh scorer: every
@@ -279,13 +310,17 @@ def time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, B=128, T=1500, K=1
 
     n = ctcdecode_amd._native
     V = len(labels)
-    lps = [synth_rows(torch, B, T, V, 7 + i).to(dev) for i in range(2)]
+    if transcripts:
+        voc = [w for w in arpa_unigrams(arpa) if w not in ("<s>", "</s>", "<unk>")]
+        lps = [synth_transcript_rows(torch, B, T, labels, voc, 7 + i).to(dev) for i in range(2)]
+    else:
+        lps = [synth_rows(torch, B, T, V, 7 + i).to(dev) for i in range(2)]
     arr = (ctypes.c_char_p * V)(*[x.encode("utf-8") for x in labels])
     inner = ctypes.c_void_p()
     n.check(n.lib.ctcd_scorer_create(ctypes.byref(inner), 0.0, 0.0, arpa.encode(), arr, V, dev.index or 0))
     order = int(n.lib.ctcd_scorer_max_order(inner))
     fn_addr = ctypes.cast(n.lib.ctcd_scorer_cond_log10, ctypes.c_void_p).value
-    out = {}
+    out = {"rows": "transcript-like (sentences of the model's words spelled with +7 on the intended label)" if transcripts else "log-softmax of N(0,1) logits (the beam wanders through every word history: the cache's worst case)"}
     try:
         ref = ctcdecode_amd.CTCBeamDecoder(labels, model_path=arpa, alpha=alpha, beta=beta, cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev)
         ref.set_timing(True)
@@ -460,8 +495,9 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
             out["configs[4] with the LM scorer"] = {"error": str(e)[:200]}
     if os.path.exists(arpa) and getattr(ctcdecode_amd, "HAVE_LM", False):
         try:
-            out["scorer hook at the configs[4] per-GPU shape (tests/data/test.arpa behind a native callback)"] = time_scorer_hook(
-                torch, ctcdecode_amd, dev, arpa, ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)])
+            lab29 = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
+            out["scorer hook at the configs[4] per-GPU shape (tests/data/test.arpa behind a native callback)"] = time_scorer_hook(torch, ctcdecode_amd, dev, arpa, lab29)
+            out["scorer hook, transcript-like rows (tests/data/test.arpa behind a native callback)"] = time_scorer_hook(torch, ctcdecode_amd, dev, arpa, lab29, transcripts=True)
         except Exception as e:
             out["scorer hook (test.arpa)"] = {"error": str(e)[:300]}
     # the same shape with a language model of realistic size (generated: 50 000 words, 3-gram, ~20 MB of ARPA text; the
@@ -479,8 +515,8 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
                 mod.make(big)
             run("configs[4] per-GPU shape with a generated 50k-word 3-gram LM (alpha 0.5, beta 1.0)", 128, 1500, 29, 100, model_path=big, alpha=0.5, beta=1.0, reps=1)
             try:
-                out["scorer hook at the configs[4] per-GPU shape (generated 50k-word model behind a native callback)"] = time_scorer_hook(
-                    torch, ctcdecode_amd, dev, big, ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)])
+                out["scorer hook, transcript-like rows (generated 50k-word model behind a native callback)"] = time_scorer_hook(
+                    torch, ctcdecode_amd, dev, big, ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)], transcripts=True)
             except Exception as e:
                 out["scorer hook (50k-word model)"] = {"error": str(e)[:300]}
         except Exception as e:

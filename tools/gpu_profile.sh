@@ -22,17 +22,17 @@ if has bench; then
 fi
 cd /tmp
 if has stats; then
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/prof.log" 2>&1; echo "rocprof stats rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-pmc > "$OUT/prof.log" 2>&1; echo "rocprof stats rc=$?"
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_cfg" -o trace -- python "$GRAFT_REPO_ROOT/tools/bench_configs.py" --only 234 --reps 1 > "$OUT/prof_cfg.log" 2>&1; echo "rocprof cfg rc=$?"
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_extras" -o trace -- python "$GRAFT_REPO_ROOT/tools/profile_extras.py" > "$OUT/prof_extras.log" 2>&1; echo "rocprof extras rc=$?"
 fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-pmc > "$OUT/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
     timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg_$c" -o p -- python "$GRAFT_REPO_ROOT/tools/bench_configs.py" --only 23 --reps 1 > "$OUT/pmc_cfg_$c.log" 2>&1; echo "pmc cfg $c rc=$?"
     timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_extras_$c" -o p -- python "$GRAFT_REPO_ROOT/tools/profile_extras.py" > "$OUT/pmc_extras_$c.log" 2>&1; echo "pmc extras $c rc=$?"
   done
-  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d "$OUT/pmc_insts" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/pmc_insts.log" 2>&1; echo "pmc insts rc=$?"
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d "$OUT/pmc_insts" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-pmc > "$OUT/pmc_insts.log" 2>&1; echo "pmc insts rc=$?"
 fi
 cd "$GRAFT_REPO_ROOT"
 if has timeline; then

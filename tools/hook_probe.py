@@ -26,6 +26,7 @@ if "--inflight" in sys.argv:
         dt = bench.time_inflight(torch, ctcdecode_amd, dev, lp256, [str(i) for i in range(29)], 100, k, steps=20)
         print("headline batch, default build, %d in flight: %.3f ms/batch (%.0f utt/s)" % (k, dt * 1e3, 256 / dt))
 print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels), indent=1))
+print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, transcripts=True), indent=1))
 if "--big" in sys.argv:
     import importlib.util
     import tempfile
@@ -36,4 +37,4 @@ if "--big" in sys.argv:
     big = os.path.join(tempfile.gettempdir(), "ctcd_big_words_50k.arpa")
     if not os.path.exists(big):
         mod.make(big)
-    print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, big, labels), indent=1))
+    print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, big, labels, transcripts=True), indent=1))
