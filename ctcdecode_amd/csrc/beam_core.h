@@ -56,6 +56,16 @@
 // Branch-probability hints for the rare paths of a frame (tie replay, revived nodes, pool overflow, last frame): the
 // compiler then lays the common path out as fall-through code (measured: +0.7 % at the north-star shape).
 #define CTC_RARE(x) __builtin_expect(!!(x), 0)
+// (the speculative select's margin control: Decoder::spec_learn)
+#if !defined(CTC_SPEC_UP)
+#define CTC_SPEC_UP 1.5f
+#endif
+#if !defined(CTC_SPEC_DN)
+#define CTC_SPEC_DN 0.7f
+#endif
+#if !defined(CTC_SPEC_OVER_SHIFT)
+#define CTC_SPEC_OVER_SHIFT 2
+#endif
 #define CTC_USUAL(x) __builtin_expect(!!(x), 1)
 
 namespace ctcbeam {
@@ -172,7 +182,14 @@ constexpr int kBinsLog = 10;
 constexpr int kListCap = 128;   // exact-rank list (one bucket's keys)
 constexpr int kSmallK = 128, kSmallV = 32;  // the class of shapes of the fixed workspace layout (SMALLV below)
 constexpr int kHotCap = 256;    // speculative select (Decoder::kSpec): capacity of the frame's hot list (keys at or above the predicted threshold)
-constexpr int kSerialCut = 24;  // introselect ranges at most this long are finished by one lane
+// (round 5: 24 -> 12.  The tail of a range on ONE lane costs an LDS round trip per access -- 8-18 k clocks for 24 elements --
+//  against ~4 k for one more partition round by the whole workgroup; tie frames decide how long a launch lasts
+//  (profiles/r05a_utt_spread.txt), and a constant is the one kind of change to this path that cannot disturb the register
+//  allocation of the frame loop's common path: configs[1] -1.1 %, inputs without ties unchanged; 8 measures the same, 48 +2.5 %.)
+#if !defined(CTC_SERIAL_CUT)
+#define CTC_SERIAL_CUT 12
+#endif
+constexpr int kSerialCut = CTC_SERIAL_CUT;  // introselect ranges at most this long are finished by one lane
 // Express pointers for the final back-trace: every pool node X (depth d >= 1) also records up(X) = its ancestor at
 // depth ((d - 1) / kExpress) * kExpress, so a label sequence of length d is read back as d / kExpress + 1 independent
 // segments of at most kExpress parent hops each instead of one chain of d dependent loads.
@@ -510,8 +527,8 @@ struct Decoder {
       // a half times as much).  Factors and trigger from a cost model over recorded key sets (tools/select_stats.py): falling
       // back 3.7 k clocks, a long list 1.5 k -- random rows 970 -> 710 clocks per frame against (x2, x0.81, K + K/2 + 10).
       if (pred) {
-        if (hot < K) margin = margin < 32.f ? margin * 1.5f : margin;
-        else if (hot > K + (K >> 2) + 3) margin = margin > 0.001f ? margin * 0.7f : margin;
+        if (hot < K) margin = margin < 32.f ? margin * CTC_SPEC_UP : margin;
+        else if (hot > K + (K >> CTC_SPEC_OVER_SHIFT) + 3) margin = margin > 0.001f ? margin * CTC_SPEC_DN : margin;
       }
       cut = (best - unord_f32(tau)) + margin;  // the next threshold lies this far below the next frame's best estimate
       // the window of a frame that falls back to the histogram select: anchored at the best key, reaching twice as far down
