@@ -1230,7 +1230,7 @@ struct Decoder {
   // each.  Returns the cut.
   template <class XX>
   CTC_HD int hoare_round(XX &xx, Ek *v, int first, int last, LrT *Lp, LrT *Rp) {
-    if (FARREP) return stlemu::hoare_round_parallel(xx, v, first, last, [](const Ek &e) { return EO::key(e); }, Lp, Rp, &w.vars[VAR_CUT]);
+    if (FARREP) return stlemu::hoare_round_parallel<true>(xx, v, first, last, [](const Ek &e) { return EO::key(e); }, Lp, Rp, &w.vars[VAR_CUT]);
     return stlemu::hoare_round_parallel_chunks(xx, v, first, last, [](const Ek &e) { return EO::key(e); }, Lp, Rp, &w.vars[VAR_CUT]);
   }
 
@@ -1781,14 +1781,36 @@ struct Decoder {
       x.mark(3);
     } else if (CTC_RARE(exact)) {
       keys_in_ord = nth_element_order(S, N, K, &lz);
-      for (int q = tid; q < K; q += nt) {  // rank by slot
-        const int mine = ord[q];
-        int r = 0;
-        for (int o = 0; o < K; ++o) r += ord[o] < mine;
-        rk[q] = r;
-        surv[r] = mine;
+      if (SMALLV) {
+        for (int q = tid; q < K; q += nt) {  // rank by slot
+          const int mine = ord[q];
+          int r = 0;
+          for (int o = 0; o < K; ++o) r += ord[o] < mine;
+          rk[q] = r;
+          surv[r] = mine;
+        }
+        x.sync();
+      } else {
+        // Wide beams: K compares per survivor are K * K / nt LDS reads per thread (beam 500: 10 us of a 42 us replay frame).  The
+        // survivors are marked in the slot bitmap and expanded in slot order -- the select's own expansion --, and every entry of
+        // the std::nth_element order finds its rank by bisection.
+        const int nw = (S + 63) / 64;
+        for (int i = tid; i < 2 * nw; i += nt) w.bitmap[i] = 0u;
+        x.sync();
+        for (int q = tid; q < K; q += nt) { const int s = ord[q]; x.atomic_or(&w.bitmap[s >> 5], 1u << (s & 31)); }
+        x.sync();
+        x.template expand_bitmap<false>(w.bitmap, nw, surv);
+        for (int q = tid; q < K; q += nt) {
+          const int mine = ord[q];
+          int lo = 0, hi = K - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (surv[mid] < mine) lo = mid + 1; else hi = mid;
+          }
+          rk[q] = lo;
+        }
+        x.sync();
       }
-      x.sync();
       if (keys_in_ord) {
         for (int q = tid; q < K; q += nt) ord[rk[q]] = (int)(uint32_t)(EO::key(ekp()[q]) >> 16);
         zero_key_tail(S);  // (the replay staged its ranges in the block of the slot keys; the frames to come rewrite [0, S))

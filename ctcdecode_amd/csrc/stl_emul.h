@@ -315,15 +315,32 @@ STLEMU_HD void sort_parallel(X &x, T *v, int n, C before, I *cur, I *nxt, I *sma
 // first_lane(v) (the value the group's first lane holds).
 // Lp, Rp: scratch for last - first + 1 positions each (P = uint16_t: n < 65536, the two counts travel in one scanned
 // word; P = uint32_t: any n, two scans); *cutvar: one shared word.  Returns the cut.
-template <class X, class T, class KeyOf, class P>
+// MEDIAN_BY_ALL: every thread reads the three candidates and the front element and finds the median itself; one thread then
+// stores the two elements that trade places.  (One thread doing median_to alone is a chain of four to five dependent memory
+// round trips with the workgroup waiting -- in HBM, where the first rounds of a wide beam's list live, 4-5 us of a 6.5 us round.)
+template <bool MEDIAN_BY_ALL = false, class X, class T, class KeyOf, class P>
 STLEMU_HD int hoare_round_parallel(X &x, T *v, int first, int last, KeyOf key_of, P *Lp, P *Rp, int *cutvar) {
   const int tid = x.tid(), nt = x.nt();
   constexpr bool wide = sizeof(P) > 2;
   auto before = [&](const T &a, const T &b) { return key_of(a) > key_of(b); };
-  if (tid == 0) median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
-  x.sync();
   const int lo = first + 1, m = last - lo;
-  const auto kp = key_of(v[first]);
+  decltype(key_of(v[first])) kp;
+  if (MEDIAN_BY_ALL) {
+    const int pa = first + 1, pb = first + (last - first) / 2, pc = last - 1;
+    const T va = v[pa], vb = v[pb], vc = v[pc], vf = v[first];
+    int pm;  // (median_to's decision tree)
+    if (before(va, vb)) pm = before(vb, vc) ? pb : (before(va, vc) ? pc : pa);
+    else pm = before(va, vc) ? pa : (before(vb, vc) ? pc : pb);
+    const T vm = pm == pa ? va : (pm == pb ? vb : vc);
+    x.sync();  // (everyone has read before the two stores)
+    if (tid == 0) { v[first] = vm; v[pm] = vf; }
+    x.sync();
+    kp = key_of(vm);
+  } else {
+    if (tid == 0) median_to(v, first, first + 1, first + (last - first) / 2, last - 1, before);
+    x.sync();
+    kp = key_of(v[first]);
+  }
   // The range is cut into one stretch per GROUP of x.lanes() threads (a wavefront on the GPU, a single thread on the host),
   // the lanes of a group taking neighbouring elements: the group's loads are contiguous (the array is in HBM for the first
   // rounds of a wide beam) and a stop's rank within the stretch is a ballot + a count of the lanes below.
