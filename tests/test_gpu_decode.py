@@ -647,6 +647,36 @@ def test_streaming_equals_one_shot(torch_mod, case):
     ou.assert_same(got, want, "chunked")
 
 
+def test_streaming_two_groups_of_streams_on_two_hip_streams(torch_mod):
+    """Two groups of streams, each behind its own decoder on its own HIP stream, fed alternately without host synchronisation
+    (check=False) -- the serving form that hides a chunk's stragglers (bench.py: streaming.two_groups_in_flight) -- give exactly the
+    one-shot results."""
+    import ctcdecode_amd
+
+    V, K, T, B, chunk = 29, 40, 400, 6, 50
+    lps = [ou.synth_logprobs(B, T, V, 171), ou.synth_logprobs(B, T, V, 172)]
+    wants = [ou.decode(lp, beam=K, which="restated") for lp in lps]
+    decs = [ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], beam_width=K, cutoff_top_n=V, log_probs_input=True) for _ in range(2)]
+    states = [[ctcdecode_amd.DecoderState(d) for _ in range(B)] for d in decs]
+    xs = [torch_mod.from_numpy(lp).cuda() for lp in lps]
+    hs = [torch_mod.cuda.Stream(), torch_mod.cuda.Stream()]
+    torch_mod.cuda.synchronize()
+    res = [None, None]
+    for f0 in range(0, T, chunk):
+        last = f0 + chunk >= T
+        for g in range(2):
+            with torch_mod.cuda.stream(hs[g]):
+                res[g] = decs[g].decode(xs[g][:, f0:f0 + chunk].contiguous(), states[g], [last] * B, check=last)
+    torch_mod.cuda.synchronize()
+    for g in range(2):
+        out, sc, ts, ln = res[g]
+        L = out.shape[2]
+        got = dict(tokens=np.zeros((B, K, T), np.int32), timesteps=np.zeros((B, K, T), np.int32), scores=sc.numpy(), lens=ln.numpy(), nres=wants[g]["nres"])
+        got["tokens"][:, : out.shape[1], :L] = out.numpy()
+        got["timesteps"][:, : out.shape[1], :L] = ts.numpy()
+        ou.assert_same(got, wants[g], "group %d" % g)
+
+
 def test_streaming_mixed_batch_and_growth(torch_mod):
     """Streams of different ages in one batch (one ends while the other continues), ragged chunk lengths, and a stream
     that outgrows its initial node pool (1024 frames)."""
