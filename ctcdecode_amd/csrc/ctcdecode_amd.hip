@@ -1315,6 +1315,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
   if (!scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel)
     fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, 2> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>;
+  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, 2>;
 #elif defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 3
   // Workgroup-size sweep (tools/build_variants.sh nt512:CTC_QUICK_BUILD=3,CTC_QUICK_NT=512; raw_multi.py --threads 512)
   if (big || !fixed || pruned_mode || scorer || occ2 || threads != CTC_QUICK_NT || d->profile)
@@ -1327,6 +1328,8 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD: only the fixed-layout, no-prune, no-LM, 1024-thread kernel was compiled");
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
   if (occ2) fn = (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
+  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024>;
+  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, false, true>;
 #else
 #define CTC_PICK(PROF_)                                                                                                  \
   (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, false>)    \
@@ -1359,6 +1362,10 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     }
   }
 #undef CTC_PICK
+  // streamed input (the host-tensor entry point): the north-star class's default builds do not poll for rows -- their twins do (decode_kernel.h PROF 4 / 5)
+  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024>;
+  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<3, 0, 1, false, 1024>) fn = (const void *)ctc_beam_decode_kernel<5, 0, 1, false, 1024>;
+  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, false, true>;
   if (scorer) {
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 0, 0, false, 0, true>;
     if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
@@ -1385,6 +1392,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true>;
       if (!scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel) fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, 2>;
     }
+    if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, 2>;  // (streamed input: its twin)
   }
 #endif
   // (CTCD_LDS_FLOOR: experiments with the occupancy the LDS request allows)

@@ -848,7 +848,14 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   if (PROF == 2 && a.tl && b == 0)
     for (int i = threadIdx.x; i < 16 * kTlCap; i += blockDim.x) tlbuf[i] = 0;
   if (PROF == 1 && threadIdx.x < 16) prof[threadIdx.x] = 0;
-  DevX<PROF, BIG != 0, NT> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
+  // PROF 4 / 5: the twins of builds 0 / 3 that take STREAMED input (a.frames_ready: the host-tensor entry point feeds the rows while the
+  // kernel runs).  The north-star class's default builds do not: the polling code at the top of the frame loop and the registers it
+  // holds across the loop cost the HBM-resident case 2.9 % (round 5: 5.24 -> 5.09 ms in tools/raw_multi.py; the word-model LM kernel
+  // 10.94 -> 10.70 ms; the kernels sit at the scalar-register limit), so that case gets a build without them and the
+  // streamed case keeps the build it had.
+  constexpr int XP = PROF == 4 ? 0 : PROF == 5 ? 3 : PROF;
+  constexpr bool kNoStreamedInput = (PROF == 0 || PROF == 3) && LAYOUT == 1 && NT == 1024 && (LM == 0 || LM == 2) && !PRUNED && BIG == 0 && (!OCC2 || LM == 0);
+  DevX<XP, BIG != 0, NT> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
                     (PROF == 2 && b == 0 && a.tl) ? tlbuf : nullptr, tlcnt, kTlCap, a.tl_f0, a.tl_nf};
   int len = a.seq_lens ? __builtin_amdgcn_readfirstlane(a.seq_lens[b]) : a.T;
   len = len < 0 ? 0 : (len > a.T ? a.T : len);  // binding.cpp:64-65
@@ -890,7 +897,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2, LM == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + ((size_t)b * a.T + f0) * a.V : nullptr, a.raw_log,
-                                  PRUNED ? (const int *)nullptr : a.frames_ready);
+                                  (PRUNED || kNoStreamedInput) ? (const int *)nullptr : a.frames_ready);
   if (threadIdx.x == 0) {
     if (a.shape) a.shape[b] = 16 * w.vars[ctcbeam::VAR_QSTAT];
     a.status[b] = st;
@@ -907,12 +914,12 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 // decode_kernels.hip instantiates the ones of its group (-DCTC_KERNEL_GROUP=g); ctcdecode_amd.hip declares them all extern.
 #define CTC_KERNEL_GROUPS 12
 #if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2  // experiment builds of the LM tier: its north-star class kernel and the timeline twin
-#define CTC_KERNEL_LIST(X) X(0, 0, 1, false, 1024, 2, false, 0) X(2, 0, 1, false, 1024, 2, false, 1) X(0, 0, 1, false, 1024, true, false, 1) X(2, 0, 1, false, 1024, true, false, 0)
+#define CTC_KERNEL_LIST(X) X(0, 0, 1, false, 1024, 2, false, 0) X(2, 0, 1, false, 1024, 2, false, 1) X(0, 0, 1, false, 1024, true, false, 1) X(2, 0, 1, false, 1024, true, false, 0) X(4, 0, 1, false, 1024, 2, false, 1)
 #elif defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 3  // workgroup-size sweep: the north-star class kernel with CTC_QUICK_NT threads folded in
 #define CTC_KERNEL_LIST(X) X(0, 0, 1, false, CTC_QUICK_NT, false, false, 0)
 #elif defined(CTC_QUICK_BUILD)  // experiment builds: the north-star class kernels and the barrier-timeline twin only
 #define CTC_KERNEL_LIST(X) \
-  X(0, 0, 1, false, 1024, false, false, 0) X(2, 0, 1, false, 1024, false, false, 1) X(0, 0, 1, false, 1024, false, true, 1)
+  X(0, 0, 1, false, 1024, false, false, 0) X(2, 0, 1, false, 1024, false, false, 1) X(0, 0, 1, false, 1024, false, true, 1) X(4, 0, 1, false, 1024, false, false, 1) X(4, 0, 1, false, 1024, false, true, 0)
 #else
 #define CTC_KERNEL_LIST(X)                                                                                                          \
   X(0, 0, 1, false, 1024, false, false, 0) X(0, 0, 1, true, 1024, false, false, 1) X(2, 0, 1, false, 1024, false, false, 2)               \
@@ -927,6 +934,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(0, 1, 0, false, 0, true, false, 6) X(0, 1, 0, true, 0, true, false, 7) X(0, 2, 0, false, 0, true, false, 8) X(0, 2, 0, true, 0, true, false, 9) \
   X(0, 3, 0, false, 0, false, false, 5) X(0, 3, 0, true, 0, false, false, 4) X(0, 3, 0, false, 0, true, false, 6) X(0, 3, 0, true, 0, true, false, 7) \
   X(0, 1, 0, false, 1024, false, false, 9) X(0, 1, 0, true, 1024, false, false, 10) X(2, 1, 0, false, 1024, false, false, 11) \
+  X(4, 0, 1, false, 1024, false, false, 3) X(5, 0, 1, false, 1024, false, false, 5) X(4, 0, 1, false, 1024, 2, false, 7) X(4, 0, 1, false, 1024, false, true, 9) \
   X(3, 0, 1, false, 1024, false, false, 1) X(3, 0, 1, true, 1024, false, false, 2) X(0, 0, 1, false, 1024, 3, false, 8) X(0, 0, 1, true, 1024, 3, false, 9) X(0, 0, 0, false, 0, 3, false, 10) X(0, 0, 0, true, 0, 3, false, 4)
 #endif
 
