@@ -97,6 +97,36 @@ static void check_all(const std::vector<int> &key, std::mt19937 &g) {
       if (!ok) { ++g_bad; fprintf(stderr, "sort_prefix_parallel mismatch n=%d limit=%d big_cut=%d\n", n, limit, big_cut); }
     }
   }
+  // one partition round by the workgroup forms (group form with the median found by one thread / by every thread -- the wide-beam
+  // layouts' --, chunk form) against the serial split_with_median_pivot: same cut, same arrangement, heavy ties included
+  if (n > 3 && n < 65536) {
+    struct SeqX3 {
+      int tid() const { return 0; }
+      int nt() const { return 1; }
+      void sync() {}
+      int uni(int v) const { return v; }
+      void block_scan_u32(uint32_t mine, uint32_t *base, uint32_t *total) { *base = 0; *total = mine; }
+      int lanes() const { return 1; }
+      uint32_t ballot(bool p) const { return p ? 1u : 0u; }
+      int count(uint32_t m) const { return (int)m; }
+      int count_below(uint32_t) const { return 0; }
+      uint32_t first_lane(uint32_t v) const { return v; }
+    } sx3;
+    const int first = (int)(g() % (n - 3)), last = first + 4 + (int)(g() % (n - first - 3));
+    auto key_of = [&](uint32_t e) { return key[e]; };
+    std::vector<uint32_t> want = base;
+    const int cut_want = stlemu::split_with_median_pivot(want.data(), first, last, cmp);
+    for (int form = 0; form < 3; ++form) {
+      std::vector<uint32_t> b = base;
+      std::vector<uint16_t> Lp(n + 2), Rp(n + 2);
+      int cutvar = -1;
+      const int cut = form == 0 ? stlemu::hoare_round_parallel<false>(sx3, b.data(), first, last, key_of, Lp.data(), Rp.data(), &cutvar)
+                    : form == 1 ? stlemu::hoare_round_parallel<true>(sx3, b.data(), first, last, key_of, Lp.data(), Rp.data(), &cutvar)
+                                : stlemu::hoare_round_parallel_chunks(sx3, b.data(), first, last, key_of, Lp.data(), Rp.data(), &cutvar);
+      ++g_checked;
+      if (cut != cut_want || b != want) { ++g_bad; fprintf(stderr, "partition round mismatch form=%d n=%d [%d,%d) cut %d vs %d\n", form, n, first, last, cut, cut_want); }
+    }
+  }
   // nth_element at a few positions
   for (int rep = 0; rep < 4 && n > 0; ++rep) {
     int nth = rep == 0 ? n / 2 : rep == 1 ? std::min(n, 100) % (n + 1) : (int)(g() % (n + 1));
