@@ -224,6 +224,7 @@ struct Work {
   uint32_t *wpre;  // build_ek_lazy's prefix over the bitmap's words (the histogram's block; widest layout: HBM scratch)
   int *bins;       // kBins buckets of the select histogram (+ kBins/16 more words: with them, the task lists of the final sorts)
   int *hotge;      // kHotCap counters of the speculative select's ranking (fixed-layout class only; zero between frames)
+  int *lcpst;      // 7 x kSmallK: range minima of the current beam's LCP array (Decoder::kLcpTable; fixed-layout class without a scorer)
   uint32_t *list;  // kListCap: (key - bucket base + 1) of the keys in the K-th key's bucket
   int *lslot;      // kListCap: their slots
   uint32_t *bitmap;  // one bit per slot: survives (select fast path)
@@ -303,7 +304,13 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   const size_t lcap = (d.K <= kSmallK && d.Vc_max <= kSmallV) ? (size_t)kHotCap + 64 : (size_t)kListCap + 4;
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, lcap);
   w.lslot = carve_ptr<int>(p, lcap);
-  w.hotge = carve_ptr<int>(p, lcap > (size_t)kListCap + 4 ? (size_t)kHotCap : 0); w.bitmap = carve_ptr<uint32_t>(huge ? q : p, 2 * ((S + 63) / 64 + 17));
+  w.hotge = carve_ptr<int>(p, lcap > (size_t)kListCap + 4 ? (size_t)kHotCap : 0);
+#if defined(CTC_EXP_LCP_TABLE)
+  w.lcpst = carve_ptr<int>(p, (lcap > (size_t)kListCap + 4 && !d.lm) ? (size_t)7 * kSmallK : 0);
+#else
+  w.lcpst = nullptr;
+#endif
+  w.bitmap = carve_ptr<uint32_t>(huge ? q : p, 2 * ((S + 63) / 64 + 17));
   w.wpre = huge ? carve_ptr<uint32_t>(q, (S + 63) / 64 + 2) : reinterpret_cast<uint32_t *>(w.bins);
   w.fin = carve_ptr<int>(BIG ? q : p, K);  // (last / exact / danger frames and finish() only: HBM scratch in the wide-beam layouts)
   w.apos = carve_ptr<int>(BIG ? q : p, K);  // (read in danger mode only: HBM scratch in the wide-beam layouts)
@@ -504,6 +511,17 @@ struct Decoder {
   // boundary, the last frame, danger mode -- falls back to the histogram select, which first has to build its histogram
   // (rehistogram()): same survivors either way, by construction.
   static constexpr bool kSpec = IDENT && SMALLV && !LM && !LAZY && X::kSpecSelect;
+  // Round 6: phase A1 of frame t + 1 reads nothing but the NEW beam's depth / LCP arrays, and the emission of frame t keeps six
+  // of the sixteen waves busy.  The emission therefore writes those two arrays first, a barrier follows, and eight of the idle
+  // waves run phase A1 of the next frame while the role waves finish the emission (pool appends, probabilities, best key); the
+  // frame's closing fence is then also the barrier between A1 and A2 of the next frame, which starts at A2.  The first frame
+  // of a launch is primed before the loop (prime_a1).  Speculative-select class at 1024 threads only (step(): emission).
+  static constexpr bool kA1Overlap = kSpec && X::kA1Overlap;
+  // Round 6: the emission's longest chain was the new LCP array -- per survivor a range minimum over the old one, a loop of LDS
+  // round trips whose length differs from lane to lane.  One wave (the last: the children's part of phase B loses nothing by
+  // it -- 26 instead of 28 parents per pass are four passes at beam 100 either way) builds a table of range minima of the
+  // CURRENT beam's LCP array while the candidates are scored (build_lcp_table), and a survivor's LCP is two reads (lca_depth_tbl).
+  static constexpr bool kLcpTable = kSpec && X::kLcpTable;
   // word models, fixed-layout class at 1024 threads, built-in tables: the n-gram query of a new entry's word runs beside phase B
   // (step(): phase A2 / phase B)
   static constexpr bool kLmOverlap = LM && WORDLM && SMALLV && !CB && !LAZY && X::kLmOverlap;
@@ -1203,6 +1221,39 @@ struct Decoder {
     return x.uni(w.vars[VAR_CUT]) == 1;
   }
 
+  // kLcpTable: st[l][i] = min lcp[i .. i + 2^l - 1] of the current beam (entries at or beyond n count as +inf), l = 0 .. 6, by ONE
+  // wave (`lane` of 64; two entries per lane).  Level l reads level l - 1 at a distance of 2^(l-1): a wave's LDS accesses
+  // execute in order, so no barrier is needed between the levels.
+  CTC_HD void build_lcp_table(const Beam &b, int n, int lane) const {
+    int *st = w.lcpst;
+    const int i0 = lane, i1 = lane + 64;
+    int v0 = i0 < n ? b.lcp[i0] : kIntMax, v1 = i1 < n ? b.lcp[i1] : kIntMax;
+    st[i0] = v0; st[i1] = v1;
+    x.wave_lds_fence();
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int l = 1; l <= 6; ++l) {
+      const int h = 1 << (l - 1);
+      const int *p = st + (l - 1) * kSmallK;
+      const int a = p[i0 + h];                                   // (i0 + h < 128)
+      const int c = i1 + h < kSmallK ? p[i1 + h] : kIntMax;
+      v0 = a < v0 ? a : v0; v1 = c < v1 ? c : v1;
+      st[l * kSmallK + i0] = v0; st[l * kSmallK + i1] = v1;
+      x.wave_lds_fence();
+    }
+  }
+  // ... and the depth of the lowest common ancestor of entries ja and jb through it: one LDS round trip, no loop
+  CTC_HD int lca_depth_tbl(int ja, int jb) const {
+    const int lo = ja < jb ? ja : jb, hi = ja < jb ? jb : ja;
+    const int len = hi - lo;
+    const int l = 31 - __builtin_clz((unsigned)(len > 0 ? len : 1));
+    const int *p = w.lcpst + l * kSmallK;
+    const int same = w.cur.dep[ja];
+    const int a = p[lo + 1 < kSmallK ? lo + 1 : kSmallK - 1], c = p[hi - (1 << l) + 1];
+    const int m = a < c ? a : c;
+    return len == 0 ? same : m;
+  }
   // min of lcp[] over (lo, hi] of the CURRENT beam (depth of the lowest common ancestor of entries lo and hi)
   CTC_HD int lca_depth(int ja, int jb) const {
     const Beam &b = w.cur;
@@ -1293,6 +1344,55 @@ struct Decoder {
     return false;
   }
 
+  // kA1Overlap: phase A1 for the FIRST frame of a launch (every later one runs beside its predecessor's emission).
+  CTC_HD void prime_a1(int t) {
+    if (!kA1Overlap) return;
+    select_beams();
+    phase_a1(w.cur, st_n, w.ancbuf + (t & 1) * d.K, w.acntbuf + (t & 1) * d.K, x.group(), x.ngroups());
+    x.sync();
+  }
+  // ---- A1 (a method of its own since round 6: see kA1Overlap): per beam entry, from the LCP array alone: the end of its
+  // subtree range (first later entry whose LCP with its predecessor is shallower than the entry), found by a wave-wide
+  // search; every entry then "paints" its proper descendants with itself, which leaves in anc[] the nearest in-beam
+  // ancestor (max = innermost enclosing range) and in acnt[] the number of in-beam ancestors.  Cost is bounded even for
+  // deeply nested beams.  `grp` of `ngr` groups (waves; ngr a power of two) take part; anc[] / acnt[] are -1 / 0 on entry.
+  CTC_HD void phase_a1(const Beam &b, int n, int *anc, int *acnt, int grp, int ngr) {
+    // Entry j = row * ngr + column; in row r this group takes column (grp - r) mod ngr.  (A plain "column = grp"
+    // split is badly unbalanced: interior entries tend to come with a fixed number of leaf children each, so they
+    // sit at a fixed residue of j and would all land on the same few groups.)
+    const int rows = ceil_div_p2(n, ngr);
+    auto entry_of = [=](int r) { return r * ngr + ((grp - r) & (ngr - 1)); };  // ngr is a power of two
+    for (int k0 = 0; k0 < rows; k0 += x.lanes()) {
+      // leaves (the next entry is not a descendant) are settled one per lane; only entries with in-beam
+      // descendants need the wave-wide search and the painting
+      const int k = k0 + x.lane();
+      const int j = entry_of(k);
+      bool internal = false;
+      int dj = 0;
+      if (k < rows && j < n) {
+        dj = b.dep[j];
+        internal = j + 1 < n && b.lcp[j + 1] >= dj;
+        if (!internal) w.e[j] = j + 1;
+      }
+      unsigned long long todo = x.ballot(internal);
+      if (internal) x.count(EV_INTERNAL, 1);
+      // (X::kQuarters: the build for chain-shaped beams without a scorer -- three or more interior entries in a wave, as blank-dominated rows
+      //  have them in most frames; by its mere presence the search costs random rows 3 % of the frame, so it is a build of its own)
+      if ((LM || (X::kQuarters && __builtin_popcountll(todo) >= 3)) && x.subtrees_by_quarters(todo, k0, grp, ngr, b.dep, b.lcp, n, w.e, anc, acnt)) todo = 0;
+      while (todo) {
+        const int kk = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int jj = entry_of(k0 + kk);
+        const int q = x.first_below(b.lcp, jj + 2, n, x.pick(dj, kk));  // the entry's depth sits in lane kk
+        if (x.lane() == 0) w.e[jj] = q;
+        for (int c = jj + 1 + x.lane(); c < q; c += x.lanes()) {
+          x.atomic_max(&anc[c], jj);
+          x.atomic_add(&acnt[c], 1);
+        }
+      }
+    }
+  }
+
   // One time step.  w.clp/w.cch (and rank_of in pruned mode) hold this step's candidates; `last` selects the
   // bookkeeping that DecoderState::decode() needs (the permutation std::nth_element leaves behind).
   // `stage`/`stage_val`: in identity mode the caller hands over its prefetched value of the NEXT frame's row; it is
@@ -1304,7 +1404,7 @@ struct Decoder {
     select_beams();
     const Beam b = w.cur;
     const Beam nb = w.nxt;
-    const int tid = x.tid(), nt = x.nt();
+    const int tid = x.tid_fresh(), nt = x.nt();
     const int n = st_n, pool_count = st_pool;
     const int K = d.K;
     const int Vc = in.Vc, brank = in.blank_rank;
@@ -1335,10 +1435,7 @@ struct Decoder {
       lm_sorted_order(b, n);
     }
 
-    // ---- A1: per beam entry, from the LCP array alone: the end of its subtree range (first later entry whose LCP
-    // with its predecessor is shallower than the entry), found by a wave-wide search; every entry then "paints" its
-    // proper descendants with itself, which leaves in anc[] the nearest in-beam ancestor (max = innermost enclosing
-    // range) and in acnt[] the number of in-beam ancestors.  Cost is bounded even for deeply nested beams.
+    // ---- A1 (phase_a1): subtree ranges, nearest in-beam ancestors.  kA1Overlap: it already ran, beside the previous frame's emission.
     w.anc = w.ancbuf + (in.t & 1) * K;
     int *acnt = w.acntbuf + (in.t & 1) * K;
     // LM tier (word models): the entries the previous frame created are pending (lm_emit) -- their dictionary record is
@@ -1365,45 +1462,11 @@ struct Decoder {
       }
     }
     x.tick();
-    {
-      const int grp = x.group(), ngr = x.ngroups();
-      // Entry j = row * ngr + column; in row r this group takes column (grp - r) mod ngr.  (A plain "column = grp"
-      // split is badly unbalanced: interior entries tend to come with a fixed number of leaf children each, so they
-      // sit at a fixed residue of j and would all land on the same few groups.)
-      const int rows = ceil_div_p2(n, ngr);
-      auto entry_of = [=](int r) { return r * ngr + ((grp - r) & (ngr - 1)); };  // ngr is a power of two
-      for (int k0 = 0; k0 < rows; k0 += x.lanes()) {
-        // leaves (the next entry is not a descendant) are settled one per lane; only entries with in-beam
-        // descendants need the wave-wide search and the painting
-        const int k = k0 + x.lane();
-        const int j = entry_of(k);
-        bool internal = false;
-        int dj = 0;
-        if (k < rows && j < n) {
-          dj = b.dep[j];
-          internal = j + 1 < n && b.lcp[j + 1] >= dj;
-          if (!internal) w.e[j] = j + 1;
-        }
-        unsigned long long todo = x.ballot(internal);
-        if (internal) x.count(EV_INTERNAL, 1);
-        // (X::kQuarters: the build for chain-shaped beams without a scorer -- three or more interior entries in a wave, as blank-dominated rows
-        //  have them in most frames; by its mere presence the search costs random rows 3 % of the frame, so it is a build of its own)
-        if ((LM || (X::kQuarters && __builtin_popcountll(todo) >= 3)) && x.subtrees_by_quarters(todo, k0, grp, ngr, b.dep, b.lcp, n, w.e, w.anc, acnt)) todo = 0;
-        while (todo) {
-          const int kk = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          const int jj = entry_of(k0 + kk);
-          const int q = x.first_below(b.lcp, jj + 2, n, x.pick(dj, kk));  // the entry's depth sits in lane kk
-          if (x.lane() == 0) w.e[jj] = q;
-          for (int c = jj + 1 + x.lane(); c < q; c += x.lanes()) {
-            x.atomic_max(&w.anc[c], jj);
-            x.atomic_add(&acnt[c], 1);
-          }
-        }
-      }
+    if (!kA1Overlap) {
+      phase_a1(b, n, w.anc, acnt, x.group(), x.ngroups());
+      x.tick();
+      x.sync();
     }
-    x.tick();
-    x.sync();
     if (kSpec && tid == x.spec_thread()) spec_predict(in.t);
     // ---- A2: Euler-tour slot offsets; which children of in-beam parents already exist
     int npin = 0;
@@ -1583,8 +1646,10 @@ struct Decoder {
       }
       x.wave_add(&pv[P_NCAND], ncand);
     }
-    if ((!split || tid >= n1) && !(lm_ovl && tid < 2 * n1)) {
-      const int t2 = lm_ovl ? tid - 2 * n1 : split ? tid - n1 : tid, nt2 = lm_ovl ? nt - 2 * n1 : split ? nt - n1 : nt;
+    if (kLcpTable && tid >= nt - 64) {
+      build_lcp_table(b, n, tid - (nt - 64));
+    } else if ((!split || tid >= n1) && !(lm_ovl && tid < 2 * n1)) {
+      const int t2 = lm_ovl ? tid - 2 * n1 : split ? tid - n1 : tid, nt2 = lm_ovl ? nt - 2 * n1 : (split ? nt - n1 : nt) - (kLcpTable ? 64 : 0);
       const int sh = ceil_log2_u32((uint32_t)(Vnb > 1 ? Vnb : 1));
       const int lp2 = 1 << sh;                       // lanes per parent (power of two >= Vnb)
       int ncand = 0;
@@ -1846,6 +1911,114 @@ struct Decoder {
       for (int k = tid; k < n_new; k += nt) sinf[k] = info_of_slot(lz, surv[k]);
       x.sync();
     }
+    if (kA1Overlap) {
+      // Threads [0, 128) LCP, [128, 256) structure, [256, 384) probabilities -- two waves each, whatever the number of survivors
+      // (at most 128) --, waves 6..13 phase A1 of the NEXT frame, waves 14 and 15 the per-frame resets and the select's prediction.
+      const int role = (tid >= kSmallK) + (tid >= 2 * kSmallK) + (tid >= 3 * kSmallK);
+      const int k = tid - role * kSmallK;  // (role 3: the thread's number among the 640 without a part in the emission)
+      const bool act = role < 3 && k < n_new;
+      int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;  // the next frame's paint buffers
+      int s = 0;
+      uint32_t inf = kHoleInfo, pinf = kHoleInfo;
+      if (act) {  // (the previous survivor's words -- the LCP role's -- ride in the same two round trips)
+        s = surv[k];
+        const int sp = surv[k > 0 ? k - 1 : 0];
+        inf = w.sinfo[s]; pinf = w.sinfo[sp];
+      }
+      const uint32_t type = info_type(inf);
+      const int j = info_entry(inf);
+      const bool self = type == T_SELF, child = type == T_CHILD;
+      const int c = self ? -1 : info_ch(inf);
+      r_prob_any = role == 2;
+      // ---- first half: everything phase A1 reads (nb.lcp, nb.dep) is written; the other roles request what they need
+      int p_id = 0, p_node = 0, p_upv = 0, p_dep = 0;                     // structure: the pool append, issued behind the barrier
+      float q_b = 0.f, q_nb = 0.f, q_sc = 0.f, q_lpc = 0.f, q_score = 0.f, q_bprev = 0.f;  // probabilities: requested here, used behind it
+      int q_ch = 0;
+      uint32_t q_key = 0;
+      if (act && role == 0) {
+        // LCP with the previous survivor: the LCA depth of two candidates is the LCA depth of the entries they hang
+        // off (a brand-new child never lies on an existing path), capped by the depth of a revived interior node.
+        int l = -1;
+        if (k > 0) {
+          const int pj = info_entry(pinf);
+          l = kLcpTable ? lca_depth_tbl(pj, j) : lca_depth(pj, j);
+          if (CTC_RARE(type == T_REVIVED)) { const int dx = b.dep[w.anc[j]] + 1; l = dx < l ? dx : l; }
+          if (CTC_RARE(info_type(pinf) == T_REVIVED)) { const int dx = b.dep[w.anc[pj]] + 1; l = dx < l ? dx : l; }
+        }
+        nb.lcp[k] = l;
+      }
+      if (act && role == 1) {
+        // An entry that stays (T_SELF) and a brand-new child (T_CHILD, of entry j) both draw everything from entry j:
+        // one batch of loads, then selects.  A revived interior node (rare) hangs off the nearest in-beam ancestor of j.
+        const int node_j = b.node[j], par_j = b.par[j], ch_j = b.ch[j], dep_j = b.dep[j];
+        const int via_j = b.via[j], viaanc_j = b.viaanc[j], viach_j = b.viach[j], up_j = b.up[j];
+        const int id = pool_count + k;                                              // ids by beam position (gaps are harmless)
+        const int upv = (dep_j & (kExpress - 1)) == 0 ? node_j : up_j;
+        int o_node = self ? node_j : id, o_par = self ? par_j : node_j, o_ch = self ? ch_j : c;
+        int o_dep = self ? dep_j : dep_j + 1, o_viaanc = self ? viaanc_j : -1, o_up = self ? up_j : upv;
+        if (CTC_RARE(!self && !child)) {                                            // path_trie.cpp:50-56 : revived
+          const int P = w.anc[j];
+          x.count(EV_REVIVED, 1);
+          o_node = via_j; o_par = b.node[P]; o_dep = b.dep[P] + 1;
+          o_up = (b.dep[P] & (kExpress - 1)) == 0 ? b.node[P] : b.up[P];
+        }
+        nb.dep[k] = o_dep;
+        nb.node[k] = o_node; nb.par[k] = o_par; nb.ch[k] = o_ch;
+        nb.via[k] = via_j; nb.viaanc[k] = o_viaanc; nb.viach[k] = viach_j; nb.up[k] = o_up;  // via/viach: only read when viaanc matches
+        p_id = id; p_node = node_j; p_upv = upv; p_dep = dep_j;
+      }
+      if (act && role == 2) {
+        q_b = w.b_new[j]; q_nb = w.nb_new[j]; q_sc = w.sc_new[j]; q_lpc = b.lpc[j];
+        q_ch = b.ch[j]; q_score = b.score[j]; q_bprev = b.bprev[j];
+        q_key = keys_in_ord ? (uint32_t)ord[k] : w.skey[s];
+      }
+      if (role == 3 && k < K) { oa[k] = -1; oc[k] = 0; }
+      x.sync();
+      x.tick();
+      // ---- second half
+      if (role == 3) {
+        if (tid < 14 * 64) {
+          phase_a1(nb, n_new, oa, oc, x.group() - 6, 8);
+        } else {
+          // Per-frame resets for the next step: the hot list's keys (its unused tail must read as zero), the survivor bitmap,
+          // the existing-children masks (last read in phase B), the counters of the other parity.
+          const int t0 = tid - 14 * 64;
+          if (t0 < 64) {  // (wave 14: the arrays; wave 15: the counters and the select's prediction -- a long chain on one lane)
+            for (int i = t0; i < kHotCap + 64; i += 64) w.list[i] = 0u;
+            for (int i = t0; i < 2 * ((kSmallK * (2 + kSmallV) + 63) / 64); i += 64) w.bitmap[i] = 0u;
+            for (int i = t0; i < n; i += 64) w.hit[i] = 0;
+          } else if (tid == x.spec_thread()) {
+            reset_pvars(pvars(in.t + 1));
+            w.vars[VAR_G] = 0; w.vars[VAR_E] = 0;
+            spec_learn(N > K, tau, hot, K);
+          }
+        }
+      } else if (act && role == 1) {
+        if (child) {                                                                // path_trie.cpp:97-105
+          PoolNode pn; pn.parent = p_node; pn.cht = PoolNode::pack(c, in.t); pn.lpc = w.clp[rank_of_char(in, c)];
+          pool[p_id] = pn;
+          if (CTC_RARE(long_t)) pool_thi[p_id] = in.t >> 16;
+          if (((p_dep + 1) & (kExpress - 1)) == 0) pool_up[p_id] = p_upv;
+        }
+      } else if (act && role == 2) {
+        float o_b = q_b, o_nb = q_nb, o_sc = q_sc, o_lpc = q_lpc;
+        if (!self) {              // a new or revived prefix starts from its first path only (path_trie.cpp:52-56, 99-104)
+          const float lp = w.clp[rank_of_char(in, c)];
+          float logp;
+          if (CTC_USUAL(child)) {                                                   // ctc_beam_search_decoder.cpp:110-118
+            const float rep = q_bprev > CTC_NEG_MAX ? lp + q_bprev : CTC_NEG_MAX;
+            logp = c == q_ch ? rep : lp + q_score;
+            o_lpc = lp;
+          } else {
+            logp = child_logp(w.anc[j], c, lp);
+            o_lpc = w.rev_lpc[j];
+          }
+          o_b = CTC_NEG_MAX; o_nb = logp; o_sc = logp;
+        }
+        nb.bprev[k] = o_b; nb.nbprev[k] = o_nb; nb.score[k] = o_sc; nb.lpc[k] = o_lpc;
+        kloc = q_key;
+      }
+    } else
     {
       // (fixed-layout class at its usual 1024 threads: at most 128 survivors -- two waves per role, whatever their number:
       //  the role of a thread, the number of roles and the threads left for the resets are then compile-time facts instead
@@ -1897,7 +2070,7 @@ struct Decoder {
           if (k > 0) {
             const uint32_t pinf = lazy_info ? sinf[k - 1] : w.sinfo[surv[k - 1]];
             const int pj = info_entry(pinf);
-            l = lca_depth(pj, j);
+            l = kLcpTable ? lca_depth_tbl(pj, j) : lca_depth(pj, j);
             if (type == T_REVIVED) { const int dx = b.dep[w.anc[j]] + 1; l = dx < l ? dx : l; }
             if (info_type(pinf) == T_REVIVED) { const int dx = b.dep[w.anc[pj]] + 1; l = dx < l ? dx : l; }
           }
@@ -2298,6 +2471,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   const int t0 = ss ? x.uni(ss->hdr[SH_FRAMES]) : 0;
   dec.long_t = (long long)t0 + len > 65536;  // (frame numbers 0 .. 65535 fit the node's 16 bits)
   if (t0 > 0) dec.load_state(*ss); else dec.init();
+  dec.prime_a1(t0);
   const int tid = x.tid(), nt = x.nt();
   // Prefetch: the candidates of step t+1 are requested from HBM before step t runs, so the latency hides behind it.
   const int width = IDENT ? d.V : pr->stride;

@@ -77,6 +77,16 @@ struct DevX {
     }
   }
   __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+  // the thread id as a value the optimiser must treat as new at this point: predicates on it ("tid < 128", "lane 0 of the last
+  // wave") are then recomputed where they are used -- one compare -- instead of being hoisted out of the frame loop into pairs of
+  // scalar registers that live across it, spill, and come back as two v_readlane each (round 6: beam_core.h step())
+  __device__ __forceinline__ int tid_fresh() const {
+    int t = (int)threadIdx.x;
+#if defined(CTC_EXP_FRESH_TID)
+    asm volatile("" : "+v"(t));
+#endif
+    return t;
+  }
   __device__ __forceinline__ int nt() const { return NT ? NT : (int)blockDim.x; }
   __device__ __forceinline__ constexpr bool nt_is(int v) const { return NT == v; }  // the workgroup size is this compile-time value
   __device__ __forceinline__ constexpr bool far() const { return FAR; }  // part of the workspace lives in HBM
@@ -88,6 +98,8 @@ struct DevX {
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (PROF == 2 && tl) tl_rec();
   }
+  // a wave's own LDS writes, made visible to its other lanes' later reads (no barrier: one wave working alone)
+  __device__ __forceinline__ void wave_lds_fence() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   __device__ __forceinline__ void sync_full() {
     if (PROF == 2 && tl) tl_rec();
     __syncthreads();
@@ -215,6 +227,17 @@ struct DevX {
   static constexpr bool kSpecSelect = true;
 #endif
   static constexpr bool kQuarters = PROF == 3;  // (beam_core.h phase A1)
+  // Round 6 experiments, all measured SLOWER than the kernel without them and therefore off (-DCTC_EXP_... builds them):
+#if defined(CTC_EXP_LCP_TABLE)
+  static constexpr bool kLcpTable = NT == 1024;  // (beam_core.h kLcpTable: the last wave builds range minima of the LCP array during phase B)
+#else
+  static constexpr bool kLcpTable = false;
+#endif
+#if defined(CTC_EXP_A1_OVERLAP)
+  static constexpr bool kA1Overlap = NT == 1024;  // (beam_core.h kA1Overlap: phase A1 of the next frame beside the emission; the geometry it assumes)
+#else
+  static constexpr bool kA1Overlap = false;
+#endif
 #if defined(CTC_NO_LM_OVERLAP)
   static constexpr bool kLmOverlap = false;
 #else
@@ -358,6 +381,41 @@ struct DevX {
 #endif
     atomicAdd(&gearr[q], ge);
     sync();
+#if defined(CTC_EXP_RANK_ALLPAIRS)
+    // Round 6, VERDICT r5 item 1(b), measurement build only: the survivors' ranks in slot order by the all-pairs machinery on ALL
+    // sixteen waves -- a survivor's rank = number of survivors with a smaller slot -- instead of the bitmap + prefix chain on the two
+    // lead waves.  Thread (q, part) looks at the sixteen hot keys of its part: their counts (complete since the barrier above) say
+    // which of them survive, their slots which of those lie before key q's.  Costs ~75 instructions on every wave against ~45 + ~60
+    // on two: measured slower.
+    if (NT == 1024 && H <= 128) {
+      const int myslot = q < H ? hs[q] : 0x7fffffff;
+      const int4 *gp = reinterpret_cast<const int4 *>(gearr + part * 16);
+      const int4 *sp = reinterpret_cast<const int4 *>(hs + part * 16);
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int4 g4 = gp[i], s4 = sp[i];
+        cnt += ((unsigned)(g4.x - 1) < (unsigned)K && s4.x < myslot) + ((unsigned)(g4.y - 1) < (unsigned)K && s4.y < myslot) +
+               ((unsigned)(g4.z - 1) < (unsigned)K && s4.z < myslot) + ((unsigned)(g4.w - 1) < (unsigned)K && s4.w < myslot);
+      }
+      atomicAdd(&gearr[128 + q], cnt);
+      sync();
+      if (t < 128) {
+        const int g = gearr[t], rk = gearr[128 + t];
+        gearr[t] = 0; gearr[128 + t] = 0;
+        const bool valid = t < H;
+        if (valid && g == K) { res[0] = (int)mine; res[2] = K; }
+        if (valid && g <= K) surv[rk] = hs[t];
+      }
+      sync();
+      const int4 rv2 = *reinterpret_cast<const int4 *>(res);
+      SpecResult r2;
+      r2.tau = (uint32_t)__builtin_amdgcn_readfirstlane(rv2.x);
+      r2.ok = __builtin_amdgcn_readfirstlane(rv2.z) == K ? 1 : 0;
+      sync();  // (nobody reads the report behind this point: the caller resets it during the emission)
+      return r2;
+    }
+#endif
     const bool lead = t < L;  // (whole waves)
     bool keep = false;
     int slot = 0;

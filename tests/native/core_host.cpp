@@ -25,6 +25,8 @@ struct HostX {
   bool far_ = false;  // the workspace layout under test keeps the exact-replay arrays "far" (CTC_HOST_BIG)
   bool far() const { return far_; }
   int tid() const { return 0; }
+  int tid_fresh() const { return 0; }
+  void wave_lds_fence() const {}
   int nt() const { return 1; }
   constexpr bool nt_is(int) const { return false; }
   void sync() {}
@@ -64,6 +66,8 @@ struct HostX {
   // speculative select (beam_core.h Decoder::kSpec), sequentially: the same contract as the device policy's
   static constexpr bool kSpecSelect = true;
   static constexpr bool kQuarters = false;
+  static constexpr bool kLcpTable = false;   // (a wave of its own builds it beside phase B)
+  static constexpr bool kA1Overlap = false;  // (an overlap of wave roles: nothing to overlap with one thread)
   static constexpr bool kLmOverlap = false;  // (a split of the workgroup's waves: nothing to overlap with one thread)
   bool spec_fits(int) const { return true; }
   void hot_append(bool hot, uint32_t key, int slot, uint32_t *hk, int *hs, int *cnt) {
