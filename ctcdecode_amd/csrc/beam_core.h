@@ -180,7 +180,12 @@ enum {
 constexpr int kBins = 1024;     // histogram buckets of the select
 constexpr int kBinsLog = 10;
 constexpr int kListCap = 128;   // exact-rank list (one bucket's keys)
-constexpr int kSmallK = 128, kSmallV = 32;  // the class of shapes of the fixed workspace layout (SMALLV below)
+constexpr int kSmallK = 128, kSmallV = 32;  // the class of shapes of the fixed workspace layout (SMALLV == 1 below)
+// A second class with a compile-time layout (round 6; SMALLV == 2): beam <= kMidK with at most kMidVc candidate labels per frame out
+// of a vocabulary of at most kMidV labels, pruned -- the reference's DEFAULT decoder (beam_width 100, cutoff_top_n 40:
+// ctcdecode/__init__.py:26-38) on any vocabulary too large for class 1, i.e. BASELINE configs[3] (V = 10 000).  Same role geometry
+// as class 1 (at most 128 entries: two waves per role); 112 x 42 slots leave room for the 20 KB rank table.
+constexpr int kMidK = 112, kMidVc = 40, kMidV = 10240;
 constexpr int kHotCap = 256;    // speculative select (Decoder::kSpec): capacity of the frame's hot list (keys at or above the predicted threshold)
 // (round 5: 24 -> 12.  The tail of a range on ONE lane costs an LDS round trip per access -- 8-18 k clocks for 24 elements --
 //  against ~4 k for one more partition round by the whole workgroup; tie frames decide how long a launch lasts
@@ -301,7 +306,7 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
   w.skey = carve_ptr<uint32_t>(deep ? q : p, S);
   w.surv = carve_ptr<int>(p, 3 * K + 4);
   // (the fixed-layout class also uses the two lists as the hot list of the speculative select: kHotCap entries + padding)
-  const size_t lcap = (d.K <= kSmallK && d.Vc_max <= kSmallV) ? (size_t)kHotCap + 64 : (size_t)kListCap + 4;
+  const size_t lcap = (d.K <= kSmallK && d.Vc_max <= kMidVc) ? (size_t)kHotCap + 64 : (size_t)kListCap + 4;
   w.bins = carve_ptr<int>(p, kBins + kBins / 16 + 4); w.list = carve_ptr<uint32_t>(p, lcap);
   w.lslot = carve_ptr<int>(p, lcap);
   w.hotge = carve_ptr<int>(p, lcap > (size_t)kListCap + 4 ? (size_t)kHotCap : 0);
@@ -444,11 +449,13 @@ struct FullSyncView {
 // (info_of_slot); the rare paths that look at every slot (ties at the K boundary, exact replay) first rebuild all of them
 // (fill_info).  Round 2 wrote S info words per frame to HBM: 30 GB per configs[2] launch, 18x the algorithmic bytes.
 // FARREP: the exact replay's scratch lives in HBM (carve).  HUGE: more than 65535 candidate slots (carve BIG == 3).
-template <class X, bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, bool WORDLM = false, bool CB = false>
+template <class X, bool IDENT, int SMALLV = 0, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, bool WORDLM = false, bool CB = false>
 struct Decoder {
   using EO = EkOps<HUGE>;
   using Ek = typename EO::E;
   using LrT = typename EO::Pos;
+  // the bounds of the shape class (SMALLV: 0 none, 1 = kSmallK x kSmallV labels, 2 = kMidK x kMidVc candidates of a pruned vocabulary)
+  static constexpr int kClsK = SMALLV == 2 ? kMidK : kSmallK, kClsVc = SMALLV == 2 ? kMidVc : kSmallV, kClsSlots = kClsK * (2 + kClsVc);
   CTC_HD Ek *ekp() const { return reinterpret_cast<Ek *>(w.ek); }
   CTC_HD LrT *lrp() const { return reinterpret_cast<LrT *>(w.lr); }
   X &x;
@@ -494,7 +501,7 @@ struct Decoder {
   static constexpr bool kTailZero = IDENT && SMALLV && !LAZY && X::kZeroKeyTail;
   CTC_HD void zero_key_tail(int from) {
     if (!kTailZero) return;
-    for (int i = from + x.tid(); i < kSmallK * (2 + kSmallV); i += x.nt()) w.skey[i] = 0u;  // (the fixed layout's block: carve)
+    for (int i = from + x.tid(); i < kClsSlots; i += x.nt()) w.skey[i] = 0u;  // (the fixed layout's block: carve)
   }
 
   // ---- speculative select (round 4) -----------------------------------------------------------------------------------
@@ -510,7 +517,8 @@ struct Decoder {
   // stages) become two all-wave stages and two barriers.  Everything else -- too few or too many hot keys, ties at the
   // boundary, the last frame, danger mode -- falls back to the histogram select, which first has to build its histogram
   // (rehistogram()): same survivors either way, by construction.
-  static constexpr bool kSpec = IDENT && SMALLV && !LM && !LAZY && X::kSpecSelect;
+  // (round 6: pruned candidate lists as well -- the row's largest log-probability is then simply its first candidate's)
+  static constexpr bool kSpec = SMALLV && !LM && !LAZY && X::kSpecSelect;
   // Round 6: phase A1 of frame t + 1 reads nothing but the NEW beam's depth / LCP arrays, and the emission of frame t keeps six
   // of the sixteen waves busy.  The emission therefore writes those two arrays first, a barrier follows, and eight of the idle
   // waves run phase A1 of the next frame while the role waves finish the emission (pool appends, probabilities, best key); the
@@ -1000,7 +1008,7 @@ struct Decoder {
   // which word of w.hit holds bit `bit` (non-blank candidate number) of entry i's existing-children mask: two words per
   // entry; the fixed-layout class (at most 31 non-blank candidates) uses ONE word per entry, indexed like every other
   // per-entry array (the scoring loop then advances one address for all of them)
-  CTC_HD static int hit_word(int i, int bit) { return SMALLV ? i : 2 * i + (bit >> 5); }
+  CTC_HD static int hit_word(int i, int bit) { return SMALLV == 1 ? i : 2 * i + (bit >> 5); }
 
   // log_p of extending beam entry P with character c (ctc_beam_search_decoder.cpp:110-118)
   CTC_HD float child_logp(int P, int c, float lp) const {
@@ -1052,7 +1060,7 @@ struct Decoder {
     }
     for (int i = x.tid(); i < kHotCap + 64; i += x.nt()) w.list[i] = 0u;
     for (int i = x.tid(); i < kHotCap; i += x.nt()) w.hotge[i] = 0;
-    for (int i = x.tid(); i < 2 * ((kSmallK * (2 + kSmallV) + 63) / 64); i += x.nt()) w.bitmap[i] = 0u;
+    for (int i = x.tid(); i < 2 * ((kClsSlots + 63) / 64); i += x.nt()) w.bitmap[i] = 0u;
   }
   // The histogram of the frame's keys, for the frames the speculative select hands back: what phase B would have counted
   // (the window is kept in LDS by the thread that keeps the prediction: spec_learn).
@@ -1408,7 +1416,7 @@ struct Decoder {
     const int n = st_n, pool_count = st_pool;
     const int K = d.K;
     const int Vc = in.Vc, brank = in.blank_rank;
-    if (SMALLV) { CTC_ASSUME(n >= 1 && n <= kSmallK); CTC_ASSUME(Vc >= 1 && Vc <= kSmallV); CTC_ASSUME(d.K <= kSmallK); }
+    if (SMALLV) { CTC_ASSUME(n >= 1 && n <= kClsK); CTC_ASSUME(Vc >= 1 && Vc <= kClsVc); CTC_ASSUME(d.K <= kClsK); }
     const int Vnb = Vc - (brank >= 0 ? 1 : 0);
     const int S = n * (2 + Vnb);
     const bool small_vocab = SMALLV || Vnb <= 64;  // existing children fit a 64-bit mask per parent
@@ -1651,12 +1659,16 @@ struct Decoder {
     } else if ((!split || tid >= n1) && !(lm_ovl && tid < 2 * n1)) {
       const int t2 = lm_ovl ? tid - 2 * n1 : split ? tid - n1 : tid, nt2 = lm_ovl ? nt - 2 * n1 : (split ? nt - n1 : nt) - (kLcpTable ? 64 : 0);
       const int sh = ceil_log2_u32((uint32_t)(Vnb > 1 ? Vnb : 1));
-      const int lp2 = 1 << sh;                       // lanes per parent (power of two >= Vnb)
+      // lanes per parent: a power of two >= Vnb -- or, in the class of the pruned default (SMALLV == 2: up to 40 candidates), 40:
+      // 22 parents per pass on fourteen waves instead of 14 (beam 100: five passes instead of eight)
+      constexpr bool fixed_lp = SMALLV == 2;
+      const int lp2 = fixed_lp ? kMidVc : 1 << sh;
       int ncand = 0;
       if (small_vocab && nt2 >= lp2) {               // a group of lp2 lanes per parent, one lane per character
-        const int rn = t2 & (lp2 - 1);
-        const int ng = nt2 >> sh;
-        if (rn < Vnb && (t2 >> sh) < ng) {
+        const int g0 = fixed_lp ? t2 / kMidVc : t2 >> sh;   // this lane's first parent
+        const int rn = fixed_lp ? t2 - g0 * kMidVc : t2 & (lp2 - 1);
+        const int ng = fixed_lp ? nt2 / kMidVc : nt2 >> sh;
+        if (rn < Vnb && g0 < ng) {
           const int r = rn + ((brank >= 0 && rn >= brank) ? 1 : 0);
           const int c = IDENT ? r : w.cch[r];
           const float lp = w.clp[r];
@@ -1667,7 +1679,7 @@ struct Decoder {
           const int *gate_w = LM && WORDLM ? (c < 32 ? b.dmlo : b.dmhi) : nullptr;
           const int gate_sh = c & 31;
           // (the info word of (label, parent i) is childinfo + i: it is the loop's induction variable)
-          uint32_t ci = childinfo + (uint32_t)(t2 >> sh);
+          uint32_t ci = childinfo + (uint32_t)g0;
           const uint32_t ci_end = childinfo + (uint32_t)n;
           // (speculative select: the list space of a pass is reserved with a returning LDS atomic -- a full round trip.  The
           //  loop is pipelined by hand: the atomic is issued, then the NEXT pass's parent fields are requested, and only then
@@ -1683,7 +1695,7 @@ struct Decoder {
             p.gw = (LM && WORDLM) ? (uint32_t)gate_w[i] : 0u;
             return p;
           };
-          int i = t2 >> sh;
+          int i = g0;
           bool act = ci < ci_end;
           Par cur{};
           if (act) cur = fetch(i);
@@ -1985,8 +1997,8 @@ struct Decoder {
           const int t0 = tid - 14 * 64;
           if (t0 < 64) {  // (wave 14: the arrays; wave 15: the counters and the select's prediction -- a long chain on one lane)
             for (int i = t0; i < kHotCap + 64; i += 64) w.list[i] = 0u;
-            for (int i = t0; i < 2 * ((kSmallK * (2 + kSmallV) + 63) / 64); i += 64) w.bitmap[i] = 0u;
-            for (int i = t0; i < n; i += 64) w.hit[i] = 0;
+            for (int i = t0; i < 2 * ((kClsSlots + 63) / 64); i += 64) w.bitmap[i] = 0u;
+            for (int i = t0; i < (SMALLV == 1 ? n : 2 * n); i += 64) w.hit[i] = 0;
           } else if (tid == x.spec_thread()) {
             reset_pvars(pvars(in.t + 1));
             w.vars[VAR_G] = 0; w.vars[VAR_E] = 0;
@@ -2044,11 +2056,11 @@ struct Decoder {
           if (kSpec) {  // the hot list's keys (its unused tail must read as zero) and the survivor bitmap; the histogram is
                         // cleared by the frames that build one (rehistogram)
             for (int i = t0; i < kHotCap + 64; i += tstep) w.list[i] = 0u;
-            for (int i = t0; i < 2 * ((kSmallK * (2 + kSmallV) + 63) / 64); i += tstep) w.bitmap[i] = 0u;
+            for (int i = t0; i < 2 * ((kClsSlots + 63) / 64); i += tstep) w.bitmap[i] = 0u;
           } else {
             for (int i = t0; i < kBins; i += tstep) w.bins[i] = 0;
           }
-          for (int i = t0; i < (SMALLV ? n : 2 * n); i += tstep) w.hit[i] = 0;
+          for (int i = t0; i < (SMALLV == 1 ? n : 2 * n); i += tstep) w.hit[i] = 0;
           int *oa = w.ancbuf + ((in.t + 1) & 1) * K, *oc = w.acntbuf + ((in.t + 1) & 1) * K;
           for (int i = t0; i < K; i += tstep) { oa[i] = -1; oc[i] = 0; }
           if (t0 == 0) {
@@ -2237,7 +2249,7 @@ struct Decoder {
     const Beam &b = w.cur;
     const int tid = x.tid(), nt = x.nt();
     const int n = st_n;
-    if (SMALLV) { CTC_ASSUME(n >= 1 && n <= kSmallK); CTC_ASSUME(d.K <= kSmallK); }
+    if (SMALLV) { CTC_ASSUME(n >= 1 && n <= kClsK); CTC_ASSUME(d.K <= kClsK); }
     const int nres = n < d.K ? n : d.K;
     if (!had_steps)
       for (int k = tid; k < nres; k += nt) w.fin[k] = k;
@@ -2459,12 +2471,13 @@ struct PrunedRows {
 // Whole utterance: `rows` = [len, V] float32 log-probabilities (identity mode) or nullptr with `pr` set.
 // LM tier: `lm` = the scorer's tables, `raw` = the caller's own [len, V] rows (log-probabilities or probabilities,
 // `raw_log` says which): ctc_beam_search_decoder.cpp:78 takes the blank's log-probability from them directly.
-template <bool IDENT, bool SMALLV = false, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, bool WORDLM = false, bool CB = false, class X>
+template <bool IDENT, int SMALLV = 0, bool LM = false, bool LAZY = false, bool FARREP = LAZY, bool HUGE = false, bool WORDLM = false, bool CB = false, class X>
 CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float *rows, const PrunedRows *pr, int len,
                             PoolNode *pool, int *pool_up, int pool_cap, const uint64_t *tbl, const OutRefs *outs, int item,
                             const StreamState *ss = nullptr, const ctclm::LmView *lm = nullptr, const float *raw = nullptr,
                             int raw_log = 1, const int *frames_ready = nullptr) {
-  if (SMALLV) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
+  if (SMALLV == 1) { CTC_ASSUME(d.K >= 1 && d.K <= kSmallK); CTC_ASSUME(d.V >= 1 && d.V <= kSmallV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kSmallV); CTC_ASSUME(blank >= 0 && blank < kSmallV); }
+  if (SMALLV == 2) { CTC_ASSUME(d.K >= 1 && d.K <= kMidK); CTC_ASSUME(d.V >= 1 && d.V <= kMidV); CTC_ASSUME(d.Vc_max >= 1 && d.Vc_max <= kMidVc); }
   using Dec0 = Decoder<X, IDENT, SMALLV, LM, LAZY, FARREP, HUGE, WORDLM, CB>;
   Dec0 dec(x, w, d, blank, pool, pool_up, pool_cap, tbl, lm);
   // a stream continues where its previous chunk stopped: frame numbers (the `timesteps` output) keep counting
@@ -2563,6 +2576,8 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
         if (tid < in.Vc) {
           w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid;
           if (t == 0) dec.note_lp(pre_lp);
+          // (speculative select: the anchor of this frame's prediction -- the list is in descending order, decoder_utils.cpp:23-24)
+          if (Dec0::kSpec && tid == 0) w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(pre_lp);
         }
         if (t + 1 < len) {
           pre_cnt = pr->cnt[t + 1];
@@ -2579,6 +2594,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
           w.clp[r] = v;
           w.rank_of[c] = (int16_t)r;
           if (t == 0) dec.note_lp(v);
+          if (Dec0::kSpec && r == 0) w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(v);
         }
         if (t + 1 < len) {
           const int cn = x.uni(pr->cnt[t + 1]);

@@ -1076,7 +1076,9 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   if (threads == 0) threads = (dims.S_max() <= 1300 && !scorer) ? 512 : 1024;
   // (the LM tier has the fixed-layout kernel at 1024 threads only)
   const bool fixed = fits_fixed_layout(dims) && !d->no_fixed_layout && (!scorer || threads == 1024);
-  const Dims ldims = fixed ? fixed_layout_dims(scorer != nullptr) : dims;
+  // the second compile-time layout: the pruned default (beam <= 112, cutoff_top_n <= 40) on a vocabulary of up to 10 240 labels
+  const bool fixed2 = !fixed && fits_mid_layout(dims) && !d->no_fixed_layout && !scorer && threads == 1024 && !d->profile;
+  const Dims ldims = fixed ? fixed_layout_dims(scorer != nullptr) : fixed2 ? mid_layout_dims() : dims;
   // two workgroups per CU (OCC2 build of the fixed-layout kernel): batches that outnumber the CUs, or on request
   const bool hooked = scorer && scorer->cbl;  // a callback scorer: its own kernel instantiations (beam_core.h CB)
   const bool occ2 = fixed && threads == 1024 && !d->profile && !hooked && (d->cu_sharing == 1 || (d->cu_sharing < 0 && B > d->cu_count));
@@ -1309,7 +1311,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   a.far = (char *)d->far.p; a.far_stride = (long long)far_bytes;
   const bool pruned_mode = a.pr_cnt != nullptr;
   const void *fn;
-#if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2
+#if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 4
+  if (big || scorer || d->profile || occ2 || !(pruned_mode || (!fixed && !fixed2)))
+    return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD=4: only the pruned-mode kernels of the compile-time layouts and the run-time layout were compiled");
+  fn = fixed2 ? (const void *)ctc_beam_decode_kernel<0, 0, 2, true, 1024> : fixed && threads == 1024 ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024>
+       : pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 0, true> : (const void *)ctc_beam_decode_kernel<0, 0, 0, false>;
+  if (fixed && threads != 1024) return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD=4: 1024 threads");
+#elif defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2
   if (big || !fixed || pruned_mode || !scorer || occ2 || threads != 1024 || (d->profile && !d->tl_armed))
     return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD=2: only the fixed-layout, no-prune, 1024-thread kernel of the LM tier was compiled");
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
@@ -1352,6 +1360,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     d->last_subtree_search = 1;
   }
   if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, false, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
+  if (fixed2 && !big) fn = (const void *)ctc_beam_decode_kernel<0, 0, 2, true, 1024>;
   if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes and for the first wide-beam layout
     if (threads != 1024) return fail(CTCD_EUNSUPPORTED, "barrier timeline: 1024 threads per workgroup (the product configuration)");
     if (big && far_level == 1 && !pruned_mode) {

@@ -878,6 +878,12 @@ struct KernelArgs {
 constexpr int kFixedK = ctcbeam::kSmallK, kFixedV = ctcbeam::kSmallV;
 __host__ __device__ constexpr Dims fixed_layout_dims(bool lm = false) { return Dims{kFixedK, kFixedV, kFixedV, 1, lm ? 1 : 0}; }
 __host__ __device__ inline bool fits_fixed_layout(const Dims &d) { return d.K <= kFixedK && d.V <= kFixedV && d.Vc_max <= kFixedV; }
+// LAYOUT 2 (round 6): the second class with a compile-time layout -- beam <= kMidK, <= kMidVc candidates per frame of a pruned
+// vocabulary of <= kMidV labels (beam_core.h kMidK: the reference's default decoder on a large vocabulary, BASELINE configs[3]).
+__host__ __device__ constexpr Dims mid_layout_dims() { return Dims{ctcbeam::kMidK, ctcbeam::kMidV, ctcbeam::kMidVc, 1, 0}; }
+__host__ __device__ inline bool fits_mid_layout(const Dims &d) {
+  return d.K <= ctcbeam::kMidK && d.V <= ctcbeam::kMidV && d.Vc_max <= ctcbeam::kMidVc && d.use_rank_table && !d.lm;
+}
 
 // PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
 // OCC2 (fixed layout only): the build for two workgroups per CU -- at most 64 VGPRs (8 waves per SIMD) and the exact
@@ -897,6 +903,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   Work w;
   // (every layout keeps the exact replay's scratch in per-utterance HBM scratch; the wide-beam layouts more: beam_core.h carve)
   if (LAYOUT == 1) carve<0, OCC2>(w, smem, a.far + (size_t)b * a.far_stride, fixed_layout_dims(LM != 0), nullptr);
+  else if (LAYOUT == 2) carve<0, OCC2>(w, smem, a.far + (size_t)b * a.far_stride, mid_layout_dims(), nullptr);
   else carve<BIG>(w, smem, a.far + (size_t)b * a.far_stride, a.dims, nullptr);
   __shared__ long long prof[16];
   constexpr int kTlCap = (LM || BIG) ? kTimelineCap / 2 : kTimelineCap;  // (the LM tier's and the wide-beam layout's workspaces leave 8 KB for the stamps)
@@ -952,7 +959,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #else
   if (LM) lmv = &a.lm;
 #endif
-  const int st = decode_utterance<!PRUNED, LAYOUT == 1, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2, LM == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
+  const int st = decode_utterance<!PRUNED, LAYOUT, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2, LM == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + ((size_t)b * a.T + f0) * a.V : nullptr, a.raw_log,
                                   (PRUNED || kNoStreamedInput) ? (const int *)nullptr : a.frames_ready);
@@ -975,6 +982,8 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #define CTC_KERNEL_LIST(X) X(0, 0, 1, false, 1024, 2, false, 0) X(2, 0, 1, false, 1024, 2, false, 1) X(0, 0, 1, false, 1024, true, false, 1) X(2, 0, 1, false, 1024, true, false, 0) X(4, 0, 1, false, 1024, 2, false, 1)
 #elif defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 3  // workgroup-size sweep: the north-star class kernel with CTC_QUICK_NT threads folded in
 #define CTC_KERNEL_LIST(X) X(0, 0, 1, false, CTC_QUICK_NT, false, false, 0)
+#elif defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 4  // experiment builds of the pruned classes: compile-time layouts 1 and 2, and the run-time layout they replace
+#define CTC_KERNEL_LIST(X) X(0, 0, 2, true, 1024, false, false, 0) X(0, 0, 1, true, 1024, false, false, 1) X(0, 0, 0, true, 0, false, false, 1) X(0, 0, 0, false, 0, false, false, 0)
 #elif defined(CTC_QUICK_BUILD)  // experiment builds: the north-star class kernels and the barrier-timeline twin only
 #define CTC_KERNEL_LIST(X) \
   X(0, 0, 1, false, 1024, false, false, 0) X(2, 0, 1, false, 1024, false, false, 1) X(0, 0, 1, false, 1024, false, true, 1) X(4, 0, 1, false, 1024, false, false, 1) X(4, 0, 1, false, 1024, false, true, 0)
@@ -993,6 +1002,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(0, 3, 0, false, 0, false, false, 5) X(0, 3, 0, true, 0, false, false, 4) X(0, 3, 0, false, 0, true, false, 6) X(0, 3, 0, true, 0, true, false, 7) \
   X(0, 1, 0, false, 1024, false, false, 9) X(0, 1, 0, true, 1024, false, false, 10) X(2, 1, 0, false, 1024, false, false, 11) \
   X(4, 0, 1, false, 1024, false, false, 3) X(5, 0, 1, false, 1024, false, false, 5) X(4, 0, 1, false, 1024, 2, false, 7) X(4, 0, 1, false, 1024, false, true, 9) \
+  X(0, 0, 2, true, 1024, false, false, 0) \
   X(3, 0, 1, false, 1024, false, false, 1) X(3, 0, 1, true, 1024, false, false, 2) X(0, 0, 1, false, 1024, 3, false, 8) X(0, 0, 1, true, 1024, 3, false, 9) X(0, 0, 0, false, 0, 3, false, 10) X(0, 0, 0, true, 0, 3, false, 4)
 #endif
 

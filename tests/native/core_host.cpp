@@ -520,6 +520,10 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
                                   ctcmath::host_tables().w, &outs, b);
         else st = decode_utterance<true, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b);
+      } else if (pruned && !(beam <= 128 && V <= 32) && beam <= kMidK && d.Vc_max <= kMidVc && V <= kMidV && !getenv("CTC_HOST_NO_CLASS2")) {
+        // the second class with a compile-time layout on the device (the pruned default on a large vocabulary: beam_core.h kMidK)
+        st = decode_utterance<false, 2>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b);
       } else if (beam <= 128 && V <= 32) {  // the shapes the device runs with its fixed layout
         if (pruned) st = decode_utterance<false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b);
