@@ -455,11 +455,13 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
     out = {}
     traffic_consts = traffic_consts or {}
 
-    def run(name, B, T, V, K, top_n=40, cutoff_prob=1.0, reps=2, kind="randn", seed=7, prob_input=False, **kw):
+    def run(name, B, T, V, K, top_n=40, cutoff_prob=1.0, reps=2, kind="randn", seed=7, prob_input=False, logits=False, **kw):
         lp = synth_rows(torch, B, T, V, seed, kind)
         if prob_input:  # the reference's DEFAULT input mode (log_probs_input=False): probabilities, converted on the device
             lp = lp.exp()
         lp = lp.to(dev)
+        if logits:  # logits_input=True (extension): the rows are taken as raw logits (a log-softmax row is a logit row of the same distribution)
+            kw = dict(kw, logits_input=True)
         labels = [str(i) for i in range(V)]
         if V == 29:  # blank, apostrophe, space, a..z: the words of tests/data/test.arpa can be spelled
             labels = ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)]
@@ -488,6 +490,31 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
             r["prune_roofline"] = {"bound": "hbm", "achieved": r["prune_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": round(r["prune_GBps"] / 8000.0, 4),
                                    "algorithmic_bytes_per_launch": B * T * V * 4, "traffic": pt, "traffic_ratio": round(pt / (B * T * V * 4), 2) if pt else None,
                                    "traffic_source": "profiles/traffic_latest.json (rocprofv3 --pmc, FETCH_SIZE x2 for 128-bit loads: calibrated)"}
+            if logits:
+                r["prune_kernel_is"] = "prune_logits_wg_kernel: the logits are read once, normalised in registers (sum of exponentials in ctcd_log_softmax's defined order) and only the kept candidates are written -- log-softmax pre-pass + prune in one kernel"
+                r["prune_roofline"]["traffic"] = None  # (the PMC constants in profiles/traffic_latest.json are the two-pass prune's)
+                r["prune_roofline"]["traffic_ratio"] = None
+                # the two-pass form it replaces (debug switch), and the stand-alone normalisation (ctcd_log_softmax: read + write)
+                dec.set_fused_logits(False)
+                p2 = []
+                for _ in range(3):
+                    dec.decode_device(lp, None, check=True)
+                    p2.append(dec.last_prune_ms())
+                dec.set_fused_logits(True)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                outb = torch.empty_like(lp)
+                lt = []
+                for _ in range(4):
+                    ev[0].record()
+                    ctcdecode_amd._native.check(ctcdecode_amd._native.lib.ctcd_log_softmax(dec._handle, lp.data_ptr(), None, B, T, V, outb.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                    ev[1].record()
+                    torch.cuda.synchronize()
+                    lt.append(ev[0].elapsed_time(ev[1]))
+                del outb
+                gb = 2 * B * T * V * 4 / (min(lt[1:]) * 1e-3) / 1e9
+                r["two_pass_form"] = {"log_softmax_kernel_ms": round(min(lt[1:]), 3), "separate_prune_kernel_ms": round(min(p2[1:]), 3),
+                                      "log_softmax_roofline": {"bound": "hbm", "achieved": round(gb, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gb / 8000.0, 4),
+                                                               "algorithmic_bytes_per_launch": 2 * B * T * V * 4}}
             r["prune_flagged_rows"] = int(ctcdecode_amd._native.lib.ctcd_last_prune_flagged_rows(dec._handle))  # settled by the device's std::sort replay ...
             r["prune_host_rows"] = int(ctcdecode_amd._native.lib.ctcd_last_prune_host_rows(dec._handle))  # ... except these
         if K == 500 and not ps:  # the wide-beam kernel's own roofline block
@@ -509,6 +536,7 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
     run("configs[1] shape with 512 utterances per launch (two workgroups per CU)", 512, 1000, 29, 100)
     run("configs[2] per-GPU shape (256 of 2048 utterances, beam 500, T 2000)", 256, 2000, 29, 500, reps=1)
     run("configs[3] (V=10000, top_n 40, cutoff_prob 0.99)", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99)
+    run("configs[3] fed raw logits (logits_input=True: pre-pass + prune fused)", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99, logits=True)
     run("configs[4] per-GPU shape without the LM (128 of 1024 utterances, T 1500)", 128, 1500, 29, 100)
     arpa = os.path.join(ROOT, "tests", "data", "test.arpa")
     # 128 utterances occupy half the CUs.  The time axis cannot be split, so the idle half is given to the

@@ -244,6 +244,22 @@ class CTCBeamDecoder(object):
         """Test hook: False forces the run-time workspace layout also for small shapes (identical results)."""
         _native.check(_native.lib.ctcd_debug_set_fixed_layout(self._handle, 1 if on else 0))
 
+    def set_fused_logits(self, on=True):
+        """Test hook (logits_input=True): False sends raw logits through the one-wave log_softmax pass and the separate prune
+        instead of the workgroup kernels / the fused logits-to-candidates pass (identical results)."""
+        _native.check(_native.lib.ctcd_debug_set_fused_logits(self._handle, 1 if on else 0))
+
+    def last_prune_rows(self, rows, stride):
+        """Test hook: the vocabulary-prune pass's output of the last call as numpy arrays (counts[rows], labels and values
+        [rows, stride], stride = min(cutoff_top_n, V); entries at or beyond a frame's count are unspecified)."""
+        import numpy as np
+
+        cnt = np.zeros((rows,), np.int32)
+        lab = np.zeros((rows, stride), np.int32)
+        val = np.zeros((rows, stride), np.float32)
+        _native.check(_native.lib.ctcd_debug_prune_rows(self._handle, rows, stride, cnt.ctypes.data, lab.ctypes.data, val.ctypes.data))
+        return cnt, lab, val
+
     def set_timing(self, on=True):
         _native.check(_native.lib.ctcd_set_timing(self._handle, 1 if on else 0))
 

@@ -63,7 +63,7 @@ __global__ void prob_to_log_kernel(const float *in, float *out, size_t n, const 
 }
 
 // Raw-logit input (log_input == 2, an extension: the reference's callers run log_softmax themselves): one wave per frame,
-//   y_j = (x_j - m) - logf(s),  m = max_j x_j,  s = sum_j expf(x_j - m) in float32,
+//   y_j = (x_j - m) - logf(s),  m = max_j x_j (a zero maximum taken as +0),  s = sum_j expf(x_j - m) in float32,
 // where lane l first adds up the terms j = l, l + 64, ... in increasing j and the 64 partial sums are then combined by a
 // butterfly (lane ^ 1, ^ 2, ... ^ 32); expf / logf are the bit-exact restatements of exact_math.h (expf below -88 is 0).
 // The order of the additions is part of the definition: tests/native/core_host.cpp computes the same thing with the C
@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(256) log_softmax_rows_kernel(const float *in, 
     float m = -INFINITY;
     for (int j = lane; j < V; j += 64) { const float v = x[j]; m = v > m ? v : m; }
     for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    m += 0.0f;  // (a zero maximum is +0)
     if (!(m > -INFINITY)) {
       for (int j = lane; j < V; j += 64) y[j] = -INFINITY;
       continue;
@@ -94,6 +95,102 @@ __global__ void __launch_bounds__(256) log_softmax_rows_kernel(const float *in, 
     for (int off = 1; off < 64; off <<= 1) part += __shfl_xor(part, off, 64);
     const float ls = ctcmath::logf_normal(part, tbl);
     for (int j = lane; j < V; j += 64) y[j] = (x[j] - m) - ls;
+  }
+}
+
+// The same normalisation for long rows, shaped for HBM bandwidth: one workgroup of four waves per frame, the row read ONCE
+// with 128-bit loads and held in registers (thread t: the float4s t, t + 256, ...), written once.  The sum keeps the order
+// the definition fixes -- 64 chains, chain l over the terms j = l, l + 64, ... in increasing j -- although no thread holds a
+// chain's terms: the exponentials of 1024 consecutive labels at a time go to LDS (every thread computes four), and one wave
+// per such chunk (the four take turns) extends the 64 chains by sixteen terms each, lane l reading its chain's terms at
+// l + 64 k.  Two chunk buffers, one barrier per chunk; the chains' running values pass from wave to wave through LDS.
+// Requires V % 4 == 0 and V <= 1024 * F4.
+constexpr int kLsmChunk = 1024;  // labels per chunk of exponentials (four per thread)
+struct LsmLds {
+  float terms[2][kLsmChunk];
+  float chain[64];
+  float wmax[4];
+};
+template <int F4>
+__device__ __forceinline__ float wg_exp_sum(const float4 (&v)[F4], int nv4, float m, LsmLds &s, const uint64_t *tbl, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int u = 0; u < F4; ++u) {
+    if (256 * u < nv4) {  // (uniform; chunks past the row's end would add zeros)
+      float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (tid + 256 * u < nv4) {
+        // (two at a time: four interleaved binary64 evaluations on top of the row cost registers -- the other waves hide the latency)
+        e.x = ctcmath::expf_nonpos(v[u].x - m, tbl); e.y = ctcmath::expf_nonpos(v[u].y - m, tbl);
+        __builtin_amdgcn_sched_barrier(0);
+        e.z = ctcmath::expf_nonpos(v[u].z - m, tbl); e.w = ctcmath::expf_nonpos(v[u].w - m, tbl);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      *reinterpret_cast<float4 *>(&s.terms[u & 1][4 * tid]) = e;
+      __syncthreads();
+      if (wave == (u & 3)) {
+        float p = u ? s.chain[lane] : 0.0f;
+        const float *c = &s.terms[u & 1][lane];
+#pragma unroll
+        for (int k = 0; k < kLsmChunk / 64; ++k) p += c[64 * k];
+        s.chain[lane] = p;
+      }
+    }
+  }
+  __syncthreads();
+  float part = s.chain[lane];
+  for (int off = 1; off < 64; off <<= 1) part += __shfl_xor(part, off, 64);
+  return part;
+}
+// the row's maximum (NaN-ignoring, as the one-wave kernel's), known to every thread; contains one barrier
+__device__ __forceinline__ float wg_row_max(float mine, LsmLds &s, int tid) {
+  for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_xor(mine, off, 64); mine = o > mine ? o : mine; }
+  if ((tid & 63) == 0) s.wmax[tid >> 6] = mine;
+  __syncthreads();
+  float m = s.wmax[0];
+  m = s.wmax[1] > m ? s.wmax[1] : m; m = s.wmax[2] > m ? s.wmax[2] : m; m = s.wmax[3] > m ? s.wmax[3] : m;
+  return m + 0.0f;  // (a zero maximum is +0 whichever zero the reduction met first: part of the definition)
+}
+template <int F4>
+__global__ void __launch_bounds__(256, F4 <= 10 ? 5 : 4) log_softmax_rows_wg_kernel(const float *in, float *out, long long rows, const int32_t *seq_lens, int T,
+                                                                                     int V, const uint64_t *tables) {
+  __shared__ uint64_t tbl[64];
+  __shared__ __attribute__((aligned(16))) LsmLds s;
+  const int tid = (int)threadIdx.x, nv4 = V >> 2;
+  if (tid < 64) tbl[tid] = tables[tid];
+  __syncthreads();
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    if (seq_lens) {  // frames beyond the utterance's length are never read (binding.cpp:64-65)
+      const long long b = r / T;
+      if ((int)(r - b * T) >= seq_lens[b]) continue;
+    }
+    const float4 *x4 = reinterpret_cast<const float4 *>(in + (size_t)r * V);
+    float4 *y4 = reinterpret_cast<float4 *>(out + (size_t)r * V);
+    int tq = tid;  // (opaque per frame: the chunks' predicates and offsets are recomputed, not kept across the frame loop)
+    asm volatile("" : "+v"(tq));
+    float4 v[F4];
+#pragma unroll
+    for (int u = 0; u < F4; ++u) {
+      const int i4 = tq + 256 * u;
+      v[u] = i4 < nv4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    float mine = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < F4; ++u) {
+      mine = v[u].x > mine ? v[u].x : mine; mine = v[u].y > mine ? v[u].y : mine;
+      mine = v[u].z > mine ? v[u].z : mine; mine = v[u].w > mine ? v[u].w : mine;
+    }
+    const float m = wg_row_max(mine, s, tid);
+    if (!(m > -INFINITY)) {
+#pragma unroll
+      for (int u = 0; u < F4; ++u)
+        if (tq + 256 * u < nv4) y4[tq + 256 * u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    } else {
+      const float ls = ctcmath::logf_normal(wg_exp_sum<F4>(v, nv4, m, s, tbl, tq), tbl);
+#pragma unroll
+      for (int u = 0; u < F4; ++u)
+        if (tq + 256 * u < nv4) y4[tq + 256 * u] = make_float4((v[u].x - m) - ls, (v[u].y - m) - ls, (v[u].z - m) - ls, (v[u].w - m) - ls);
+    }
+    __syncthreads();  // (the chunk buffers and wmax are reused by the next frame)
   }
 }
 
@@ -119,7 +216,17 @@ struct PruneArgs {
   float *lp;
   unsigned *n_flag, *flag_rows;
   unsigned flag_cap;
+  double cut_exp;            // exp(cutoff_prob)
+  const uint64_t *tables;    // exact_math.h Tables, in global memory
+  float *row_max, *row_lse;  // log_input == 2 (raw logits, prune_logits_wg_kernel): every frame's maximum and logf(sum of exponentials)
 };
+
+// log_input == 2: the value the prune ranks is the frame's log-softmax (x - m) - ls, never stored as a row; m = -inf (no finite
+// logit): -inf everywhere, as log_softmax_rows_kernel defines it
+__device__ __forceinline__ float prune_row_value(const PruneArgs &a, float x, float m, float ls) {
+  if (a.log_input != 2) return x;
+  return m > -INFINITY ? (x - m) - ls : -INFINITY;
+}
 
 __device__ __forceinline__ uint32_t prune_key(float v) {  // order of the doubles the reference compares; -0 == +0
   uint32_t u = __float_as_uint(v);
@@ -373,25 +480,30 @@ __global__ void __launch_bounds__(256) prune_rows_kernel(PruneArgs a) {
 // value starts at 0.0 in log space).  This is the fast form -- a wave-parallel prefix sum and the device library's
 // exp()/log(), not the reference's sequential chain: whenever the comparison with cutoff_prob could go either way before (or
 // at) the stopping point, `flag` is raised and prune_resolve_kernel walks the chain exactly (prune_exact_cut).
-__device__ __forceinline__ int prune_cumulative_cut(const PruneArgs &a, const float *x, const int *sidx, int kept, int lane, bool &flag) {
+__device__ __forceinline__ int prune_cumulative_cut(const PruneArgs &a, const float *x, const int *sidx, int kept, int lane, bool &flag, const uint64_t *tbl) {
+  // cum = log(1 + sum) >= cutoff_prob  <=>  1 + sum >= exp(cutoff_prob) (a.cut_exp, from the host's libm): no logarithm here, and
+  // the probabilities of log-probability rows from expf's own evaluation kept in binary64 (exact_math.h expf_core_f64, ~2e-10):
+  // sums within 1e-8 of the threshold -- fifty times that error -- are not decided here.  (The device library's exp() / log(),
+  // used until round 5, cost the kernels ~35 registers and their constants.)
   int stop = kept;
-  double carry = 0.0;
+  double carry = 1.0;
   for (int i0 = 0; i0 < kept && stop == kept; i0 += 64) {
     const int i = i0 + lane;
     double p = 0.0;
+    bool odd = false;
     if (i < kept) {
-      const double v = (double)(sidx ? x[sidx[i]] : x[i]);  // (sidx == nullptr: x[] already holds the kept values, best first)
-      p = a.log_input ? exp(v) : v;
+      const float v = sidx ? x[sidx[i]] : x[i];  // (sidx == nullptr: x[] already holds the kept values, best first)
+      odd = !(v <= 80.0f) || (!a.log_input && v < 0.0f);  // (outside expf_core_f64's range, a NaN, a negative probability)
+      p = a.log_input ? ctcmath::expf_core_f64(odd ? 0.0f : v, tbl) : (double)v;
     }
-    const double incl = wave_scan_f64_sum(p);
-    const double cum = log(1.0 + carry + incl);
-    const bool near = i < kept && (fabs(cum - a.cutoff_prob) <= 1e-9 * (1.0 + fabs(cum)) || !(cum == cum));
-    const bool hit = i < kept && (cum >= a.cutoff_prob || i + 1 >= a.top_n);
+    const double sum = carry + wave_scan_f64_sum(p);
+    const bool near = i < kept && (odd || fabs(sum - a.cut_exp) <= 1e-8 * a.cut_exp || !(sum == sum));
+    const bool hit = i < kept && (sum >= a.cut_exp || i + 1 >= a.top_n);
     const unsigned long long mh = __ballot(hit), mn = __ballot(near);
     const int firsthit = mh ? __ffsll((long long)mh) - 1 : 64;
     if (mn && (__ffsll((long long)mn) - 1) <= firsthit) flag = true;
     if (mh) stop = i0 + firsthit + 1;
-    carry += f64_from_lane(incl, 63);
+    carry = f64_from_lane(sum, 63);
   }
   flag = __ballot(flag) != 0ull;
   return stop;
@@ -509,7 +621,143 @@ __global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
       flag = __ballot(flag) != 0ull;
       int len = kept;
-      if (a.cutoff_prob < 1.0 && !flag) len = prune_cumulative_cut(a, sval, nullptr, kept, lane, flag);
+      if (a.cutoff_prob < 1.0 && !flag) len = prune_cumulative_cut(a, sval, nullptr, kept, lane, flag, a.tables);
+      if (lane == 0) {
+        a.cnt[r] = len;
+        if (flag) {
+          const unsigned k = atomicAdd(a.n_flag, 1u);
+          if (k < a.flag_cap) a.flag_rows[k] = (unsigned)r;
+        }
+      }
+    }
+    __syncthreads();  // the lists are reused by the next frame
+  }
+}
+
+// Raw logits (log_input == 2) straight into the prune: the frame's log-softmax is never written.  One workgroup per frame as
+// above, but the row -- read once, 128-bit loads -- stays in registers: its maximum and the lower bound of the n-th largest
+// logit come from the first look at it, the sum of exponentials in the order ctcd_log_softmax defines from wg_exp_sum, and only
+// the few dozen labels at or above the bound are ever normalised: y = (x - m) - ls, ranked on y (two logits can round to one y).
+// x -> y is monotone, so a label below the bound cannot outrank one above it; it could TIE with the n-th largest y if that
+// equals the bound's own image -- such a frame is flagged, as are frames that hold a NaN or +inf (no order argument there), and
+// prune_resolve_kernel settles flagged frames from the logits with the frame's (m, ls) stored here.
+// Requires V % 4 == 0, V <= 1024 * F4, cutoff_top_n <= 64.
+__device__ __forceinline__ float prune_key_value(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+template <int F4>
+__global__ void __launch_bounds__(256, F4 <= 4 ? 6 : F4 <= 10 ? 5 : 3) prune_logits_wg_kernel(PruneArgs a, const uint64_t *tables) {
+  extern __shared__ __attribute__((aligned(16))) char psm[];
+  __shared__ uint64_t tbl[64];
+  __shared__ __attribute__((aligned(16))) LsmLds s;
+  __shared__ uint32_t s_bound[4];
+  __shared__ int s_cnt;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.top_n < a.V ? a.top_n : a.V;
+  const int nq = (n + 3) >> 2;  // per-wave share
+  float *sval = (float *)psm;
+  uint32_t *ckey = (uint32_t *)(sval + ((3 * a.stride + 3) & ~3));
+  int *cidx = (int *)ckey + kPruneCand;
+  float *cval = (float *)(cidx + kPruneCand);
+  const int nv4 = a.V >> 2;
+  if (tid < 64) tbl[tid] = tables[tid];
+  __syncthreads();
+  for (long long r = blockIdx.x; r < a.rows; r += gridDim.x) {
+    if (a.seq_lens) {
+      const long long b = r / a.T;
+      int len = a.seq_lens[b];
+      len = len < 0 ? 0 : len;
+      if ((int)(r - b * a.T) >= len) continue;
+    }
+    const float4 *x4 = reinterpret_cast<const float4 *>(a.in + (size_t)r * a.V);
+    // (the thread index, opaque per frame: derived from the hoisted one, every chunk's predicate and offsets would be kept in
+    //  registers across the frame loop -- thirty-odd of them, spilled)
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    float4 v[F4];
+#pragma unroll
+    for (int u = 0; u < F4; ++u) {
+      const int i4 = tq + 256 * u;
+      v[u] = i4 < nv4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    if (tid == 0) s_cnt = 0;
+    // (maxima on the values themselves -- a NaN is skipped, as by the one-wave kernel; the key of the thread's maximum is the
+    //  maximum of its keys whenever the row holds no NaN, and rows that do are flagged below)
+    float mine = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < F4; ++u) mine = fmaxf(fmaxf(fmaxf(mine, v[u].x), fmaxf(v[u].y, v[u].z)), v[u].w);
+    const uint32_t lmax = prune_key(mine);
+    uint32_t bw = 0;
+    for (int bit = 31; bit >= 12; --bit) {
+      const uint32_t trial = bw | (1u << bit);
+      if (__popcll(__ballot(lmax >= trial)) >= nq) bw = trial;
+    }
+    if (lane == 0) s_bound[wave] = bw;
+    const float m = wg_row_max(mine, s, tid);  // (contains a barrier: s_bound is in place)
+    uint32_t bound = s_bound[0];
+    bound = s_bound[1] < bound ? s_bound[1] : bound;
+    bound = s_bound[2] < bound ? s_bound[2] : bound;
+    bound = s_bound[3] < bound ? s_bound[3] : bound;
+    float ls = 0.0f;
+    bool rowflag = !(m > -INFINITY);
+    if (!rowflag) {
+      const float sum = wg_exp_sum<F4>(v, nv4, m, s, tbl, tq);
+      rowflag = !(sum == sum);  // a NaN or +inf among the logits: (x - m) is a NaN for it, and so is the sum
+      ls = ctcmath::logf_normal(sum, tbl);
+    }
+    if (tid == 0) { a.row_max[r] = m; a.row_lse[r] = ls; }
+    // the labels at or above the bound, compared as values: for numbers, x >= value(bound) <=> key(x) >= bound (the key is monotone
+    // and value(bound)'s key is bound itself); a bound below every number's key decodes to a NaN pattern: everything is listed
+    const float bf = prune_key_value(bound);
+    const bool all = bound <= prune_key(-INFINITY);
+    if (!rowflag && (all || mine >= bf)) {
+#pragma unroll
+      for (int u = 0; u < F4; ++u) {
+        const int i4 = tq + 256 * u;
+        if (i4 < nv4) {
+          const float xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (all || xs[e] >= bf) {
+              const int p = atomicAdd(&s_cnt, 1);
+              if (p < kPruneCand) { const float y = (xs[e] - m) - ls; ckey[p] = prune_key(y); cidx[p] = 4 * i4 + e; cval[p] = y; }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int ns = s_cnt;
+    if (wave == 0) {
+      bool flag = rowflag || ns > kPruneCand;
+      int kept = 0;
+      int *och = a.ch + (size_t)r * a.stride;
+      float *olp = a.lp + (size_t)r * a.stride;
+      if (!flag) {
+        // the image of the bound: no label outside the list has a larger y
+        const uint32_t ybkey = bound ? prune_key((prune_key_value(bound) - m) - ls) : 0u;
+        for (int p = ns + lane; p < ((ns + 3) & ~3); p += 64) ckey[p] = 0u;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int q0 = 0; q0 < ns; q0 += 64) {
+          const int q = q0 + lane;
+          const uint32_t mine_k = q < ns ? ckey[q] : 0xFFFFFFFFu;
+          int gg = 0, ee = 0;
+          for (int o = 0; o < ns; o += 4) {
+            const uint4 k4 = *reinterpret_cast<const uint4 *>(ckey + o);
+            gg += (k4.x > mine_k) + (k4.y > mine_k) + (k4.z > mine_k) + (k4.w > mine_k);
+            ee += (k4.x == mine_k) + (k4.y == mine_k) + (k4.z == mine_k) + (k4.w == mine_k);
+          }
+          const bool keep = q < ns && gg < n;
+          if (keep && gg + ee > n) flag = true;   // equal values straddle the cut: std::sort decides which of them are kept
+          if (keep && ee > 1) flag = true;        // equal kept values: their order is std::sort's business
+          if (keep && mine_k <= ybkey) flag = true;  // a label outside the list could tie with this one
+          if (keep && ee == 1) { och[gg] = cidx[q]; olp[gg] = cval[q]; sval[gg] = cval[q]; }
+          kept += __popcll(__ballot(keep));
+        }
+        if (kept > n) kept = n;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      flag = __ballot(flag) != 0ull;
+      int len = kept;
+      if (a.cutoff_prob < 1.0 && !flag) len = prune_cumulative_cut(a, sval, nullptr, kept, lane, flag, tbl);
       if (lane == 0) {
         a.cnt[r] = len;
         if (flag) {
@@ -571,11 +819,11 @@ __host__ __device__ inline size_t prune_resolve_lds_bytes(int V, int n) {
 }
 // decoder_utils.cpp:25-32 to the letter, by one thread: cum = log_sum_exp<double>(cum, log p_i) from cum = 0.0 over the sorted
 // candidates until cum >= cutoff_prob or cutoff_top_n of them are taken; every log / exp the bit-exact one.
-__device__ int prune_exact_cut(const PruneArgs &a, const float *row, const int *sidx, int n) {
+__device__ int prune_exact_cut(const PruneArgs &a, const float *row, const int *sidx, int n, float m, float ls) {
   double cum = 0.0;
   int keep = 0;
   for (int i = 0; i < n; ++i) {
-    const double v = (double)row[sidx[i]];
+    const double v = (double)prune_row_value(a, row[sidx[i]], m, ls);
     cum = ctcmath::lse_f64(cum, a.log_input ? v : ctcmath::log_f64(v, g_t64), g_t64);
     ++keep;
     if (cum >= a.cutoff_prob || keep >= a.top_n) break;
@@ -601,8 +849,9 @@ __global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArg
   for (unsigned k = blockIdx.x; k < nf; k += gridDim.x) {
     const long long r = (long long)a.flag_rows[k];
     const float *row = a.in + (size_t)r * V;
+    const float m = a.log_input == 2 ? a.row_max[r] : 0.0f, ls = a.log_input == 2 ? a.row_lse[r] : 0.0f;  // (raw logits: prune_logits_wg_kernel)
     __syncthreads();
-    for (int i = tid; i < V; i += kResolveThreads) v[i] = ((unsigned long long)prune_key(row[i]) << 32) | (unsigned)i;
+    for (int i = tid; i < V; i += kResolveThreads) v[i] = ((unsigned long long)prune_key(prune_row_value(a, row[i], m, ls)) << 32) | (unsigned)i;
     __syncthreads();
     // decoder_utils.cpp:19-20: (index, double) pairs in index order, std::sort on the value alone, descending
     // (stl_emul.h: long ranges split by the whole workgroup, the rest by one thread per range; only the ranges that reach
@@ -614,12 +863,12 @@ __global__ void __launch_bounds__(kResolveThreads) prune_resolve_kernel(PruneArg
       float *olp = a.lp + (size_t)r * a.stride;
       for (int q = lane; q < n; q += 64) {
         const int idx = (int)(uint32_t)v[q];
-        float val = row[idx];
+        float val = prune_row_value(a, row[idx], m, ls);
         if (!a.log_input) val = (float)ctcmath::log_f64((double)val + (double)FLT_MIN, g_t64);  // decoder_utils.cpp:42
         och[q] = idx; olp[q] = val; sidx[q] = idx;
       }
       __threadfence_block();  // the wave's own writes (LDS or global) are visible to its lane 0
-      if (lane == 0) a.cnt[r] = a.cutoff_prob < 1.0 ? prune_exact_cut(a, row, sidx, n) : n;
+      if (lane == 0) a.cnt[r] = a.cutoff_prob < 1.0 ? prune_exact_cut(a, row, sidx, n, m, ls) : n;
     }
   }
 }
@@ -817,7 +1066,7 @@ struct ctcd_decoder {
   int cu_count = 0;
   long long lds_floor = -1;  // CTCD_LDS_FLOOR (experiments): dynamic LDS bytes every decode launch asks for at least
   int cu_sharing = -1;       // ctcd_set_cu_sharing: 1 = always launch the two-workgroups-per-CU build, 0 = never, -1 = when B > #CUs
-  Buf pool, status, tables, logp, lsm, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, far, st_args;
+  Buf pool, status, tables, logp, lsm, flags, stage_in, stage_out, pr_cnt, pr_ch, pr_lp, pr_ml, far, st_args;
   Buf prune_in, prune_out, st_lens;  // own staging: the host-pointer entry points keep their tensors in stage_in/out
   Buf cb_blocks, cb_ctl;             // scorer hook: the temporary streams' blocks of a one-shot decode; per-item control words
   int32_t *h_cb = nullptr;           // ... and, page-locked, what a round reports: [status | frames done | #misses]
@@ -830,6 +1079,7 @@ struct ctcd_decoder {
   bool timing = false;
   bool profile = false, dbg_on = false;
   bool no_fixed_layout = false;  // debugging: always use the run-time workspace layout
+  bool no_fused_logits = false;  // tests: raw logits always through the one-wave log_softmax pass and the separate prune
   Buf prof, dbg, tl;
   int tl_f0 = 0, tl_nf = 0;
   int status_items = 0;          // items of the launch whose status words (and shape statistic) are in d->status
@@ -1004,7 +1254,7 @@ void ctcd_destroy(ctcd_decoder *d) {
   if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
   if (d->ev_in) (void)hipEventDestroy(d->ev_in);
   if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->ev3); }
-  d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->lsm.release(); d->flags.release();
+  d->pool.release(); d->status.release(); d->prof.release(); d->tables.release(); d->logp.release(); d->lsm.release(); d->pr_ml.release(); d->flags.release();
   d->stage_in.release(); d->stage_out.release(); d->pr_cnt.release(); d->pr_ch.release(); d->pr_lp.release(); d->far.release(); d->st_args.release(); d->prune_in.release(); d->prune_out.release(); d->st_lens.release();
   d->dbg.release(); d->tl.release();
   d->cb_blocks.release(); d->cb_ctl.release();
@@ -1039,6 +1289,23 @@ int ctcd_last_subtree_search(const ctcd_decoder *d) { return d ? d->last_subtree
 int ctcd_set_threads(ctcd_decoder *d, int t) {
   if (!d || t < 0 || t > 1024 || (t && (t < 64 || (t & (t - 1))))) return fail(CTCD_EINVAL, "threads must be 0 (automatic) or a power of two in [64, 1024]");
   d->threads = t;
+  return CTCD_OK;
+}
+
+// log_softmax of every frame (ctcd_log_softmax's definition): long rows by a workgroup each, short ones by a wave each
+static int launch_log_softmax(ctcd_decoder *d, const float *in, float *out, long long rows, const int32_t *lens, int T, int V, hipStream_t stream) {
+  const uint64_t *tb = (const uint64_t *)d->tables.p;
+  if (V % 4 == 0 && V > 256 && V <= 16384 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && !d->no_fused_logits) {
+    const dim3 grid((unsigned)std::min<long long>(rows, 256 * 32));
+    if (V <= 1024) hipLaunchKernelGGL(log_softmax_rows_wg_kernel<1>, grid, dim3(256), 0, stream, in, out, rows, lens, T, V, tb);
+    else if (V <= 2048) hipLaunchKernelGGL(log_softmax_rows_wg_kernel<2>, grid, dim3(256), 0, stream, in, out, rows, lens, T, V, tb);
+    else if (V <= 4096) hipLaunchKernelGGL(log_softmax_rows_wg_kernel<4>, grid, dim3(256), 0, stream, in, out, rows, lens, T, V, tb);
+    else if (V <= 10240) hipLaunchKernelGGL(log_softmax_rows_wg_kernel<10>, grid, dim3(256), 0, stream, in, out, rows, lens, T, V, tb);
+    else hipLaunchKernelGGL(log_softmax_rows_wg_kernel<16>, grid, dim3(256), 0, stream, in, out, rows, lens, T, V, tb);
+  } else {
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 256 * 64)), dim3(256), 0, stream, in, out, rows, lens, T, V, tb);
+  }
+  HIP_TRY(hipGetLastError());
   return CTCD_OK;
 }
 
@@ -1165,14 +1432,15 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   // the rows the pre-passes cover (resumed launches of the scorer hook start inside the rows: StreamCall::row_lens)
   const int32_t *pre_lens = (sc && sc->row_lens) ? sc->row_lens : seq_lens;
 
-  if (log_input == 2) {  // raw logits: normalise once, in HBM; everything below sees log-probabilities
+  // raw logits in front of a vocabulary prune: one pass does both (prune_logits_wg_kernel -- the normalised rows are never written).
+  // Not with a scorer: the LM tier reads the blank's log-probability from the rows themselves (ctc_beam_search_decoder.cpp:78).
+  const bool fuse_logits = log_input == 2 && dims.use_rank_table && T > 0 && !scorer && !d->no_fused_logits && V % 4 == 0 && V > 256 &&
+                           V <= 16384 && std::min(cutoff_top_n, V) <= 64 && ((uintptr_t)probs & 15) == 0;
+  if (log_input == 2 && !fuse_logits) {  // raw logits: normalise once, in HBM; everything below sees log-probabilities
     if (T > 0) {
       if ((rc = d->lsm.ensure((size_t)B * T * V * 4))) return rc;
       if (pre_lens) HIP_TRY(hipMemsetAsync(d->lsm.p, 0, (size_t)B * T * V * 4, stream));  // frames past an utterance's end stay defined
-      const long long rows = (long long)B * T;
-      hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 256 * 64)), dim3(256), 0, stream, probs,
-                         (float *)d->lsm.p, rows, pre_lens, T, V, (const uint64_t *)d->tables.p);
-      HIP_TRY(hipGetLastError());
+      if ((rc = launch_log_softmax(d, probs, (float *)d->lsm.p, (long long)B * T, pre_lens, T, V, stream))) return rc;
       probs = (const float *)d->lsm.p;
     }
     log_input = 1;
@@ -1210,6 +1478,12 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
           : V <= 4096 ? (const void *)prune_rows_wg_kernel<4> : V <= 10240 ? (const void *)prune_rows_wg_kernel<10>
           : (const void *)prune_rows_wg_kernel<16>;
     }
+    if (fuse_logits) {  // (same shape conditions)
+      pfn = V <= 1024 ? (const void *)prune_logits_wg_kernel<1> : V <= 2048 ? (const void *)prune_logits_wg_kernel<2>
+          : V <= 4096 ? (const void *)prune_logits_wg_kernel<4> : V <= 10240 ? (const void *)prune_logits_wg_kernel<10>
+          : (const void *)prune_logits_wg_kernel<16>;
+      if ((rc = d->pr_ml.ensure((size_t)rows * 8))) return rc;
+    }
     const size_t psm_launch = wg_kernel ? (3 * (size_t)stride + 3 * kPruneCand + 4) * 4 : psm;
     // (measured: a persistent grid of 1280 or 2560 workgroups is slower, 16 k / 32 k the same)
     const int blocks_launch = wg_kernel ? (int)std::min<long long>(rows, 256 * 32) : blocks;
@@ -1233,7 +1507,10 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     pa.in = probs; pa.seq_lens = pre_lens; pa.T = T; pa.V = V; pa.top_n = cutoff_top_n; pa.log_input = log_input;
     pa.stride = stride; pa.rows = rows; pa.cutoff_prob = cutoff_prob; pa.cnt = (int *)d->pr_cnt.p; pa.ch = (int *)d->pr_ch.p;
     pa.lp = (float *)d->pr_lp.p; pa.n_flag = n_flag; pa.flag_rows = flag_rows; pa.flag_cap = cap;
-    void *pargs[] = {&pa};
+    pa.cut_exp = std::exp(cutoff_prob); pa.tables = (const uint64_t *)d->tables.p;
+    pa.row_max = fuse_logits ? (float *)d->pr_ml.p : nullptr; pa.row_lse = fuse_logits ? (float *)d->pr_ml.p + rows : nullptr;
+    const uint64_t *ptables = (const uint64_t *)d->tables.p;
+    void *pargs[] = {&pa, (void *)&ptables};  // (the second argument: prune_logits_wg_kernel only)
     if (d->timing) HIP_TRY(hipEventRecord(d->ev2, stream));
     HIP_TRY(hipLaunchKernel(pfn, dim3(blocks_launch), dim3(wpb * 64), pargs, psm_launch, stream));
     HIP_TRY(hipGetLastError());
@@ -2125,11 +2402,7 @@ int ctcd_log_softmax(ctcd_decoder *d, const float *logits, const int32_t *seq_le
       d->tables_ready = true;
     }
   }
-  const long long rows = (long long)B * T;
-  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 256 * 64)), dim3(256), 0, stream, logits, out, rows,
-                     seq_lens, T, V, (const uint64_t *)d->tables.p);
-  HIP_TRY(hipGetLastError());
-  return CTCD_OK;
+  return launch_log_softmax(d, logits, out, (long long)B * T, seq_lens, T, V, stream);
 }
 
 // HIP-event timing of the decode kernel alone, on the stream it is launched on (bench.py's roofline figure).
@@ -2187,6 +2460,15 @@ int ctcd_debug_set_prune_resolve(ctcd_decoder *d, int on) {
   return CTCD_OK;
 }
 
+// Raw-logit input (log_input == 2): 1 (default) = long rows take the workgroup kernels (log_softmax_rows_wg_kernel; in front of a
+// vocabulary prune the fused prune_logits_wg_kernel), 0 = always the one-wave log_softmax pass followed by the separate prune.
+// Results are identical; the switch exists so tests can compare the two.
+int ctcd_debug_set_fused_logits(ctcd_decoder *d, int on) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  d->no_fused_logits = on == 0;
+  return CTCD_OK;
+}
+
 // Barrier timeline of batch item 0 (profiling build): call with out == NULL to arm frames [frame0, frame0 + nframes) of
 // the following decodes, with out != NULL (int64 [16][ctcd_debug_timeline_cap()]) to fetch: per wave, the shader clock
 // at arrival at / departure from each barrier, in program order.
@@ -2241,6 +2523,22 @@ long long ctcd_last_prune_flagged_rows(ctcd_decoder *d) {
     d->flagged_pending = false;
   }
   return d->prune_flagged_rows;
+}
+
+// The vocabulary-prune pass's output of the last call, copied to host memory (test hook: lets a test compare prune variants
+// directly): cnt[rows], labels / values [rows][stride] with stride = min(cutoff_top_n, V); entries at or beyond a frame's count
+// are unspecified.  Waits for the launch stream.
+int ctcd_debug_prune_rows(ctcd_decoder *d, long long rows, int stride, int32_t *cnt, int32_t *labels, float *values) {
+  if (!d || rows < 0 || stride < 1 || !cnt || !labels || !values) return fail(CTCD_EINVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(d->mu);
+  CTC_ON_DEVICE(d->device);
+  if (d->pr_cnt.cap < (size_t)rows * 4 || d->pr_ch.cap < (size_t)rows * stride * 4 || d->pr_lp.cap < (size_t)rows * stride * 4)
+    return fail(CTCD_EINVAL, "the last call's prune pass did not produce that many frames");
+  HIP_TRY(hipStreamSynchronize(d->last_stream));
+  HIP_TRY(hipMemcpy(cnt, d->pr_cnt.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(labels, d->pr_ch.p, (size_t)rows * stride * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(values, d->pr_lp.p, (size_t)rows * stride * 4, hipMemcpyDeviceToHost));
+  return CTCD_OK;
 }
 
 // The same words, fetched without blocking: the copy into `host_status` (B words, page-locked memory for a truly

@@ -112,6 +112,28 @@ CTC_HD float expf_nonpos(float x, const uint64_t *tbl) {
   return (float)(y * s);
 }
 
+// The same evaluation before its final rounding to float: exp(x) as a double with a relative error of ~2e-10 (the degree-3
+// polynomial's), for -88 <= x <= 80 (below: 0).  NOT part of any bit-exact result -- the vocabulary prune's fast cumulative cut
+// uses it where a comparison has nine digits to spare, and leaves everything closer to the exact chain.
+CTC_HD double expf_core_f64(float x, const uint64_t *tbl) {
+  if (x < -88.0f) return 0.0;
+  const double InvLn2N = 0x1.71547652b82fep+5;
+  const double Shift = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
+  double xd = (double)x;
+  double kds = __builtin_fma(InvLn2N, xd, Shift);
+  uint64_t ki = f64_to_bits(kds);
+  double kd = kds - Shift;
+  double r = __builtin_fma(InvLn2N, xd, -kd);
+  uint64_t t = tbl[ki & 31] + (ki << 47);
+  double s = bits_to_f64(t);
+  double z = __builtin_fma(r, C0, C1);
+  double r2 = r * r;
+  double y = __builtin_fma(r, C2, 1.0);
+  y = __builtin_fma(z, r2, y);
+  return y * s;
+}
+
 // logf for normal positive finite x (the log-sum-exp domain is [1, 2]).
 // glibc e_logf.c, FMA build:
 //   tmp = ix - 0x3f330000; i = (tmp >> 19) % 16; k = (int)tmp >> 23; iz = ix - (tmp & 0xff800000)

@@ -60,7 +60,7 @@ int ctcd_beam_decode(ctcd_decoder *dec, const float *probs, const int32_t *seq_l
 
 /* log_softmax over the last axis of float32 [B, T, V] device memory, `out` may alias `logits` (no reference counterpart:
  * its callers run torch's log_softmax before decode(), README.md:30-38).  This is what log_input == 2 applies.  Defined
- * to the bit: y_j = (x_j - m) - logf(s), m = max x, s = sum_j expf(x_j - m) in float32 with lane l = j mod 64 adding its
+ * to the bit: y_j = (x_j - m) - logf(s), m = max x (NaNs skipped, a zero maximum taken as +0), s = sum_j expf(x_j - m) in float32 with lane l = j mod 64 adding its
  * terms in increasing j and the 64 partial sums combined by a butterfly (^1, ^2, ... ^32); expf / logf as in glibc, expf
  * below -88 taken as 0.  Frames at or beyond seq_lens[b] are not touched.  Asynchronous on `stream`. */
 int ctcd_log_softmax(ctcd_decoder *dec, const float *logits, const int32_t *seq_lens, int B, int T, int V, float *out, void *stream);
@@ -222,6 +222,14 @@ int ctcd_debug_set_fixed_layout(ctcd_decoder *dec, int on);
 /* Test hook: 1 (default) = the std::sort replay of flagged prune frames works in LDS when the row fits, 0 = always in
  * global memory, the path of rows beyond ~11 000 labels (identical results). */
 int ctcd_debug_set_prune_resolve(ctcd_decoder *dec, int on);
+/* Test hook for log_input == 2: 1 (default) = rows of more than 256 labels (a multiple of four) are normalised by a workgroup
+ * each, and in front of a vocabulary prune not at all -- one kernel reads the logits and emits the kept candidates' normalised
+ * values; 0 = always the one-wave log_softmax pass followed by the separate prune (identical results). */
+int ctcd_debug_set_fused_logits(ctcd_decoder *dec, int on);
+/* Test hook: the vocabulary-prune pass's output of the last call (get_pruned_log_probs, decoder_utils.cpp:10-45, per frame), copied
+ * to HOST memory: cnt[rows], labels / values [rows][stride], stride = min(cutoff_top_n, V); entries at or beyond a frame's count
+ * are unspecified.  Waits for the launch stream. */
+int ctcd_debug_prune_rows(ctcd_decoder *dec, long long rows, int stride, int32_t *cnt, int32_t *labels, float *values);
 /* Tuning aid (instrumented build): per-wave shader-clock stamps at every workgroup barrier of batch item 0 during frames
  * [frame0, frame0 + nframes).  out == NULL arms the following decodes; out != NULL (int64 [16][ctcd_debug_timeline_cap()])
  * fetches the stamps, arrival and departure alternating, in program order (tools/barrier_timeline.py). */

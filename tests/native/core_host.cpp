@@ -255,6 +255,7 @@ extern "C" void ctccore_log_softmax_rows(const float *x, long long rows, int V, 
     float *yr = out + (size_t)r * V;
     float m = -INFINITY;
     for (int j = 0; j < V; ++j) m = xr[j] > m ? xr[j] : m;
+    m += 0.0f;  // (a zero maximum is +0)
     if (!(m > -INFINITY)) {
       for (int j = 0; j < V; ++j) yr[j] = -INFINITY;
       continue;

@@ -864,7 +864,7 @@ def test_logits_input_prepass(torch_mod):
 
     torch = torch_mod
     rng = np.random.default_rng(5)
-    for V in (1, 2, 29, 64, 65, 130, 1000):
+    for V in (1, 2, 29, 64, 65, 130, 1000, 260, 1024, 2052, 4096, 10240, 16384, 16388):  # (> 256 and a multiple of 4: one workgroup per row)
         x = (rng.standard_normal((3, 17, V)) * 4).astype(np.float32)
         x[0, 1] -= 200.0
         x[1, 2, ::3] = -np.inf
@@ -889,6 +889,99 @@ def test_logits_input_prepass(torch_mod):
         # device-resident logits through the HBM-to-HBM entry as well
         d2 = dec.decode_device(torch.from_numpy(logits).cuda(), torch.from_numpy(sl).cuda())
         assert np.array_equal(d2[1].cpu().numpy().view(np.uint32), sc.numpy().view(np.uint32))
+
+
+def _logit_rows_for_prune(rng, T, V):
+    """Frames that exercise every branch of the logits -> candidates pass: plain, quantised (ties in x), wide spread (distinct
+    logits that round to one normalised value), plateaus at the cut, -inf entries, a frame without a finite logit, a far outlier."""
+    x = (rng.standard_normal((T, V)) * 3).astype(np.float32)
+    for t in range(T):
+        kind = t % 9
+        if kind == 1:
+            x[t] = np.round(x[t] * 2) / 2                      # few hundred distinct values: ties everywhere
+        elif kind == 2:
+            x[t] = np.round(x[t])                                # coarser still
+        elif kind == 3:
+            x[t] += 60000.0                                      # a large offset: the logits are quantised to 2^-8, m is huge
+        elif kind == 4:
+            x[t] = x[t] * 1e-4 + 9.0                             # all within 1e-3: y ~ -log V, many x share a y
+        elif kind == 5:
+            x[t, ::3] = -np.inf
+        elif kind == 6:
+            x[t] = -np.inf if t % 2 == 0 else -7.25              # no finite logit / every value equal
+        elif kind == 7:
+            x[t, rng.integers(0, V)] += 200.0                    # exp(x - m) underflows everywhere else
+        elif kind == 8:
+            x[t] = -np.abs(x[t]) * 30                            # most terms below the -88 cutoff of expf
+    return x
+
+
+@pytest.mark.parametrize("V,top_n,cp", [(260, 40, 1.0), (1000, 40, 0.9), (2048, 64, 1.0), (5000, 40, 0.6), (10240, 40, 1.0), (10240, 40, 0.95),
+                                        (12000, 7, 1.0), (16384, 40, 0.99)])
+def test_fused_logits_prune_equals_log_softmax_then_prune(torch_mod, V, top_n, cp):
+    """log_input == 2 in front of a vocabulary prune: ONE kernel reads the logits and emits the kept candidates (the normalised
+    rows are never written).  Its per-frame output -- count, labels, values -- must equal, bit for bit, what ctcd_log_softmax
+    followed by the separate prune produces (debug switch), tie frames and the cumulative cut included; the normalised rows'
+    definition is checked against its host twin, and the decode against the oracle fed the host twin's rows."""
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    torch = torch_mod
+    rng = np.random.default_rng(V + top_n)
+    B, T, K = 3, 27, 20
+    logits = np.stack([_logit_rows_for_prune(rng, T, V) for _ in range(B)])
+    sl = np.array([T, T - 5, 0], np.int32)
+    kw = dict(beam_width=K, cutoff_top_n=top_n, cutoff_prob=cp, logits_input=True, device="cuda:0")
+    stride = min(top_n, V)
+    res = {}
+    for fused in (True, False):
+        dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], **kw)
+        dec.set_fused_logits(fused)
+        out, sc, ts, ln = dec.decode(torch.from_numpy(logits), torch.from_numpy(sl))
+        cnt, lab, val = dec.last_prune_rows(B * T, stride)
+        res[fused] = (out.numpy(), sc.numpy(), ts.numpy(), ln.numpy(), cnt, lab, val, n.lib.ctcd_last_prune_flagged_rows(dec._handle))
+    a, b = res[True], res[False]
+    assert np.array_equal(a[4], b[4]), "counts differ in frames %s" % np.nonzero(a[4] != b[4])[0][:10]
+    for r in range(B * T):
+        c = int(a[4][r])
+        assert np.array_equal(a[5][r, :c], b[5][r, :c]), "labels of frame %d" % r
+        assert np.array_equal(a[6][r, :c].view(np.uint32), b[6][r, :c].view(np.uint32)), "values of frame %d" % r
+    for k in range(4):
+        assert np.array_equal(a[k], b[k]), "decode output %d" % k
+    assert a[7] > 0 and b[7] > 0  # tie frames went through the std::sort replay on both sides
+    # (the fused pass may flag a few more frames than the two-pass form: its NaN / +inf / image-of-the-bound guards)
+    want = ou.decode(ou.log_softmax_rows(logits), sl, beam=K, cutoff_top_n=top_n, cutoff_prob=cp,
+                     which="reference" if ou.have_reference() else "restated")
+    got = dict(tokens=a[0], scores=a[1], timesteps=a[2], lens=a[3])
+    ou.assert_same(_with_nres(got, want), want, "fused logits V=%d" % V)
+
+
+def test_fused_logits_nan_and_inf_rows(torch_mod):
+    """Frames holding NaN or +inf: no order argument applies, the fused pass hands them to the replay -- same output as the
+    two-pass form (whose treatment of NaN is the library's own definition: below every number)."""
+    import ctcdecode_amd
+
+    torch = torch_mod
+    rng = np.random.default_rng(99)
+    B, T, V, K = 2, 12, 1024, 10
+    logits = (rng.standard_normal((B, T, V)) * 2).astype(np.float32)
+    logits[0, 1, 5] = np.nan
+    logits[0, 2, ::7] = np.nan
+    logits[0, 3, 17] = np.inf
+    logits[1, 4, 100:120] = np.inf
+    logits[1, 5] = np.nan
+    res = {}
+    for fused in (True, False):
+        dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], beam_width=K, cutoff_top_n=40, logits_input=True, device="cuda:0")
+        dec.set_fused_logits(fused)
+        out, sc, ts, ln = dec.decode(torch.from_numpy(logits))
+        cnt, lab, val = dec.last_prune_rows(B * T, 40)
+        res[fused] = (cnt, lab, out.numpy(), ln.numpy())
+    assert np.array_equal(res[True][0], res[False][0])
+    for r in range(B * T):
+        c = int(res[True][0][r])
+        assert np.array_equal(res[True][1][r, :c], res[False][1][r, :c]), r
+    assert np.array_equal(res[True][2], res[False][2]) and np.array_equal(res[True][3], res[False][3])
 
 
 def test_prune_tie_replay_patterns(torch_mod):
