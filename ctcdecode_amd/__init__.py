@@ -637,6 +637,39 @@ class OnlineCTCBeamDecoder(object):
                 if is_eos_s[b]:
                     ln = T if lens_cpu is None else max(0, min(int(lens_cpu[b]), T))
                     out_T = max(out_T, int(_native.lib.ctcd_stream_frames(ptrs[b])) + ln)
+        if any_eos and not (self._scorer is not None and isinstance(self._scorer, CallbackScorer)) and out_T <= 65536 and V <= 65535:
+            # streams end: their results leave the GPU as compact records and are expanded on the host, straight into tensors of the
+            # reference's sizes (binding.cpp:186-205) -- the allocator below is called once the kernel has run and R, L are known
+            made = {}
+
+            def alloc(_user, R, L, p_tok, p_ts):
+                try:
+                    pin = B * R * L > 0
+                    made["tok"] = torch.empty((B, R, L), dtype=torch.int32, pin_memory=pin)
+                    made["ts"] = torch.empty((B, R, L), dtype=torch.int32, pin_memory=pin)
+                    p_tok[0] = made["tok"].data_ptr()
+                    p_ts[0] = made["ts"].data_ptr()
+                    return 0
+                except Exception as e:  # (reported through the return code: no exception crosses the C frame)
+                    made["error"] = e
+                    return 1
+
+            cb = _native.RESULT_ALLOC_FN(alloc)
+            scores = torch.empty((B, K), dtype=torch.float32, pin_memory=True)
+            out_len = torch.empty((B, K), dtype=torch.int32, pin_memory=True)
+            nres = torch.empty((B,), dtype=torch.int32, pin_memory=True)
+            R, L = ctypes.c_int(0), ctypes.c_int(0)
+            with torch.cuda.device(self._device):
+                stream = torch.cuda.current_stream(self._device).cuda_stream
+                rc = _native.lib.ctcd_stream_decode_to_host(
+                    self._handle, ptrs, eos, probs.data_ptr(), lens_cpu.data_ptr() if lens_cpu is not None else None, B, T, V, K, self._num_processes,
+                    float(self._cutoff_prob), int(self._cutoff_top_n), int(self._blank_id), self._log_probs, cb, None,
+                    scores.data_ptr(), out_len.data_ptr(), nres.data_ptr(), out_T, ctypes.byref(R), ctypes.byref(L), stream)
+            self._ptr_cache = None  # (ended streams are not decoded again: the next call brings other states)
+            if "error" in made:
+                raise made["error"]
+            self._check(rc)
+            return made["tok"], scores, made["ts"], out_len
         with torch.cuda.device(self._device):
             scr = getattr(self, "_scratch", None)
             if scr is None or scr[0].shape[0] != B:

@@ -35,9 +35,12 @@ inline void stream_row(int32_t *dst, const int32_t *src, int n, int T) {
 // One item: the entries come in trie (DFS) order.  The label sequence of entry j is built in a cache-resident row buffer
 // -- it keeps what j shares with its predecessor, only the entry's own labels are written into it -- and streamed out to
 // row `row` of the two tensors, zeros behind it.  Rows without a result are zeroed.
-inline void expand_item_host(const int32_t *hdr, const int32_t *ent, const uint32_t *rag, int b, int K, int T, int32_t *tok, int32_t *ts) {
+// (R rows of T labels per item in the output; K = the entries' stride in `ent` -- the beam width.  The one-shot decode has R == K;
+//  a streaming call's results are sized to the most results / the longest beam of the batch, binding.cpp:186-205)
+inline void expand_item_host(const int32_t *hdr, const int32_t *ent, const uint32_t *rag, int b, int K, int T, int32_t *tok, int32_t *ts, int R = -1) {
+  if (R < 0) R = K;
   const int nres = hdr[(size_t)b * 4];
-  int32_t *tk0 = tok + (size_t)b * K * T, *ts0 = ts + (size_t)b * K * T;
+  int32_t *tk0 = tok + (size_t)b * R * T, *ts0 = ts + (size_t)b * R * T;
   std::vector<unsigned long long> used((size_t)(K + 63) / 64, 0ull);
   std::vector<int32_t> buf((size_t)2 * T + 8, 0);
   int32_t *bt = buf.data(), *bs = buf.data() + T + 4;
@@ -54,7 +57,7 @@ inline void expand_item_host(const int32_t *hdr, const int32_t *ent, const uint3
     stream_row(ts0 + (size_t)row * T, bs, dep, T);
     used[(size_t)row >> 6] |= 1ull << (row & 63);
   }
-  for (int p = 0; p < K; ++p)
+  for (int p = 0; p < R; ++p)
     if (!((used[(size_t)p >> 6] >> (p & 63)) & 1ull)) {
       stream_row(tk0 + (size_t)p * T, bt, 0, T);
       stream_row(ts0 + (size_t)p * T, bs, 0, T);

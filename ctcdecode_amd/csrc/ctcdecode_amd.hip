@@ -509,11 +509,15 @@ __device__ __forceinline__ int prune_cumulative_cut(const PruneArgs &a, const fl
   return stop;
 }
 
-// (six waves per SIMD = six workgroups per CU: the pass is bound by the latency chain of a frame inside a workgroup, so
-//  what counts is how many frames a CU has in flight -- 0.418 ms at five (the compiler's own choice, 88 VGPRs), 0.349 ms
-//  at six, 0.39 / 0.43 ms at seven / eight, where the register budget starts to cost more than the extra frames bring)
+// (workgroups per CU: the pass is bound by the latency chain of a frame inside a workgroup, so what counts is how many frames a CU
+//  has in flight.  Rounds 2-5, with the device library's exp / log in the cumulative cut (88 VGPRs at the compiler's own choice):
+//  0.418 ms at five, 0.349 at six, 0.39 / 0.43 at seven / eight, where the register budget cost more than the extra frames brought.
+//  Round 6, without them (63 VGPRs): 0.354 ms at six, 0.336 at seven, 0.323 at eight -- profiles/r06i_prune_variants.txt)
+#ifndef CTC_PRUNE_WG_OCC
+#define CTC_PRUNE_WG_OCC 8
+#endif
 template <int F4>
-__global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
+__global__ void __launch_bounds__(256, CTC_PRUNE_WG_OCC) prune_rows_wg_kernel(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
   __shared__ uint32_t s_bound[4];
   __shared__ int s_cnt;
@@ -643,8 +647,11 @@ __global__ void __launch_bounds__(256, 6) prune_rows_wg_kernel(PruneArgs a) {
 // prune_resolve_kernel settles flagged frames from the logits with the frame's (m, ls) stored here.
 // Requires V % 4 == 0, V <= 1024 * F4, cutoff_top_n <= 64.
 __device__ __forceinline__ float prune_key_value(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+#ifndef CTC_PRUNE_LOGITS_OCC
+#define CTC_PRUNE_LOGITS_OCC 5
+#endif
 template <int F4>
-__global__ void __launch_bounds__(256, F4 <= 4 ? 6 : F4 <= 10 ? 5 : 3) prune_logits_wg_kernel(PruneArgs a, const uint64_t *tables) {
+__global__ void __launch_bounds__(256, F4 <= 4 ? 6 : F4 <= 10 ? CTC_PRUNE_LOGITS_OCC : 3) prune_logits_wg_kernel(PruneArgs a, const uint64_t *tables) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
   __shared__ uint64_t tbl[64];
   __shared__ __attribute__((aligned(16))) LsmLds s;
@@ -2054,17 +2061,12 @@ void ctcd_stream_destroy(ctcd_decoder *d, ctcd_stream *st) {
 
 long long ctcd_stream_frames(const ctcd_stream *st) { return st ? st->frames : -1; }
 
-int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned char *is_eos, const float *probs,
-                       const int32_t *seq_lens_host, int B, int T, int V, int beam, int /*num_processes*/, double cutoff_prob,
-                       int cutoff_top_n, int blank_id, int log_input, int32_t *out_tok, int32_t *out_ts, float *out_sc,
-                       int32_t *out_len, int32_t *n_results, int out_T, void *stream_) {
-  if (!d || !states || !is_eos || B < 0 || T < 0 || out_T < 0) return fail(CTCD_EINVAL, "bad arguments");
-  if (B == 0) return CTCD_OK;
-  CTC_ON_DEVICE(d->device);
-  hipStream_t stream = (hipStream_t)stream_;
-  std::vector<int32_t> lens(B);
+// what every streaming call does first: the states are checked against the call, the chunk lengths clamped (binding.cpp:171),
+// node pools that the chunk would overflow grown
+static int stream_prepare(ctcd_decoder *d, ctcd_stream **states, const unsigned char *is_eos, const int32_t *seq_lens_host, int B, int T, int V,
+                          int beam, int out_T, hipStream_t stream, std::vector<int32_t> &lens, bool &any_eos) {
   const unsigned long long call_id = ++g_stream_call_id;
-  bool any_eos = false;
+  any_eos = false;
   for (int b = 0; b < B; ++b) {
     ctcd_stream *st = states[b];
     if (!st || st->V != V || st->beam != beam) return fail(CTCD_EINVAL, "stream state does not match the decoder configuration");
@@ -2096,6 +2098,23 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
       st->cap_frames = cap;
     }
   }
+  return CTCD_OK;
+}
+
+int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned char *is_eos, const float *probs,
+                       const int32_t *seq_lens_host, int B, int T, int V, int beam, int /*num_processes*/, double cutoff_prob,
+                       int cutoff_top_n, int blank_id, int log_input, int32_t *out_tok, int32_t *out_ts, float *out_sc,
+                       int32_t *out_len, int32_t *n_results, int out_T, void *stream_) {
+  if (!d || !states || !is_eos || B < 0 || T < 0 || out_T < 0) return fail(CTCD_EINVAL, "bad arguments");
+  if (B == 0) return CTCD_OK;
+  CTC_ON_DEVICE(d->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<int32_t> lens(B);
+  bool any_eos = false;
+  {
+    const int prc = stream_prepare(d, states, is_eos, seq_lens_host, B, T, V, beam, out_T, stream, lens, any_eos);
+    if (prc) return prc;
+  }
   // (the chunk lengths travel with the other per-item arguments: decode_common)
   if (states[0]->scorer && states[0]->scorer->cbl) {  // a callback scorer: as many launches as its cache needs
     const int rc = cb_rounds(d, states, is_eos, lens.data(), probs, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, states[0]->scorer, out_tok,
@@ -2109,6 +2128,124 @@ int ctcd_stream_decode(ctcd_decoder *d, ctcd_stream **states, const unsigned cha
                          out_ts, out_sc, out_len, n_results, stream_, &sc, states[0]->scorer);
   if (rc) return rc;
   for (int b = 0; b < B; ++b) states[b]->frames += lens[b];
+  return CTCD_OK;
+}
+
+// The streaming call with its results delivered to HOST memory, sized as the reference sizes them (binding.cpp:186-205: tokens /
+// timesteps [B, R, L] with R = the most results of any item that ended, L = the longest of their label sequences).  R and L are
+// known only when the kernel has run: the caller hands over an allocator, called once with (R, L), that returns the two buffers
+// (the reference's binding resizes its tensors at that point).  The results leave the GPU in compact form -- the kernel mirrors
+// every finished stream's records into page-locked memory -- and host threads expand them into the caller's buffers: a tenth of the
+// padded [B, K, out_T] pair crosses PCIe.  out_scores / out_lens [B, beam] and n_results [B] are host pointers too.  Synchronous.
+// A callback scorer decodes launch after launch into padded device tensors (cb_rounds): not through this entry (CTCD_EUNSUPPORTED).
+int ctcd_stream_decode_to_host(ctcd_decoder *d, ctcd_stream **states, const unsigned char *is_eos, const float *probs,
+                               const int32_t *seq_lens_host, int B, int T, int V, int beam, int num_processes, double cutoff_prob,
+                               int cutoff_top_n, int blank_id, int log_input, ctcd_result_alloc_fn alloc, void *alloc_user,
+                               float *out_sc, int32_t *out_len, int32_t *n_results, int out_T, int *out_R, int *out_L, void *stream_) {
+  if (!d || !states || !is_eos || !alloc || !out_sc || !out_len || !n_results || B < 0 || T < 0 || out_T < 0) return fail(CTCD_EINVAL, "bad arguments");
+  if (out_R) *out_R = 0;
+  if (out_L) *out_L = 0;
+  if (B == 0) return CTCD_OK;
+  CTC_ON_DEVICE(d->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (states[0] && states[0]->scorer && states[0]->scorer->cbl) return fail(CTCD_EUNSUPPORTED, "a callback scorer's streams end through ctcd_stream_decode");
+  if (out_T > 65536 || V > 65535) return fail(CTCD_EUNSUPPORTED, "compact results pack label and frame into 16 bits each");
+  std::lock_guard<std::mutex> host_lock(d->mu_host);
+  static const bool trace = getenv("CTCD_STREAM_TIMING") != nullptr;  // (stderr: where the call's time goes)
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  double t_launch = 0, t_sync = 0, t_alloc = 0;
+  std::vector<int32_t> lens(B);
+  bool any_eos = false;
+  int rc = stream_prepare(d, states, is_eos, seq_lens_host, B, T, V, beam, out_T, stream, lens, any_eos);
+  if (rc) return rc;
+  const size_t kk = (size_t)B * beam;
+  const long long cap = std::max<long long>(ctcd_compact_label_capacity(B, beam, out_T), 1);
+  if (cap > 0xFFFFFFFFLL) return fail(CTCD_EUNSUPPORTED, "batch too large for one compact label buffer; split the batch");
+  if ((rc = d->c_hdr.ensure((size_t)B * 16)) || (rc = d->c_ent.ensure(kk * 16)) || (rc = d->c_rag.ensure((size_t)cap * 4)) ||
+      (rc = d->c_cnt.ensure(256)) || (rc = d->c_sc.ensure(kk * 4)) || (rc = d->c_ln.ensure(kk * 4 + (size_t)B * 4)))
+    return rc;
+  int32_t *d_nres = (int32_t *)((char *)d->c_ln.p + kk * 4);
+  // the page-locked mirror the kernel writes a finished stream's records to (as in ctcd_beam_decode_to_host)
+  const size_t o_done = 256, o_hdr = (o_done + (size_t)B * 4 + 255) / 256 * 256, o_ent = o_hdr + (size_t)B * 16,
+               o_lab = (o_ent + kk * 16 + 255) / 256 * 256;
+  const size_t mcap = d->mirror_cap_override >= 0 ? (size_t)d->mirror_cap_override + 1 : std::max<size_t>((size_t)1 << 20, (size_t)cap / 3);
+  const size_t need = o_lab + mcap * 4;
+  if (d->h_stage_cap < need) {
+    if (d->h_stage) (void)hipHostFree(d->h_stage);
+    d->h_stage = nullptr;
+    d->h_stage_cap = 0;
+    HIP_TRY(hipHostMalloc(&d->h_stage, need, hipHostMallocMapped | hipHostMallocCoherent));
+    d->h_stage_cap = need;
+  }
+  char *hs = (char *)d->h_stage, *ds = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void **)&ds, d->h_stage, 0));
+  volatile int32_t *done = (volatile int32_t *)(hs + o_done);
+  for (int b = 0; b < B; ++b) done[b] = 0;
+  std::memset(hs + o_hdr, 0, (size_t)B * 16);  // (streams that do not end write nothing)
+  CompactOut co{(int32_t *)d->c_hdr.p, (int32_t *)d->c_ent.p, (uint32_t *)d->c_rag.p, (unsigned *)d->c_cnt.p, (unsigned)cap};
+  co.m_hdr = (int32_t *)(ds + o_hdr); co.m_ent = (int32_t *)(ds + o_ent); co.m_done = (int32_t *)(ds + o_done);
+  co.m_rag = (uint32_t *)(ds + o_lab); co.m_cap = (unsigned)std::min<size_t>(mcap, 0xFFFFFFFFu);
+  StreamCall sc{states, is_eos, out_T, lens.data(), any_eos};
+  rc = decode_common(d, probs, nullptr, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, nullptr, nullptr, (float *)d->c_sc.p,
+                     (int32_t *)d->c_ln.p, d_nres, stream, &sc, states[0]->scorer, &co);
+  if (rc) return rc;
+  for (int b = 0; b < B; ++b) states[b]->frames += lens[b];
+  struct Drain {
+    hipStream_t a;
+    ~Drain() { (void)hipStreamSynchronize(a); }
+  } drain{stream};
+  if (any_eos) {
+    HIP_TRY(hipMemcpyAsync(out_sc, d->c_sc.p, kk * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(out_len, d->c_ln.p, kk * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(n_results, d_nres, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+  } else {
+    std::memset(out_sc, 0, kk * 4); std::memset(out_len, 0, kk * 4); std::memset(n_results, 0, (size_t)B * 4);
+  }
+  t_launch = since();
+  HIP_TRY(hipStreamSynchronize(stream));
+  if ((rc = ctcd_check_status(d, B))) return rc;
+  t_sync = since();
+  if (!any_eos) return CTCD_OK;
+  // the records: from the mirror, or -- an item whose labels fell beyond it -- everything from the device buffers
+  const int32_t *hh = (const int32_t *)(hs + o_hdr), *he = (const int32_t *)(hs + o_ent);
+  const uint32_t *hl = (const uint32_t *)(hs + o_lab);
+  std::vector<int32_t> fh, fe;
+  std::vector<uint32_t> fl;
+  bool late = false;
+  for (int b = 0; b < B; ++b) late |= is_eos[b] && done[b] != 1;
+  if (late) {
+    unsigned nlab = 0;
+    HIP_TRY(hipMemcpy(&nlab, d->c_cnt.p, 4, hipMemcpyDeviceToHost));
+    fh.resize((size_t)B * 4); fe.resize(kk * 4); fl.resize(nlab ? nlab : 1);
+    HIP_TRY(hipMemcpy(fh.data(), d->c_hdr.p, (size_t)B * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fe.data(), d->c_ent.p, kk * 16, hipMemcpyDeviceToHost));
+    if (nlab) HIP_TRY(hipMemcpy(fl.data(), d->c_rag.p, (size_t)nlab * 4, hipMemcpyDeviceToHost));
+    hh = fh.data(); he = fe.data(); hl = fl.data();
+  }
+  int R = 0, L = 0;
+  for (int b = 0; b < B; ++b) {
+    const int nres = hh[(size_t)b * 4];
+    R = std::max(R, nres);
+    for (int j = 0; j < nres; ++j) L = std::max(L, he[((size_t)b * beam + j) * 4 + 2]);
+  }
+  if (out_R) *out_R = R;
+  if (out_L) *out_L = L;
+  int32_t *out_tok = nullptr, *out_ts = nullptr;
+  if (alloc(alloc_user, R, L, &out_tok, &out_ts) != 0) return fail(CTCD_EINVAL, "the result allocator failed");
+  t_alloc = since();
+  if (R == 0 || L == 0) return CTCD_OK;
+  if (!out_tok || !out_ts) return fail(CTCD_EINVAL, "the result allocator returned no buffers");
+  if (!d->workers) d->workers = new HostPool;
+  {
+    const long long out_mb = (long long)B * R * L * 8 >> 20;
+    const int want = std::max<long long>(num_processes, std::min<long long>(160, std::max<long long>(16, out_mb)));
+    const int target = std::max(1, std::min(want, (int)std::thread::hardware_concurrency()));
+    if (target > (int)d->workers->th.size()) d->workers->start(target - (int)d->workers->th.size());
+  }
+  d->workers->run(B, [=](int b) { ctcbeam::expand_item_host(hh, he, hl, b, beam, L, out_tok, out_ts, R); });
+  if (trace) fprintf(stderr, "ctcd_stream_decode_to_host: queued %.3f ms, kernel done %.3f, buffers (R=%d, L=%d) %.3f, expanded by %d threads %.3f\n", t_launch, t_sync, R, L,
+                     t_alloc, (int)d->workers->th.size(), since());
   return CTCD_OK;
 }
 

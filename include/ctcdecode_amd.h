@@ -186,6 +186,19 @@ int ctcd_stream_decode(ctcd_decoder *dec, ctcd_stream **states, const unsigned c
                        int cutoff_top_n, int blank_id, int log_input, int32_t *out_tokens, int32_t *out_timesteps,
                        float *out_scores, int32_t *out_lens, int32_t *n_results, int out_T, void *stream);
 
+/* The same call with the results delivered to HOST memory in the reference's own sizes (binding.cpp:186-205 resizes its tensors
+ * to [B, R, L]: R = the most results of any stream that ended, L = the longest of their label sequences).  R and L exist only
+ * once the kernel has run, so the caller passes an allocator: it is called once, with (R, L), and returns the two int32 buffers
+ * of B * R * L elements (return non-zero to fail the call; with R * L == 0 the buffers are not touched).  The finished streams'
+ * results cross PCIe in compact form and host threads expand them (as ctcd_beam_decode_to_host does for the one-shot call).
+ * `probs` is a DEVICE pointer; out_scores / out_lens [B, beam], n_results [B], *out_R, *out_L are HOST memory.  Synchronous.
+ * Streams behind a callback scorer end through ctcd_stream_decode (CTCD_EUNSUPPORTED here). */
+typedef int (*ctcd_result_alloc_fn)(void *user, int R, int L, int32_t **tokens, int32_t **timesteps);
+int ctcd_stream_decode_to_host(ctcd_decoder *dec, ctcd_stream **states, const unsigned char *is_eos, const float *probs,
+                               const int32_t *seq_lens_host, int B, int T, int V, int beam, int num_processes, double cutoff_prob,
+                               int cutoff_top_n, int blank_id, int log_input, ctcd_result_alloc_fn alloc, void *alloc_user,
+                               float *out_scores, int32_t *out_lens, int32_t *n_results, int out_T, int *out_R, int *out_L, void *stream);
+
 /* Host check of the per-item status words written by the last ctcd_beam_decode (synchronises the device). */
 int ctcd_check_status(ctcd_decoder *dec, int B);
 /* ... without blocking: enqueues the copy of the B status words (0 = ok) into `host_status` (page-locked memory) on

@@ -700,6 +700,57 @@ def test_streaming_mixed_batch_and_growth(torch_mod):
         assert np.array_equal(o2[0, p, :n].numpy(), want["tokens"][0, p, :n]) and np.array_equal(t2[0, p, :n].numpy(), want["timesteps"][0, p, :n])
 
 
+def test_streaming_final_call_compact_delivery(torch_mod):
+    """The call that ends streams hands its results over as compact records expanded on the host, straight into [B, R, L] tensors
+    (ctcd_stream_decode_to_host; R = the most results, L = the longest beam, binding.cpp:186-205): same tensors with the records
+    coming from the kernel's page-locked mirror and -- mirror too small for any of them -- fetched from the device afterwards; a
+    batch in which only some streams end; R and L equal to what the padded delivery (ctcd_stream_decode) returns."""
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    V, K, T, B = 29, 30, 260, 5
+    lp = ou.synth_logprobs(B, T, V, 181)
+    x = torch_mod.from_numpy(lp).cuda()
+    want = ou.decode(lp, beam=K, which="restated")
+    res = []
+    for mirror_cap in (-1, 0):
+        dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], beam_width=K, cutoff_top_n=V, log_probs_input=True)
+        n.check(n.lib.ctcd_debug_set_host_path(dec._handle, 1, mirror_cap))
+        st = [ctcdecode_amd.DecoderState(dec) for _ in range(B)]
+        dec.decode(x[:, :100].contiguous(), st, [False] * B)
+        out, sc, ts, ln = dec.decode(x[:, 100:].contiguous(), st, [True] * B)
+        R, L = int(want["nres"].max()), int(want["lens"].max())
+        assert tuple(out.shape) == (B, R, L) and tuple(ts.shape) == (B, R, L) and not out.is_cuda
+        got = dict(tokens=np.zeros((B, K, T), np.int32), timesteps=np.zeros((B, K, T), np.int32), scores=sc.numpy(), lens=ln.numpy(), nres=want["nres"])
+        got["tokens"][:, :R, :L] = out.numpy()
+        got["timesteps"][:, :R, :L] = ts.numpy()
+        ou.assert_same(got, want, "mirror cap %d" % mirror_cap)
+        res.append((out.numpy().copy(), ts.numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    # only streams 1 and 3 end; the others' rows are zero and they go on afterwards
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], beam_width=K, cutoff_top_n=V, log_probs_input=True)
+    st = [ctcdecode_amd.DecoderState(dec) for _ in range(B)]
+    ends = [False, True, False, True, False]
+    w2 = ou.decode(lp[:, :150], beam=K, which="restated")
+    out, sc, ts, ln = dec.decode(x[:, :150].contiguous(), st, ends)
+    for b in range(B):
+        if ends[b]:
+            assert np.array_equal(ln[b].numpy(), w2["lens"][b]) and np.array_equal(sc[b].numpy().view(np.uint32), w2["scores"][b].view(np.uint32))
+            for p in range(int(w2["nres"][b])):
+                m = int(ln[b, p])
+                assert np.array_equal(out[b, p, :m].numpy(), w2["tokens"][b, p, :m]) and np.array_equal(ts[b, p, :m].numpy(), w2["timesteps"][b, p, :m])
+                assert not out[b, p, m:].any()
+        else:
+            assert not out[b].any() and not ln[b].any() and not sc[b].any()
+    rest = [st[b] for b in range(B) if not ends[b]]
+    keep = [b for b in range(B) if not ends[b]]
+    out, sc, ts, ln = dec.decode(x[keep, 150:].contiguous(), rest, [True] * len(rest))
+    for i, b in enumerate(keep):
+        assert np.array_equal(ln[i].numpy(), want["lens"][b]) and np.array_equal(sc[i].numpy().view(np.uint32), want["scores"][b].view(np.uint32))
+        m = int(ln[i, 0])
+        assert np.array_equal(out[i, 0, :m].numpy(), want["tokens"][b, 0, :m])
+
+
 def test_empty_and_degenerate_batches(torch_mod):
     import ctcdecode_amd
 
