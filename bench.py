@@ -334,16 +334,18 @@ def time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, B=128, T=1500, K=1
         out["built-in tables"] = {"call_ms": round(dt * 1e3, 3), "kernel_ms": round(ref.last_kernel_ms(), 3)}
         sc = ctcdecode_amd.CallbackScorer.from_c(fn_addr, inner.value, arpa_unigrams(arpa), order, labels, alpha=alpha, beta=beta, device=dev)
         dec = ctcdecode_amd.CTCBeamDecoder(labels, scorer=sc, cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev)
-        calls0 = 0
+        calls0, secs0 = 0, 0.0
         for name, lp, w in (("cold (fresh scorer)", lps[0], want[0]), ("second batch of other utterances (lukewarm)", lps[1], want[1]), ("first batch again (warm)", lps[0], want[0])):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             r = dec.decode_device(lp, None, check=True)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             calls = sc.callback_calls()
+            secs = sc.callback_seconds()
             same = all(torch.equal(a, b) for a, b in zip(r, w))
-            out[name] = {"call_ms": round(dt * 1e3, 3), "launches": int(n.lib.ctcd_last_scorer_rounds(dec._handle)), "callback_calls": int(calls - calls0),
-                         "equals_built_in": bool(same)}
-            calls0 = calls
+            out[name] = {"call_ms": round(dt * 1e3, 3), "launches": int(n.lib.ctcd_last_scorer_rounds(dec._handle)),
+                         "answer_batches_to_waiting_launches": int(n.lib.ctcd_last_scorer_waits(dec._handle)), "callback_calls": int(calls - calls0),
+                         "ms_inside_the_callback": round((secs - secs0) * 1e3, 1), "equals_built_in": bool(same)}
+            calls0, secs0 = calls, secs
         del dec, sc, ref
     finally:
         n.lib.ctcd_scorer_destroy(inner)

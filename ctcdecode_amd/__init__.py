@@ -110,6 +110,10 @@ class CallbackScorer(object):
         """Distinct windows the callback has been asked for so far."""
         return int(_native.lib.ctcd_scorer_callback_calls(self.handle))
 
+    def callback_seconds(self):
+        """Time spent inside the callback so far (an estimate: every 16th call is timed)."""
+        return float(_native.lib.ctcd_scorer_callback_seconds(self.handle))
+
     def _raise_pending(self):
         e, self._error = self._error, None
         if e is not None:
@@ -243,6 +247,15 @@ class CTCBeamDecoder(object):
     def set_fixed_layout(self, on=True):
         """Test hook: False forces the run-time workspace layout also for small shapes (identical results)."""
         _native.check(_native.lib.ctcd_debug_set_fixed_layout(self._handle, 1 if on else 0))
+
+    def set_scorer_wait(self, on=True):
+        """Callback scorers: True (default) = a launch waits on the GPU for the callback's answers; False = every miss ends the
+        utterance's launch and the host relaunches (the form of rounds 4-5).  Identical results."""
+        _native.check(_native.lib.ctcd_set_scorer_wait(self._handle, 1 if on else 0))
+
+    def last_scorer_launches(self):
+        """(launches, answer batches handed to waiting launches) of the last decode with a callback scorer."""
+        return int(_native.lib.ctcd_last_scorer_rounds(self._handle)), int(_native.lib.ctcd_last_scorer_waits(self._handle))
 
     def set_fused_logits(self, on=True):
         """Test hook (logits_input=True): False sends raw logits through the one-wave log_softmax pass and the separate prune
@@ -600,6 +613,10 @@ class OnlineCTCBeamDecoder(object):
     def set_threads(self, n):
         """Test hook (as CTCBeamDecoder.set_threads): threads per workgroup, 0 = the library's choice."""
         _native.check(_native.lib.ctcd_set_threads(self._handle, int(n)))
+
+    def set_scorer_wait(self, on=True):
+        """As CTCBeamDecoder.set_scorer_wait."""
+        _native.check(_native.lib.ctcd_set_scorer_wait(self._handle, 1 if on else 0))
 
     def decode(self, probs, states, is_eos_s, seq_lens=None, check=True):
         """Same contract as ctcdecode/__init__.py:189-238: returns CPU tensors (beam_results[B, R, L], beam_scores[B, K],

@@ -175,6 +175,7 @@ enum {
   VAR_ROWMAX = VAR_SPEC + SP_ROWMAX,
   VAR_QSTAT = VAR_SPEC + 9,   // entries of the launch's final beam with descendants in it (the shape statistic the host reads: chains or bushes)
   VAR_LMMISS = VAR_SPEC + 8,  // host-side scorer hook: this frame asked for something the cache does not hold (sticky within a launch)
+  VAR_LMQ = VAR_SPEC + 10,    // ... and how many pairs the utterance has queued since init() / load_state()
   VAR_COUNT = VAR_SPEC + 12
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
@@ -607,8 +608,10 @@ struct Decoder {
     if (CTC_RARE(lm_cb)) {
       if (v != v) {
         w.vars[VAR_LMMISS] = 1;
-        const unsigned i = x.global_add(lm->cb_count, 1u);
-        if (i < lm->cb_cap) { lm->cb_miss[2 * i] = st0; lm->cb_miss[2 * i + 1] = word; }
+        unsigned i = x.global_add(lm->cb_count, 1u);
+        if (lm->cb_ring) i &= lm->cb_cap - 1;  // (a launch that waits for its answers: the host empties the list while it fills)
+        if (i < lm->cb_cap) lm->cb_miss[i] = ctclm::MissEntry{st0, word, (uint32_t)x.item(), 1u};
+        x.atomic_add(&w.vars[VAR_LMQ], 1);  // (pairs this utterance has queued since it was taken up: what its workgroup waits to see answered)
         *st = st0; *cl = cl0;
         if (missed) *missed = true;
         return 0.0;
@@ -835,6 +838,7 @@ struct Decoder {
       w.vars[VAR_INTO] = 0;
       w.vars[VAR_QSTAT] = 0;
       w.vars[VAR_LMMISS] = 0;
+      w.vars[VAR_LMQ] = 0;
       w.apos[0] = 0; w.fin[0] = 0;
     }
     st_n = 1; st_pool = 1; st_wlog = 32;  // first select looks at the whole key range
@@ -881,6 +885,7 @@ struct Decoder {
       w.vars[VAR_INTO] = 0;
       w.vars[VAR_QSTAT] = 0;
       w.vars[VAR_LMMISS] = 0;
+      w.vars[VAR_LMQ] = 0;
     }
     for (int i = tid; i < kBins + kBins / 16; i += nt) w.bins[i] = 0;
     for (int i = tid; i < 2 * K; i += nt) { w.hit[i] = 0; w.ancbuf[i] = -1; w.acntbuf[i] = 0; }

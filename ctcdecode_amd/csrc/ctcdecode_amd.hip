@@ -1086,6 +1086,8 @@ struct ctcd_decoder {
   bool timing = false;
   bool profile = false, dbg_on = false;
   bool no_fixed_layout = false;  // debugging: always use the run-time workspace layout
+  bool no_hook_wait = false;     // tests: a callback scorer's launches end at a miss (the form of rounds 4-5) instead of waiting for the answer
+  int last_cb_waits = 0;         // answer batches the last call's launches were handed while they waited
   bool no_fused_logits = false;  // tests: raw logits always through the one-wave log_softmax pass and the separate prune
   Buf prof, dbg, tl;
   int tl_f0 = 0, tl_nf = 0;
@@ -1149,8 +1151,20 @@ struct ctcd_scorer {
   size_t cb_stage_cap = 0;   // ... slots it holds
   std::vector<char> cb_stage_h;
   std::mutex cb_mu;          // one decode at a time mutates the cache
+  // page-locked, device-visible block of the launches that wait for their answers (cb_rounds): [log length | workgroup reports |
+  // pairs answered per item | miss list | log: slot indices | log: slots]
+  char *h_live = nullptr, *d_live = nullptr;  // host address / the same memory as the device addresses it
+  unsigned live_miss_hw = 0;                  // miss-list entries the last launch may have written (reset to the sentinel before the next)
+  std::vector<uint32_t> live_stamp;           // per cache slot: the waiting launch whose log holds it
+  std::vector<unsigned long long> live_memo;  // (state, word) pairs recently put into / found in that log (direct-mapped, 512 KB)
+  uint32_t live_launch = 0;
 };
 constexpr uint32_t kCbMissCap = 1u << 18;  // queued (state, word) pairs per round (2 MB); more are dropped and asked again
+constexpr uint32_t kCbLogCap = 1u << 20;   // cache slots one waiting launch can be handed (20 MB of page-locked memory)
+constexpr uint32_t kCbLiveItems = 1u << 16;
+constexpr size_t kLiveOffDone = 256, kLiveOffAns = kLiveOffDone + (size_t)kCbLiveItems * 4, kLiveOffMiss = kLiveOffAns + (size_t)kCbLiveItems * 4,
+                 kLiveOffIdx = kLiveOffMiss + (size_t)kCbMissCap * sizeof(ctclm::MissEntry), kLiveOffSlot = kLiveOffIdx + (size_t)kCbLogCap * 4,
+                 kLiveBytes = kLiveOffSlot + (size_t)kCbLogCap * sizeof(ctclm::NgSlot);
 
 namespace {
 
@@ -1177,6 +1191,7 @@ struct StreamCall {          // extra arguments of a streaming decode (lens: the
   const int *frame_off = nullptr;   // device, [B]
   int *frames_done = nullptr;       // device, [B]
   const int32_t *row_lens = nullptr;  // device, [B]: frame_off + lens = the rows the pre-passes (log conversion, pruning) cover
+  const char *live = nullptr;         // the scorer's page-locked block as the device sees it (ctcd_scorer::d_live): the launch waits for its answers
 };
 
 std::atomic<unsigned long long> g_stream_call_id{0};
@@ -1569,6 +1584,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     a.lm.beta = scorer->host.beta;
   }
   a.frames_ready = frames_ready;  // (streamed input of the host-tensor entry point; null: every row is in place)
+  a.cb_log_len = nullptr; a.cb_log_idx = nullptr; a.cb_log_slot = nullptr; a.cb_done = nullptr; a.cb_ans = nullptr;
+  a.lm.cb_ring = 0;
+  if (sc && sc->live) {
+    a.lm.cb_ring = 1;
+    a.cb_log_len = (const unsigned *)sc->live; a.cb_done = (int32_t *)(sc->live + kLiveOffDone); a.cb_ans = (const unsigned *)(sc->live + kLiveOffAns);
+    a.cb_log_idx = (const uint32_t *)(sc->live + kLiveOffIdx); a.cb_log_slot = (const ctclm::NgSlot *)(sc->live + kLiveOffSlot);
+  }
   a.frame_off = sc ? sc->frame_off : nullptr;
   a.frames_done = sc ? sc->frames_done : nullptr;
   a.pr_cnt = nullptr; a.pr_ch = nullptr; a.pr_lp = nullptr; a.pr_stride = 0;
@@ -1761,6 +1783,7 @@ void ctcd_scorer_destroy(ctcd_scorer *s) {
   if (s->blob) (void)hipFree(s->blob);
   for (char *p : {s->cb_ng, s->cb_st, s->cb_uni, s->cb_miss, s->cb_stage})
     if (p) (void)hipFree(p);
+  if (s->h_live) (void)hipHostFree(s->h_live);
   delete s->cbl;
   delete s;
 }
@@ -1808,7 +1831,7 @@ static int cb_sync(ctcd_scorer *s, hipStream_t stream = nullptr) {
   if (s->cb_st_cap < h.st_bo.size()) {  // every state backs off to the empty context with weight 0: two zeroed arrays
     if (s->cb_st) (void)hipFree(s->cb_st);
     s->cb_st = nullptr;
-    const size_t cap = h.st_bo.size() * 2;
+    const size_t cap = std::max<size_t>(h.st_bo.size() * 2, (size_t)1 << 20);  // (head room: a waiting launch cannot have them replaced)
     HIP_TRY(hipMalloc((void **)&s->cb_st, cap * 8));
     HIP_TRY(hipMemset(s->cb_st, 0, cap * 8));
     s->cb_st_cap = cap;
@@ -1847,7 +1870,7 @@ int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, in
   const size_t o_up = place(h.uni_prob.size() * 4), o_us = place(h.uni_state.size() * 4), o_dc = place(h.dict.size() * sizeof(ctclm::DictNode)),
                o_lw = place(h.label_word.size() * 4), o_dl = place(h.dict_lab.size() * 4);
   hipError_t e = hipMalloc((void **)&s->cb_uni, off ? off : 256);
-  if (e == hipSuccess) e = hipMalloc((void **)&s->cb_miss, (size_t)kCbMissCap * 8 + 256);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->cb_miss, (size_t)kCbMissCap * sizeof(ctclm::MissEntry) + 256);
   if (e != hipSuccess) { ctcd_scorer_destroy(s); return fail(CTCD_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
   auto up = [&](size_t o, const void *src, size_t bytes) { return bytes ? hipMemcpy(s->cb_uni + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
   if ((e = up(o_up, h.uni_prob.data(), h.uni_prob.size() * 4)) != hipSuccess || (e = up(o_us, h.uni_state.data(), h.uni_state.size() * 4)) != hipSuccess ||
@@ -1862,8 +1885,19 @@ int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, in
   s->dview.dict_lab = (const uint32_t *)(s->cb_uni + o_dl);
   s->dview.cb = 1;
   s->dview.cb_count = (unsigned *)s->cb_miss;
-  s->dview.cb_miss = (uint32_t *)(s->cb_miss + 256);
+  s->dview.cb_miss = (ctclm::MissEntry *)(s->cb_miss + 256);
   s->dview.cb_cap = kCbMissCap;
+  // the miss list itself lives in page-locked memory the host reads while a launch runs (the counter stays on the device)
+  if (hipHostMalloc((void **)&s->h_live, kLiveBytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+      hipHostGetDevicePointer((void **)&s->d_live, s->h_live, 0) == hipSuccess) {
+    std::memset(s->h_live, 0, kLiveOffMiss);
+    std::memset(s->h_live + kLiveOffMiss, 0xff, (size_t)kCbMissCap * sizeof(ctclm::MissEntry));
+    s->dview.cb_miss = (ctclm::MissEntry *)(s->d_live + kLiveOffMiss);
+  } else {
+    if (s->h_live) (void)hipHostFree(s->h_live);
+    s->h_live = nullptr; s->d_live = nullptr;
+    (void)hipGetLastError();
+  }
   const int rc = cb_sync(s);
   if (rc) { ctcd_scorer_destroy(s); return rc; }
   *out = s;
@@ -1894,11 +1928,22 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *s, const char *const *words,
 int ctcd_scorer_cond_log10(const ctcd_scorer *s, const char *const *words, int n, float *log10_prob) {
   if (!s || !words || n <= 0 || !log10_prob) return -1;
   if (s->cbl) return s->cbl->fn(s->cbl->user, words, n, log10_prob);
-  std::vector<std::string> w(n);
-  for (int i = 0; i < n; ++i) w[i] = words[i] ? words[i] : "";
-  return s->host.cond_log10(w, log10_prob);
+  // (HostScorer::cond_log10 without the vector of strings: this function is what bench.py puts behind the hook as a native callback)
+  const ctclm::LmView v = s->host.view();
+  uint32_t st = 0;
+  float p = 0.f;
+  std::string key;
+  for (int i = 0; i < n; ++i) {
+    key.assign(words[i] ? words[i] : "");
+    const uint32_t id = s->host.id_of(key);
+    if (id == 0) return 1;
+    p = ctclm::lm_score(v, st, id, &st);
+  }
+  *log10_prob = p;
+  return 0;
 }
 long long ctcd_scorer_callback_calls(const ctcd_scorer *s) { return s && s->cbl ? (long long)s->cbl->queries : 0; }
+double ctcd_scorer_callback_seconds(const ctcd_scorer *s) { return s && s->cbl ? s->cbl->cb_seconds : 0.0; }
 
 // Decoding with a callback scorer (ctcd_scorer_create_callback).  A launch decodes until an utterance asks for a (history, word)
 // pair the device cache does not hold, parks that utterance in front of the frame it was in (every utterance runs as a stream:
@@ -1929,9 +1974,24 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
   std::vector<unsigned char> eos(B), finished(B, 0);
   std::vector<uint32_t> miss;
   int rc;
+  // The launch that waits (decode_kernel.h KernelArgs::cb_log_len): a workgroup whose utterance misses stays on its CU while this
+  // thread -- polling the miss list in page-locked memory -- asks the callback and publishes the answered slots; a round of misses
+  // costs two PCIe crossings instead of a launch.  What it cannot do while the kernel runs -- move the table (rehash), lengthen the
+  // state arrays, hold more than its log -- ends the wait: the workgroups leave as they always did and the loop below relaunches.
+  static const bool live_off = getenv("CTCD_HOOK_WAIT") && atoi(getenv("CTCD_HOOK_WAIT")) == 0;
+  const bool live = scorer->h_live && !live_off && !d->no_hook_wait && (uint32_t)B <= kCbLiveItems;
+  ctclm::CallbackLm &cl = *scorer->cbl;
+  d->last_cb_waits = 0;
   for (int round = 0;; ++round) {
     d->last_cb_rounds = round;
     if (round > 4 * T + 64) return fail(CTCD_EINTERNAL, "scorer hook: the decode does not make progress");
+    if (live) {  // head room for the answers of a waiting launch: 8192 more slots / states before anything has to move
+      if ((cl.used + 8192) * 2 > cl.hs.ng.size()) cl.grow(std::max<size_t>(cl.hs.ng.size() * 4, (size_t)1 << 20));  // (16 MB to begin with)
+      if (cl.hist.size() + 8192 >= scorer->cb_st_cap / 2 && cl.hs.st_bo.size() <= scorer->cb_st_cap) {  // (cb_sync doubles the device arrays)
+        cl.hs.st_bo.resize(scorer->cb_st_cap + 64, 0.0f);
+        cl.hs.st_fail.resize(cl.hs.st_bo.size(), 0u);
+      }
+    }
     if ((rc = cb_sync(scorer, stream))) return rc;
     int left = 0;
     bool any_eos = false;
@@ -1949,6 +2009,20 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
     sc.frame_off = d_off;
     sc.frames_done = d_done;
     sc.row_lens = d_rows;
+    volatile unsigned *h_len = (volatile unsigned *)scorer->h_live;
+    volatile int32_t *h_done = (volatile int32_t *)(scorer->h_live + kLiveOffDone);
+    volatile uint32_t *h_miss = (volatile uint32_t *)(scorer->h_live + kLiveOffMiss);  // (four words per pair: ctclm::MissEntry)
+    volatile unsigned *h_ans = (volatile unsigned *)(scorer->h_live + kLiveOffAns);
+    if (scorer->h_live) {  // (the miss list of the last launch: back to "not written")
+      std::memset(scorer->h_live + kLiveOffMiss, 0xff, (size_t)scorer->live_miss_hw * sizeof(ctclm::MissEntry));
+      scorer->live_miss_hw = 0;
+    }
+    if (live) {
+      *h_len = 0;
+      for (int b = 0; b < B; ++b) { h_done[b] = finished[b] ? 1 : 0; h_ans[b] = 0; }
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+      sc.live = scorer->d_live;
+    }
     if ((rc = decode_common(d, probs, nullptr, B, T, V, beam, cutoff_prob, cutoff_top_n, blank_id, log_input, out_tok, out_ts, out_sc, out_len,
                             n_results, stream_, &sc, scorer, co)))
       return rc;
@@ -1956,8 +2030,113 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
     HIP_TRY(hipMemcpyAsync(st_h, d->status.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(fd_h, d_done, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(nmiss_h, scorer->cb_miss, 4, hipMemcpyDeviceToHost, stream));
+    unsigned long long seen = 0;  // miss-list entries answered while the launch ran (the list is a ring then: entry i sits at i mod capacity)
+    if (live) {
+      uint32_t *l_idx = (uint32_t *)(scorer->h_live + kLiveOffIdx);
+      ctclm::NgSlot *l_slot = (ctclm::NgSlot *)(scorer->h_live + kLiveOffSlot);
+      // a slot goes into the log once per launch: a workgroup that asks for a pair the log already holds finds it there (it applies
+      // the log before it waits), so the duplicates -- every park queues what its pending entries need -- cost a table probe each
+      if (scorer->live_stamp.size() != cl.hs.ng.size()) scorer->live_stamp.assign(cl.hs.ng.size(), 0u);
+      const uint32_t launch_id = ++scorer->live_launch;
+      scorer->live_memo.assign((size_t)1 << 16, 0ull);
+      unsigned log_n = 0;
+      bool give_up = false;
+      std::vector<unsigned> ans_local((size_t)B, 0u);
+      auto t_last = std::chrono::steady_clock::now();
+      static const bool trace = getenv("CTCD_HOOK_TIMING") != nullptr;  // (stderr: how busy this thread is while a launch waits on it)
+      const auto t_begin = t_last;
+      double busy = 0.0;
+      for (unsigned spin = 0;; ++spin) {
+        const unsigned long long s0 = seen;
+        const auto t_in = trace ? std::chrono::steady_clock::now() : t_begin;
+        unsigned fresh = 0;
+        for (bool more = true; more && !give_up;) {
+          // the pairs that have arrived, up to 32 at a time: their table lines are requested first (a cold probe of a table of tens of MB
+          // is a DRAM access; the duplicates -- most of the list -- cost nothing else)
+          struct Pend { uint32_t st, wd, item; size_t ring; } pend[32];
+          int np = 0;
+          const uint32_t mask = (uint32_t)cl.hs.ng.size() - 1;
+          while (np < 32) {
+            const size_t at_ring = (size_t)((seen + (unsigned)np) & (kCbMissCap - 1));
+            if (h_miss[4 * at_ring + 3] == 0xFFFFFFFFu) { more = false; break; }  // (the flag word: the pair's 16 bytes arrive in one piece)
+            std::atomic_thread_fence(std::memory_order_acquire);
+            pend[np] = Pend{h_miss[4 * at_ring], h_miss[4 * at_ring + 1], h_miss[4 * at_ring + 2], at_ring};
+            const uint32_t hh = ctclm::ng_hash(pend[np].st, pend[np].wd) & mask;
+            __builtin_prefetch(&cl.hs.ng[hh]);
+            __builtin_prefetch(&scorer->live_stamp[hh]);
+            ++np;
+          }
+          for (int q = 0; q < np; ++q) {
+            const uint32_t st = pend[q].st, wd = pend[q].wd, item = pend[q].item;
+            const size_t at_ring = pend[q].ring;
+            // most of the list repeats pairs asked moments ago (every park queues what its pending entries need, neighbouring prefixes
+            // and utterances want the same windows): a small direct-mapped memo of the pairs already in this launch's log answers
+            // those without touching the table
+            const unsigned long long key = ((unsigned long long)st << 32) | wd;
+            unsigned long long &memo = scorer->live_memo[(size_t)((key * 0x9E3779B97F4A7C15ull) >> 48)];
+            if (memo == key) {
+              if (item < (uint32_t)B) {
+                std::atomic_thread_fence(std::memory_order_release);
+                h_ans[item] = ++ans_local[item];
+              }
+              h_miss[4 * at_ring] = 0xFFFFFFFFu; h_miss[4 * at_ring + 1] = 0xFFFFFFFFu; h_miss[4 * at_ring + 2] = 0xFFFFFFFFu; h_miss[4 * at_ring + 3] = 0xFFFFFFFFu;
+              ++seen;
+              continue;
+            }
+            uint32_t at = 0;
+            const long long have = cl.find_slot(st, wd);
+            if (have < 0) {
+              if (!cl.room_for(1, scorer->cb_st_cap)) { give_up = true; break; }  // (the tables would have to move: between launches)
+              if (!cl.resolve(st, wd, &at)) {
+                *h_len = 0xFFFFFFFFu;
+                (void)hipStreamSynchronize(stream);
+                scorer->live_miss_hw = kCbMissCap;
+                return fail(CTCD_EINVAL, cl.hs.error);
+              }
+            } else {
+              at = (uint32_t)have;
+            }
+            if (scorer->live_stamp[at] != launch_id) {
+              if (log_n >= kCbLogCap) { give_up = true; break; }
+              scorer->live_stamp[at] = launch_id;
+              l_idx[log_n] = at;
+              l_slot[log_n] = cl.hs.ng[at];
+              ++log_n;
+              ++fresh;
+              std::atomic_thread_fence(std::memory_order_release);
+              *h_len = log_n;  // (published entry by entry: the stores of this thread arrive in order)
+            }
+            memo = key;  // (in the log from here on)
+            if (item < (uint32_t)B) {  // the item's workgroup goes on when every pair it queued has been dealt with
+              std::atomic_thread_fence(std::memory_order_release);
+              h_ans[item] = ++ans_local[item];
+            }
+            h_miss[4 * at_ring] = 0xFFFFFFFFu; h_miss[4 * at_ring + 1] = 0xFFFFFFFFu; h_miss[4 * at_ring + 2] = 0xFFFFFFFFu; h_miss[4 * at_ring + 3] = 0xFFFFFFFFu;
+            ++seen;
+          }
+        }
+        if (fresh) ++d->last_cb_waits;
+        if (seen > s0) {
+          t_last = std::chrono::steady_clock::now();
+          if (trace) busy += std::chrono::duration<double>(t_last - t_in).count();
+        }
+        bool all = true;
+        for (int b = 0; b < B && all; ++b) all = h_done[b] != 0;
+        if (all) break;
+        if (!give_up && (spin & 1023) == 1023) {
+          // (nothing new for a second with workgroups still out, or a launch that has ended some other way)
+          if (std::chrono::steady_clock::now() - t_last > std::chrono::seconds(1) || hipStreamQuery(stream) != hipErrorNotReady) give_up = true;
+          (void)hipGetLastError();
+        }
+        if (give_up) { *h_len = 0xFFFFFFFFu; break; }
+        __builtin_ia32_pause();
+      }
+      if (trace) fprintf(stderr, "scorer hook, waiting launch %d: %.2f ms, this thread busy %.2f ms with %llu queued pairs (%u new to the launch's log)%s\n", round,
+                         1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), 1e3 * busy, seen, log_n, give_up ? "; gave up" : "");
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     const unsigned nmiss = *nmiss_h;
+    scorer->live_miss_hw = live ? kCbMissCap : (nmiss < kCbMissCap ? nmiss : kCbMissCap);  // (a ring may hold unconsumed pairs anywhere)
     bool need = false;
     for (int b = 0; b < B; ++b) {
       if (finished[b]) continue;
@@ -1970,11 +2149,20 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
     }
     if (need) {
       if (nmiss == 0) return fail(CTCD_EINTERNAL, "scorer hook: an utterance waits for the host but queued nothing");
-      const unsigned take = nmiss < kCbMissCap ? nmiss : kCbMissCap;  // (pairs beyond the list's capacity are asked for again next round)
-      miss.resize((size_t)2 * take);
-      HIP_TRY(hipMemcpy(miss.data(), scorer->cb_miss + 256, (size_t)take * 8, hipMemcpyDeviceToHost));
-      for (unsigned i = 0; i < take; ++i)
-        if (!scorer->cbl->resolve(miss[2 * i], miss[2 * i + 1])) return fail(CTCD_EINVAL, scorer->cbl->hs.error);
+      if (live) {  // what the ring still holds (the launch has ended: every pair queued is written)
+        for (size_t i = 0; i < (size_t)kCbMissCap; ++i)
+          if (h_miss[4 * i + 3] != 0xFFFFFFFFu && !scorer->cbl->resolve(h_miss[4 * i], h_miss[4 * i + 1])) return fail(CTCD_EINVAL, scorer->cbl->hs.error);
+      } else {
+        const unsigned take = nmiss < kCbMissCap ? nmiss : kCbMissCap;  // (pairs beyond the list's capacity are asked for again next round)
+        miss.resize((size_t)4 * take);
+        if (scorer->h_live) {  // (the list is in page-locked memory)
+          for (size_t i = 0; i < (size_t)4 * take; ++i) miss[i] = h_miss[i];
+        } else {
+          HIP_TRY(hipMemcpy(miss.data(), scorer->cb_miss + 256, (size_t)take * sizeof(ctclm::MissEntry), hipMemcpyDeviceToHost));
+        }
+        for (unsigned i = 0; i < take; ++i)
+          if (!scorer->cbl->resolve(miss[4 * i], miss[4 * i + 1])) return fail(CTCD_EINVAL, scorer->cbl->hs.error);
+      }
     }
   }
   return CTCD_OK;
@@ -2649,6 +2837,12 @@ int ctcd_debug_math_check(ctcd_decoder *d, int mode, uint32_t lo, uint32_t hi, u
 // of earlier rounds; the host path is gone).
 long long ctcd_last_prune_host_rows(ctcd_decoder *d) { return d ? 0 : -1; }
 int ctcd_last_scorer_rounds(ctcd_decoder *d) { return d ? d->last_cb_rounds : -1; }
+int ctcd_last_scorer_waits(ctcd_decoder *d) { return d ? d->last_cb_waits : -1; }
+int ctcd_set_scorer_wait(ctcd_decoder *d, int on) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  d->no_hook_wait = on == 0;
+  return CTCD_OK;
+}
 // ... and the number the fast prune pass flagged (settled by the device's std::sort replay + exact cumulative chain).  The
 // count arrives behind the call's kernels: asking for it waits for the launch stream.
 long long ctcd_last_prune_flagged_rows(ctcd_decoder *d) {

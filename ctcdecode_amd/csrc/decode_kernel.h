@@ -486,6 +486,7 @@ struct DevX {
     if ((threadIdx.x & 63) == 0 && v) atomicMax((unsigned *)p, v);
   }
   __device__ __forceinline__ unsigned global_add(unsigned *p, unsigned v) { return atomicAdd(p, v); }
+  __device__ __forceinline__ int item() const { return (int)blockIdx.x; }  // batch item of this workgroup
   __device__ __forceinline__ void wave_min_to(int *p, uint32_t v) {
     v = ~wave_max_u32(~v);
     if ((threadIdx.x & 63) == 0) atomicMin((unsigned *)p, v);
@@ -870,6 +871,16 @@ struct KernelArgs {
   const int *pr_ch;         //              [B, T, pr_stride] their labels, reference order
   const float *pr_lp;       //              [B, T, pr_stride] their log-probabilities
   int pr_stride;
+  // host-side scorer hook, the launch that WAITS for its answers (LM == 3 builds; null: a miss ends the utterance's launch as before).
+  // All in page-locked host memory.  An utterance that misses parks, and its workgroup stays: the host -- polling the miss list -- asks
+  // the callback and appends the answered cache slots to a log; the workgroup copies the log's new entries into the device table
+  // (every workgroup applies every entry itself: its own stores are what its later loads are guaranteed to see) and takes the utterance
+  // up again from its parked state, as a new launch would.
+  const unsigned *cb_log_len;        // entries published so far (only grows); 0xFFFFFFFF: give up waiting (the host relaunches)
+  const uint32_t *cb_log_idx;        // [cap] slot index in lm.ng
+  const ctclm::NgSlot *cb_log_slot;  // [cap] its contents
+  int32_t *cb_done;                  // [B] 1 + status once the workgroup has left
+  const unsigned *cb_ans;            // [B] queued pairs of the item the host has dealt with (with their slots in the log by then)
 };
 
 // LAYOUT: 0 = the workspace is laid out for the call's own beam width / vocabulary (array bases are run-time values);
@@ -959,14 +970,67 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 #else
   if (LM) lmv = &a.lm;
 #endif
-  const int st = decode_utterance<!PRUNED, LAYOUT, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2, LM == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
+  int st;
+  if (LM == 3) {
+    // (the scorer hook's builds: the call sits in a loop -- see KernelArgs::cb_log_len)
+    __shared__ unsigned cb_n;
+    size_t fo = f0;
+    unsigned log_pos = 0, q_total = 0;
+    for (;;) {
+      const int before = a.st_base ? __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ss.hdr[SH_FRAMES], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
+      if (PRUNED) {
+        prow.cnt = a.pr_cnt + (size_t)b * a.T + fo;
+        prow.ch = a.pr_ch + ((size_t)b * a.T + fo) * a.pr_stride;
+        prow.lp = a.pr_lp + ((size_t)b * a.T + fo) * a.pr_stride;
+      }
+      st = decode_utterance<!PRUNED, LAYOUT, true, BIG != 0, BIG != 0 || OCC2, BIG == 3, false, true>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + fo) * a.V,
+                                  PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
+                                  a.st_base ? &ss : (const StreamState *)nullptr, lmv, a.raw + ((size_t)b * a.T + fo) * a.V, a.raw_log, (const int *)nullptr);
+      if (st != ctcbeam::ST_NEED_HOST || a.cb_log_len == nullptr || !a.st_base) break;
+      __threadfence_system();  // every lane's queued pairs are on their way to the host before the workgroup says it waits
+      __syncthreads();         // (and the parked state is complete)
+      const unsigned asked = (unsigned)w.vars[ctcbeam::VAR_LMQ];
+      if (asked == 0) break;  // (parked without a question: the host reports it)
+      q_total += asked;
+      if (threadIdx.x == 0) {
+        // wait until the host has dealt with every pair this utterance queued (their slots are in the log by then)
+        unsigned n = 0;
+        for (int spins = 0;; ++spins) {
+          const unsigned ans = __hip_atomic_load(&a.cb_ans[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+          n = __hip_atomic_load(a.cb_log_len, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (n == 0xFFFFFFFFu || ans >= q_total) break;
+          if (spins > (1 << 21)) { n = 0xFFFFFFFFu; break; }  // (~2 s without an answer: leave, the host will relaunch)
+          __builtin_amdgcn_s_sleep(8);
+        }
+        cb_n = n;
+      }
+      __syncthreads();
+      const unsigned n = cb_n;
+      if (n == 0xFFFFFFFFu || n < log_pos) break;
+      ctclm::NgSlot *ng = const_cast<ctclm::NgSlot *>(a.lm.ng);
+      for (unsigned i = log_pos + threadIdx.x; i < n; i += blockDim.x) ng[a.cb_log_idx[i]] = a.cb_log_slot[i];
+      log_pos = n;
+      __threadfence();  // (release + acquire at device scope: the table entries are written, and nothing read from here on -- the table, the
+                        //  parked state -- comes from a line this CU cached before)
+      const int consumed = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ss.hdr[SH_FRAMES], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - before;
+      __syncthreads();
+      fo += (size_t)consumed;
+      len -= consumed;
+    }
+  } else {
+  st = decode_utterance<!PRUNED, LAYOUT, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2, LM == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + ((size_t)b * a.T + f0) * a.V : nullptr, a.raw_log,
                                   (PRUNED || kNoStreamedInput) ? (const int *)nullptr : a.frames_ready);
+  }
   if (threadIdx.x == 0) {
     if (a.shape) a.shape[b] = 16 * w.vars[ctcbeam::VAR_QSTAT];
     a.status[b] = st;
     if (a.frames_done && a.st_base) a.frames_done[b] = ss.hdr[SH_FRAMES];  // (written by this thread in save_state)
+    if (LM == 3 && a.cb_done) {  // (the host's service loop ends when every workgroup has reported)
+      __threadfence_system();
+      __hip_atomic_store(&a.cb_done[b], 1 + st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (PROF == 2 && a.tl && b == 0) {
     __syncthreads();

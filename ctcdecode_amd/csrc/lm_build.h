@@ -69,7 +69,7 @@ struct HostScorer {
     v.dict_lab = dict_lab.data(); v.dict_wide = dict_wide ? 1 : 0;
     v.ng_mask = (uint32_t)ng.size() - 1; v.order = order; v.char_based = char_based ? 1 : 0; v.space_id = space_id;
     v.s0 = s0; v.clean0 = clean0; v.w_bos = w_bos; v.w_eos = w_eos; v.alpha = alpha; v.beta = beta;
-    v.cb = 0; v.cb_miss = nullptr; v.cb_count = nullptr; v.cb_cap = 0;
+    v.cb = 0; v.cb_miss = nullptr; v.cb_count = nullptr; v.cb_cap = 0; v.cb_ring = 0;
     return v;
   }
 

@@ -24,8 +24,9 @@
 #pragma once
 #include <cmath>
 #include <limits>
-#include <map>
+#include <chrono>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "lm_build.h"
@@ -40,8 +41,18 @@ struct CallbackLm {
   HostScorer hs;  // labels, dictionary, and the cache tables (ng, st_bo, st_fail, uni_prob, uni_state)
   CondLog10Fn fn = nullptr;
   void *user = nullptr;
+  struct HistHash {
+    size_t operator()(const std::vector<uint32_t> &h) const {
+      uint64_t x = 0x9E3779B97F4A7C15ull;
+      for (uint32_t w : h) { x ^= w + 0x7F4A7C15u; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32; }
+      return (size_t)x;
+    }
+  };
   std::vector<std::vector<uint32_t>> hist;                 // per state: its word history (state 0 is never used)
-  std::map<std::vector<uint32_t>, uint32_t> state_of;
+  std::unordered_map<std::vector<uint32_t>, uint32_t, HistHash> state_of;
+  std::vector<uint32_t> win_, nh_;                         // scratch of resolve()
+  std::vector<const char *> ptr_;
+  double cb_seconds = 0.0;                                 // time inside the callback (every 16th call is timed, x 16)
   size_t used = 0;                                         // cache slots in use
   std::vector<uint32_t> dirty;                             // slots written since the device copy was last brought up to date
   bool rehashed = true;                                    // the whole table must travel
@@ -94,18 +105,32 @@ struct CallbackLm {
     return hs.build_labels_and_dictionary();
   }
 
-  void insert(const NgSlot &s) {
-    if ((used + 1) * 2 > hs.ng.size()) {  // at most half full
-      std::vector<NgSlot> old;
-      old.swap(hs.ng);
-      hs.ng.assign(old.size() * 2, NgSlot{kEmptySlot, 0, 0, 0});
-      for (const NgSlot &o : old)
-        if (o.state != kEmptySlot) place(o);
-      rehashed = true;
-    }
+  void grow(size_t slots) {  // a table of at least `slots` slots (a power of two): everything moves
+    size_t n = hs.ng.size();
+    while (n < slots) n *= 2;
+    if (n == hs.ng.size()) return;
+    std::vector<NgSlot> old;
+    old.swap(hs.ng);
+    hs.ng.assign(n, NgSlot{kEmptySlot, 0, 0, 0});
+    for (const NgSlot &o : old)
+      if (o.state != kEmptySlot) place(o);
+    rehashed = true;
+  }
+  // room for `more` insertions without the table moving (a launch that waits for its answers -- ctcdecode_amd.hip cb_rounds --
+  // applies single slots to the device copy while it runs: a rehash or a longer state array would pull the tables from under it)
+  bool room_for(size_t more, size_t state_cap) const { return (used + more) * 2 <= hs.ng.size() && hist.size() + more < state_cap; }
+  uint32_t insert(const NgSlot &s) {
+    if ((used + 1) * 2 > hs.ng.size()) grow(hs.ng.size() * 2);  // at most half full
     const uint32_t h = place(s);
     ++used;
     if (!rehashed) dirty.push_back(h);
+    return h;
+  }
+  long long find_slot(uint32_t state, uint32_t word) const {
+    const uint32_t mask = (uint32_t)hs.ng.size() - 1;
+    for (uint32_t h = ng_hash(state, word) & mask; hs.ng[h].state != kEmptySlot; h = (h + 1) & mask)
+      if (hs.ng[h].state == state && hs.ng[h].word == word) return (long long)h;
+    return -1;
   }
   uint32_t place(const NgSlot &s) {
     const uint32_t mask = (uint32_t)hs.ng.size() - 1;
@@ -122,15 +147,26 @@ struct CallbackLm {
   }
 
   // one queued pair: ask the callback, cache the answer.  false: the callback failed (hs.error says how)
-  bool resolve(uint32_t state, uint32_t word) {
+  // slot_out (optional): where the pair's slot sits in the table afterwards
+  bool resolve(uint32_t state, uint32_t word, uint32_t *slot_out = nullptr) {
     if (state == 0 || state >= hist.size() || word == 0 || word >= hs.vocab.size()) return hs.fail("scorer hook: the kernel queued a query that cannot exist (state " + std::to_string(state) + " of " + std::to_string(hist.size()) + ", word " + std::to_string(word) + " of " + std::to_string(hs.vocab.size()) + ")");
-    if (cached(state, word)) return true;  // (queued by several prefixes / utterances in the same round)
-    std::vector<uint32_t> win = hist[state];
-    win.push_back(word);
-    std::vector<const char *> ptr;
-    for (uint32_t id : win) ptr.push_back(hs.vocab[id].c_str());
+    {
+      const long long at = find_slot(state, word);  // (queued by several prefixes / utterances in the same round)
+      if (at >= 0) { if (slot_out) *slot_out = (uint32_t)at; return true; }
+    }
+    win_.assign(hist[state].begin(), hist[state].end());
+    win_.push_back(word);
+    ptr_.clear();
+    for (uint32_t id : win_) ptr_.push_back(hs.vocab[id].c_str());
     float p10 = 0.f;
-    const int rc = fn(user, ptr.data(), (int)ptr.size(), &p10);
+    int rc;
+    if ((queries & 15) == 0) {  // (what share of a cold decode is the callback's own time: bench.py reports it)
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = fn(user, ptr_.data(), (int)ptr_.size(), &p10);
+      cb_seconds += 16.0 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+      rc = fn(user, ptr_.data(), (int)ptr_.size(), &p10);
+    }
     ++queries;
     if (rc < 0) return hs.fail("scorer hook: the callback reported an error");
     if (rc == 0 && !(p10 == p10)) return hs.fail("scorer hook: the callback returned NaN");
@@ -143,9 +179,10 @@ struct CallbackLm {
     NgSlot s;
     s.state = state; s.word = word;
     std::memcpy(&s.prob_bits, &p10, 4);
-    std::vector<uint32_t> nh(win.end() - (hs.order - 1), win.end());  // the window's last N-1 words
-    s.next = state_id(nh);
-    insert(s);
+    nh_.assign(win_.end() - (hs.order - 1), win_.end());  // the window's last N-1 words
+    s.next = state_id(nh_);
+    const uint32_t at = insert(s);
+    if (slot_out) *slot_out = at;
     return true;
   }
 };

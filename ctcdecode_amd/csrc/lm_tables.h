@@ -45,6 +45,7 @@ constexpr int kMaxOrder = 6;               // KENLM_MAX_ORDER of the reference's
 constexpr double kOovScore = -1000.0;      // scorer.h:16
 
 struct NgSlot { uint32_t state, word, prob_bits, next; };         // 16 bytes
+struct alignas(16) MissEntry { uint32_t state, word, item, flag; };  // host-side scorer hook: a queued query (one 16-byte store: it arrives whole)
 struct DictNode { uint32_t mask_lo, mask_hi, first_child, word; };  // 16 bytes (wide dictionaries: mask_lo = first arc in dict_lab, mask_hi = #arcs)
 
 struct LmView {
@@ -71,9 +72,10 @@ struct LmView {
   // bump counter, cb_cap pairs fit) and ends the launch for that utterance at the frame boundary; the host asks the
   // callback, inserts, and the launch resumes.  A cached "out of vocabulary" answer is log10 prob = -inf.
   int cb;                      // 1: callback scorer
-  uint32_t *cb_miss;           // [cb_cap][2] (state, word)
+  MissEntry *cb_miss;          // [cb_cap] (state, word) asked for by batch item `item`; flag = 1
   unsigned *cb_count;
   uint32_t cb_cap;
+  int cb_ring;                 // 1: cb_miss is a ring of cb_cap (a power of two) pairs the host consumes while the launch runs
 };
 
 CTC_HD uint32_t ng_hash(uint32_t state, uint32_t word) {

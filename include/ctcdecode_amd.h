@@ -144,10 +144,12 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *w
  *   Decodes that share one callback scorer are serialised (its cache is one object) and the callback runs under that lock:
  *   a callback that itself decodes with the same scorer deadlocks.  A ctcd_stream_decode call that fails half-way (the
  *   callback reported an error) leaves the streams of that call unusable: destroy them.
- *   Cost: a warm cache decodes in one launch, like the built-in tables; every round of misses is one more launch plus the
- *   callback's own time, and an utterance can miss once per frame in which a prefix completes a word it has not asked about
- *   (bench.py "scorer hook": random rows under a 5-gram model miss in nearly every frame -- hundreds of launches; real
- *   transcripts revisit few histories).  ctcd_last_scorer_rounds tells how many launches the last call took.
+ *   Cost: a warm cache decodes in one launch, like the built-in tables.  Cold, an utterance misses once per frame in which a
+ *   prefix completes a word under a history it has not asked about; since round 6 its workgroup WAITS for the answer (see
+ *   ctcd_last_scorer_waits below) instead of ending its launch, and the call is bound by the calling thread: the callback's own
+ *   time plus ~0.15 us of bookkeeping per new window (bench.py "scorer hook": 128 x 1500 frames of transcript-like rows under a
+ *   5-gram model, 195 k windows, 87 ms cold in one launch -- 264 ms and 699 launches in round 5).  ctcd_last_scorer_rounds tells
+ *   how many launches the last call took.
  * ctcd_scorer_cond_log10 evaluates any scorer in the callback's own form (so the built-in tables can sit behind one);
  * ctcd_scorer_callback_calls counts the callback invocations so far (= distinct windows cached). */
 typedef int (*ctcd_cond_log10_fn)(void *user, const char *const *words, int n, float *log10_prob);
@@ -155,9 +157,18 @@ int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, in
                                 int n_vocabulary, ctcd_cond_log10_fn fn, void *user, const char *const *labels, int V, int device_id);
 int ctcd_scorer_cond_log10(const ctcd_scorer *scorer, const char *const *words, int n, float *log10_prob);
 long long ctcd_scorer_callback_calls(const ctcd_scorer *scorer);
+/* seconds spent inside the callback so far (every 16th call is timed and counted sixteen times: an estimate) */
+double ctcd_scorer_callback_seconds(const ctcd_scorer *scorer);
 /* launches the decoder's last call through a callback scorer took (1 = the cache held everything; one more per round of
  * misses): what a cold / lukewarm cache costs (bench.py "scorer hook") */
 int ctcd_last_scorer_rounds(ctcd_decoder *dec);
+/* Since round 6 a launch WAITS for the callback's answers: a workgroup whose utterance misses stays on its CU, the calling thread
+ * -- polling a miss list in page-locked memory -- asks the callback and publishes the answered cache slots, and the workgroup takes
+ * the utterance up again; a relaunch remains for what cannot be done under a running kernel (the cache table or the state arrays
+ * have to grow).  ctcd_last_scorer_waits: the answer batches the last call's launches were handed that way;
+ * ctcd_set_scorer_wait(dec, 0): every miss ends the utterance's launch, as in rounds 4-5 (identical results; tests run both). */
+int ctcd_last_scorer_waits(ctcd_decoder *dec);
+int ctcd_set_scorer_wait(ctcd_decoder *dec, int on);
 
 int ctcd_beam_decode_lm(ctcd_decoder *dec, const float *probs, const int32_t *seq_lens, int B, int T, int V, int beam,
                         int num_processes, double cutoff_prob, int cutoff_top_n, int blank_id, int log_input, ctcd_scorer *scorer,

@@ -198,6 +198,8 @@ struct HostX {
   void wave_max_to(int *p, uint32_t v) { *p = (int)std::max((uint32_t)*p, v); }
   void wave_min_to(int *p, uint32_t v) { *p = (int)std::min((uint32_t)*p, v); }
   unsigned global_add(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
+  int item_ = 0;
+  int item() const { return item_; }
 };
 
 // Vocabulary pruning exactly as the reference does it (decoder_utils.cpp:10-45) -- host stand-in for the GPU prune pass.
@@ -350,7 +352,7 @@ extern "C" int ctccore_decode_lm_cb_f32(const float *probs, const int32_t *seq_l
   size_t far_bytes = 0;
   std::vector<char> mem(carve<0>(w, nullptr, nullptr, d, &far_bytes) + 64);
   std::vector<char> far(far_bytes + 64);
-  std::vector<uint32_t> miss(2 * 65536);
+  std::vector<ctclm::MissEntry> miss(65536);
   unsigned nmiss = 0;
   long long resumes = 0;
   const bool wordlm = !cb.hs.char_based && !cb.hs.dict_wide && !getenv("CTC_HOST_GENERAL_LM");
@@ -363,11 +365,12 @@ extern "C" int ctccore_decode_lm_cb_f32(const float *probs, const int32_t *seq_l
     for (int guard = 0;; ++guard) {
       if (guard > 4 * T + 64) return -103;  // (every resumption consumes a frame or answers a query: this cannot loop)
       ctclm::LmView view = cb.hs.view();
-      view.cb = 1; view.cb_miss = miss.data(); view.cb_count = &nmiss; view.cb_cap = (uint32_t)(miss.size() / 2);
+      view.cb = 1; view.cb_miss = miss.data(); view.cb_count = &nmiss; view.cb_cap = (uint32_t)miss.size(); view.cb_ring = 0;
       nmiss = 0;
       const int done = hdr[SH_FRAMES];
       carve<0>(w, mem.data(), far.data(), d, nullptr);
       HostX x;
+      x.item_ = b;
       StreamState ss{hdr.data(), arrays.data(), 1};
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, 0u};
       const float *rows = in + ((size_t)b * T + done) * V, *raw = probs + ((size_t)b * T + done) * V;
@@ -379,8 +382,10 @@ extern "C" int ctccore_decode_lm_cb_f32(const float *probs, const int32_t *seq_l
       if (st == ST_OK) break;
       if (st != ST_NEED_HOST) return -st;
       if (nmiss == 0 || nmiss > view.cb_cap) return -104;
-      for (unsigned i = 0; i < nmiss; ++i)
-        if (!cb.resolve(miss[2 * i], miss[2 * i + 1])) return -105;
+      for (unsigned i = 0; i < nmiss; ++i) {
+        if ((int)miss[i].item != b || miss[i].flag != 1u) return -106;
+        if (!cb.resolve(miss[i].state, miss[i].word)) return -105;
+      }
       ++resumes;
     }
   }

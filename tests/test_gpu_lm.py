@@ -345,12 +345,14 @@ def test_scorer_hook_batch_with_pruning_and_streaming(torch_mod):
             ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.7, beta=0.9, beam_width=K, cutoff_top_n=topn, cutoff_prob=cp,
                                                log_probs_input=True)
             want = [t.numpy() for t in ref.decode(x, torch_mod.from_numpy(sl))]
-            sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, LABELS29, alpha=0.7, beta=0.9)
-            dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc, beam_width=K, cutoff_top_n=topn, cutoff_prob=cp, log_probs_input=True)
-            got = [t.numpy() for t in dec.decode(x, torch_mod.from_numpy(sl))]
-            for g, w in zip(got, want):
-                assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), (topn, cp)
-            assert sc.callback_calls() > 0
+            for wait in (True, False):  # (a launch that waits for its answers -- the default -- and a launch per round of misses)
+                sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, LABELS29, alpha=0.7, beta=0.9)
+                dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc, beam_width=K, cutoff_top_n=topn, cutoff_prob=cp, log_probs_input=True)
+                dec.set_scorer_wait(wait)
+                got = [t.numpy() for t in dec.decode(x, torch_mod.from_numpy(sl))]
+                for g, w in zip(got, want):
+                    assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), (topn, cp, wait)
+                assert sc.callback_calls() > 0
         # streaming: a fresh scorer (cold cache), chunk boundaries that split the parked frames
         sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, LABELS29, alpha=0.7, beta=0.9)
         ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.7, beta=0.9, beam_width=K, log_probs_input=True)
@@ -449,19 +451,24 @@ def test_scorer_hook_compact_results_cold_cache_and_order_one(torch_mod):
     lp = (lp - (m + np.log(np.exp(lp - m).sum(-1, keepdims=True)))).astype(np.float32)
     sl = np.random.default_rng(6).integers(0, T + 1, size=B).astype(np.int32)
     x, xs = torch_mod.from_numpy(lp), torch_mod.from_numpy(sl)
-    inner = _BuiltinBehindCallback(dict(labels=LABELS29, lm_path=TEST_ARPA))
-    try:
-        ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.7, beta=0.9, beam_width=K, cutoff_top_n=V, log_probs_input=True)
-        want = [t.cpu().numpy() for t in ref.decode_device(x, xs)]
-        sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, LABELS29, alpha=0.7, beta=0.9)
-        dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc, beam_width=K, cutoff_top_n=V, log_probs_input=True)
-        hdr, ent, labs, csc, cln = dec.decode_compact(x, xs)
-        assert sc.callback_calls() > 0 and int(ctcdecode_amd._native.lib.ctcd_last_scorer_rounds(dec._handle)) > 1
-        cout, cts = dec.expand_compact(hdr, ent, labs, T)
-        for g, w in zip((cout, csc, cts, cln), want):
-            assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
-    finally:
-        inner.close()
+    ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.7, beta=0.9, beam_width=K, cutoff_top_n=V, log_probs_input=True)
+    want = [t.cpu().numpy() for t in ref.decode_device(x, xs)]
+    # (round 6: by default a launch WAITS for the callback's answers -- one launch, many answer batches; set_scorer_wait(False) is the
+    #  launch-per-round-of-misses form, in which the records of utterances that finish in different launches accumulate)
+    for wait in (True, False):
+        inner = _BuiltinBehindCallback(dict(labels=LABELS29, lm_path=TEST_ARPA))
+        try:
+            sc = ctcdecode_amd.CallbackScorer(inner, inner.vocabulary, inner.order, LABELS29, alpha=0.7, beta=0.9)
+            dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc, beam_width=K, cutoff_top_n=V, log_probs_input=True)
+            dec.set_scorer_wait(wait)
+            hdr, ent, labs, csc, cln = dec.decode_compact(x, xs)
+            launches, waits = dec.last_scorer_launches()
+            assert sc.callback_calls() > 0 and ((waits > 0 and launches <= 2) if wait else (waits == 0 and launches > 1)), (wait, launches, waits)
+            cout, cts = dec.expand_compact(hdr, ent, labs, T)
+            for g, w in zip((cout, csc, cts, cln), want):
+                assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
+        finally:
+            inner.close()
     arpa1 = os.path.join(gu.DATA_DIR, "unigram_bo.arpa")
     labs4 = ["_", " ", "a", "b"]
     inner = _BuiltinBehindCallback(dict(labels=labs4, lm_path=arpa1))
