@@ -98,9 +98,10 @@ def measure_traffic(a):
     try:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, c)
-            # (the child decodes the same batch -- same generator, same seed -- four times and does nothing else: tools/pmc_child.py)
+            # (the child -- tools/pmc_child.py -- builds the batch this run times: rank 0's, same generator expression, same seed and shape,
+            #  decodes it four times and does nothing else; config 1 only: no LM, no pruning)
             cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
-                   os.path.join(ROOT, "tools", "pmc_child.py"), str(a.batch or 256), str(a.frames or 1000), str(a.vocab), str(a.beam or 100), str(a.threads)]
+                   os.path.join(ROOT, "tools", "pmc_child.py"), str(a.batch or 256), str(a.frames or 1000), str(a.vocab), str(a.beam or 100), str(a.threads), "1234"]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             vals = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -110,7 +111,7 @@ def measure_traffic(a):
             if not vals:
                 return None, "rocprofv3 --pmc %s gave no rows for the decode kernel (rc %d)" % (c, r.returncode)
             total += sum(vals) / len(vals) * 1024.0
-        return int(total), "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (mean over their launches)"
+        return int(total), "measured during this run on the batch it times: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_child.py, which decodes rank 0's batch (same generator, seed 1234, shape) four times; mean over those launches"
     except Exception as e:  # (a profiler that is missing or hangs must not take the bench line with it)
         return None, "rocprofv3 child run failed: %r" % (e,)
     finally:
@@ -238,8 +239,9 @@ def time_inflight(torch, ctcdecode_amd, dev, lp, labels, K, inflight, steps=12, 
     """Batches of lp.shape[0] utterances through ctcdecode_amd.DecodePipeline with `inflight` launches in flight, DEFAULT build of
     the kernel (one workgroup per CU, nothing shared): seconds per batch.  inflight = 1 is the plain loop."""
     V = lp.shape[2]
-    pipe = ctcdecode_amd.DecodePipeline(lambda: ctcdecode_amd.CTCBeamDecoder(labels, cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev, **dec_kw),
-                                        inflight=inflight)
+    kw = dict(cutoff_top_n=V)
+    kw.update(dec_kw)
+    pipe = ctcdecode_amd.DecodePipeline(lambda: ctcdecode_amd.CTCBeamDecoder(labels, beam_width=K, log_probs_input=True, device=dev, **kw), inflight=inflight)
 
     def run(n):  # (results are collected -- and dropped -- as a serving loop would: `inflight` batches are alive at any time)
         tickets = []
@@ -540,6 +542,21 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
     run("configs[3] (V=10000, top_n 40, cutoff_prob 0.99)", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99)
     run("configs[3] fed raw logits (logits_input=True: pre-pass + prune fused)", 64, 500, 10000, 100, top_n=40, cutoff_prob=0.99, logits=True)
     run("configs[4] per-GPU shape without the LM (128 of 1024 utterances, T 1500)", 128, 1500, 29, 100)
+    # configs[3]'s 64 utterances occupy a quarter of the CUs -- the rest goes to the next batches (DecodePipeline; the rule
+    # inflight_for(64) says 2, four launches fill the chip)
+    try:
+        lp64 = synth_rows(torch, 64, 500, 10000, 7).to(dev)
+        lab10k = [str(i) for i in range(10000)]
+        q = {"what": "batches of 64 utterances (configs[3]: V=10000, top_n 40, cutoff_prob 0.99; a quarter of the CUs) through ctcdecode_amd.DecodePipeline, prune pass + decode per batch; utterances/s",
+             "inflight_for(64)": int(ctcdecode_amd.DecodePipeline.inflight_for(64, dev))}
+        for k in (1, 2, 4):
+            dt = time_inflight(torch, ctcdecode_amd, dev, lp64, lab10k, 100, k, steps=16, warm=4, cutoff_top_n=40, cutoff_prob=0.99)
+            q["%d_in_flight" % k] = {"utt_per_s": round(64 / dt, 1), "ms_per_batch": round(dt * 1e3, 3)}
+        out["configs[3], idle three quarters of the chip given to the next batches"] = q
+        del lp64
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["configs[3], several launches in flight"] = {"error": str(e)[:200]}
     arpa = os.path.join(ROOT, "tests", "data", "test.arpa")
     # 128 utterances occupy half the CUs.  The time axis cannot be split, so the idle half is given to the
     # NEXT batch: ctcdecode_amd.DecodePipeline, two launches in flight on two streams, default build, no CU shared.

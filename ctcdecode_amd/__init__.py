@@ -396,7 +396,7 @@ class CTCBeamDecoder(object):
             scores = torch.empty((B, K), dtype=torch.float32, device=self._device)
             out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
             stream = torch.cuda.current_stream(self._device).cuda_stream
-            _native.check(_native.lib.ctcd_beam_decode_compact(
+            self._check(_native.lib.ctcd_beam_decode_compact(
                 self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K, self._num_processes,
                 float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
                 self._scorer.handle if self._scorer is not None else None, hdr.data_ptr(), ent.data_ptr(), self._c_labels.data_ptr(),
@@ -411,7 +411,8 @@ class CTCBeamDecoder(object):
         """``decode_compact`` without waiting: the kernel, then the copies of the status words and of the label count into
         page-locked memory, are enqueued on the current stream and an event is recorded behind them.  Returns a ticket for
         ``finish_compact``; the caller may queue the NEXT batch (on another decoder object: this one's workspace is in use)
-        before looking at this one -- how a serving loop keeps the GPU busy while the host handles the previous results."""
+        before looking at this one -- how a serving loop keeps the GPU busy while the host handles the previous results.
+        With a callback scorer the call BLOCKS until the decode is done: the callback is served on the calling thread."""
         if probs.dim() != 3:
             raise ValueError("probs must be [batch, time, labels]")
         probs = probs.to(device=self._device, dtype=torch.float32).contiguous()
@@ -431,7 +432,7 @@ class CTCBeamDecoder(object):
             scores = torch.empty((B, K), dtype=torch.float32, device=self._device)
             out_len = torch.empty((B, K), dtype=torch.int32, device=self._device)
             stream = torch.cuda.current_stream(self._device)
-            _native.check(_native.lib.ctcd_beam_decode_compact(
+            self._check(_native.lib.ctcd_beam_decode_compact(
                 self._handle, probs.data_ptr(), seq_lens.data_ptr() if seq_lens is not None else None, B, T, V, K, self._num_processes,
                 float(self._cutoff_prob), int(self.cutoff_top_n), int(self._blank_id), self._log_probs,
                 self._scorer.handle if self._scorer is not None else None, hdr.data_ptr(), ent.data_ptr(), self._c_labels.data_ptr(),
@@ -508,8 +509,9 @@ class DecodePipeline(object):
         tickets = [pipe.submit(batch) for batch in batches]      # asynchronous; at most `inflight` are in flight
         results = [pipe.result(t) for t in tickets]              # (output, scores, timesteps, out_lens) in HBM, in order
 
-    ``submit`` waits for the slot's previous launch if its result has not been collected yet; results must be collected in
-    submission order per slot (``result`` of an older ticket of the same slot after a newer submit raises).
+    ``submit`` waits for the slot's previous launch if its status has not been looked at yet; tickets stay fetchable in any
+    order.  A batch that failed (a status word, a scorer callback's exception) raises from ``result`` of ITS ticket -- every time it
+    is asked -- and from ``drain``; it never blocks its slot: the next ``submit`` there goes ahead.
     """
 
     def __init__(self, make_decoder, inflight=2, cu_sharing=False):
@@ -545,32 +547,46 @@ class DecodePipeline(object):
         # (the launch reads the caller's tensors on the side stream: they stay referenced until it has finished -- a tensor
         #  dropped by the caller right after submit() would otherwise go back to the caching allocator and be handed out again)
         ticket = {"slot": slot, "serial": self._serial, "res": res, "event": ev, "batch": int(probs.shape[0]), "done": False,
-                  "inputs": (probs, seq_lens)}
+                  "inputs": (probs, seq_lens), "error": None}
         self._pending[slot] = ticket
         self._serial += 1
         return ticket
 
     def _finish(self, ticket):
+        """Waits for the ticket's launch and looks at its status words once; a failure is kept on the ticket (raising from
+        here left the slot pending for ever)."""
         if ticket["done"]:
             return
-        if self._pending[ticket["slot"]] is not ticket:
-            raise RuntimeError("DecodePipeline: this ticket's slot has been resubmitted; collect results in submission order")
-        ticket["event"].synchronize()
-        self._decs[ticket["slot"]]._check(_native.lib.ctcd_check_status(self._decs[ticket["slot"]]._handle, ticket["batch"]))
-        ticket["done"] = True
-        ticket["inputs"] = None
-        self._pending[ticket["slot"]] = None
+        slot = ticket["slot"]
+        try:
+            ticket["event"].synchronize()
+            self._decs[slot]._check(_native.lib.ctcd_check_status(self._decs[slot]._handle, ticket["batch"]))
+        except Exception as e:  # noqa: BLE001 (whatever decode_device would have raised)
+            ticket["error"] = e
+        finally:
+            ticket["done"] = True
+            ticket["inputs"] = None
+            if self._pending[slot] is ticket:
+                self._pending[slot] = None
 
     def result(self, ticket):
         """The four HBM tensors of a submitted batch (waits for its launch; raises what ``decode_device`` would have raised)."""
         self._finish(ticket)
+        if ticket.get("error") is not None:
+            raise ticket["error"]
         torch.cuda.current_stream(self._device).wait_event(ticket["event"])
         return ticket["res"]
 
     def drain(self):
+        """Waits for everything in flight; raises the first failure among the batches nobody has asked about yet."""
+        first = None
         for t in list(self._pending):
             if t is not None:
                 self._finish(t)
+                if first is None and t.get("error") is not None:
+                    first = t["error"]
+        if first is not None:
+            raise first
 
 
 class OnlineCTCBeamDecoder(object):

@@ -1149,7 +1149,8 @@ struct ctcd_scorer {
   size_t cb_ng_slots = 0, cb_st_cap = 0;
   char *cb_stage = nullptr;  // dirty cache slots of a round, sent with ONE copy and scattered by a kernel: [indices | slots]
   size_t cb_stage_cap = 0;   // ... slots it holds
-  std::vector<char> cb_stage_h;
+  char *cb_stage_hp = nullptr;  // ... its page-locked host end
+  hipEvent_t cb_stage_ev = nullptr;  // ... and the last copy out of it
   std::mutex cb_mu;          // one decode at a time mutates the cache
   // page-locked, device-visible block of the launches that wait for their answers (cb_rounds): [log length | workgroup reports |
   // pairs answered per item | miss list | log: slot indices | log: slots]
@@ -1312,6 +1313,30 @@ int ctcd_set_threads(ctcd_decoder *d, int t) {
   if (!d || t < 0 || t > 1024 || (t && (t < 64 || (t & (t - 1))))) return fail(CTCD_EINVAL, "threads must be 0 (automatic) or a power of two in [64, 1024]");
   d->threads = t;
   return CTCD_OK;
+}
+
+// The builds whose kernels ignore KernelArgs::frames_ready (decode_kernel.h kNoStreamedInput) and the twins that poll it.  EVERY
+// instantiation for which kNoStreamedInput holds must be listed here.
+static const void *streamed_input_twin(const void *fn) {
+  struct Pair { const void *plain, *twin; };
+  static const Pair tab[] = {
+#if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2
+    {(const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>, (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, 2>},
+#elif defined(CTC_QUICK_BUILD) && (CTC_QUICK_BUILD == 3 || CTC_QUICK_BUILD == 4)
+    {nullptr, nullptr},
+#elif defined(CTC_QUICK_BUILD)
+    {(const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>, (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024>},
+    {(const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>, (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, false, true>},
+#else
+    {(const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>, (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024>},
+    {(const void *)ctc_beam_decode_kernel<3, 0, 1, false, 1024>, (const void *)ctc_beam_decode_kernel<5, 0, 1, false, 1024>},
+    {(const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>, (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, false, true>},
+    {(const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>, (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, 2>},
+#endif
+  };
+  for (const Pair &p : tab)
+    if (p.plain && p.plain == fn) return p.twin;
+  return nullptr;
 }
 
 // log_softmax of every frame (ctcd_log_softmax's definition): long rows by a workgroup each, short ones by a wave each
@@ -1629,7 +1654,6 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, true>;
   if (!scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel)
     fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, 2> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>;
-  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, 2>;
 #elif defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 3
   // Workgroup-size sweep (tools/build_variants.sh nt512:CTC_QUICK_BUILD=3,CTC_QUICK_NT=512; raw_multi.py --threads 512)
   if (big || !fixed || pruned_mode || scorer || occ2 || threads != CTC_QUICK_NT || d->profile)
@@ -1642,8 +1666,6 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     return fail(CTCD_EUNSUPPORTED, "CTC_QUICK_BUILD: only the fixed-layout, no-prune, no-LM, 1024-thread kernel was compiled");
   fn = d->profile ? (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>;
   if (occ2) fn = (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
-  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024>;
-  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, false, true>;
 #else
 #define CTC_PICK(PROF_)                                                                                                  \
   (big ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, true> : (const void *)ctc_beam_decode_kernel<PROF_, 1, 0, false>)    \
@@ -1677,10 +1699,6 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     }
   }
 #undef CTC_PICK
-  // streamed input (the host-tensor entry point): the north-star class's default builds do not poll for rows -- their twins do (decode_kernel.h PROF 4 / 5)
-  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024>;
-  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<3, 0, 1, false, 1024>) fn = (const void *)ctc_beam_decode_kernel<5, 0, 1, false, 1024>;
-  if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, false, true>;
   if (scorer) {
     fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 0, 0, false, 0, true>;
     if (fixed)  // the usual class of shapes: compile-time workspace layout and workgroup size, as without a scorer
@@ -1707,9 +1725,18 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, true>;
       if (!scorer->host.char_based && !scorer->host.dict_wide && !d->general_lm_kernel) fn = (const void *)ctc_beam_decode_kernel<2, 0, 1, false, 1024, 2>;
     }
-    if (a.frames_ready && fn == (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 2>) fn = (const void *)ctc_beam_decode_kernel<4, 0, 1, false, 1024, 2>;  // (streamed input: its twin)
   }
 #endif
+  // streamed input (a.frames_ready: the host-tensor entry point feeds the rows while the kernel runs): the north-star class's default
+  // builds do not poll for rows (decode_kernel.h kNoStreamedInput) -- their twins do.  The mapping lives HERE, behind every branch of the
+  // selection above (it used to be repeated per branch; a branch without it would decode rows that have not crossed PCIe).
+  if (a.frames_ready) {
+    const void *twin = streamed_input_twin(fn);
+    if (twin) fn = twin;
+#if defined(CTC_QUICK_BUILD) && (CTC_QUICK_BUILD == 3 || CTC_QUICK_BUILD == 4)
+    else return fail(CTCD_EUNSUPPORTED, "this experiment build has no kernels that take streamed input");
+#endif
+  }
   // (CTCD_LDS_FLOOR: experiments with the occupancy the LDS request allows)
   if (d->lds_floor >= 0) lds = std::max(lds, std::min((size_t)d->lds_floor, (size_t)d->max_lds - 2048));
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1784,6 +1811,8 @@ void ctcd_scorer_destroy(ctcd_scorer *s) {
   for (char *p : {s->cb_ng, s->cb_st, s->cb_uni, s->cb_miss, s->cb_stage})
     if (p) (void)hipFree(p);
   if (s->h_live) (void)hipHostFree(s->h_live);
+  if (s->cb_stage_hp) (void)hipHostFree(s->cb_stage_hp);
+  if (s->cb_stage_ev) (void)hipEventDestroy(s->cb_stage_ev);
   delete s->cbl;
   delete s;
 }
@@ -1810,18 +1839,24 @@ static int cb_sync(ctcd_scorer *s, hipStream_t stream = nullptr) {
     // them in place.  (Rounds 1-4: one blocking 16-byte hipMemcpy per slot -- ~10 us each, 500 a round at the configs[4] shape:
     // two thirds of a round's 8 ms.)
     const size_t n = c.dirty.size();
-    if (s->cb_stage_cap < n) {
+    if (s->cb_stage_cap < n) {  // (both ends of the copy grow together; the host end is page-locked: the copy is queued on `stream`, in front
+                                //  of the scatter kernel, and its ordering comes from the stream -- ADVICE r5)
+      if (stream) HIP_TRY(hipStreamSynchronize(stream)); else HIP_TRY(hipDeviceSynchronize());
       if (s->cb_stage) (void)hipFree(s->cb_stage);
-      s->cb_stage = nullptr;
+      if (s->cb_stage_hp) (void)hipHostFree(s->cb_stage_hp);
+      s->cb_stage = nullptr; s->cb_stage_hp = nullptr; s->cb_stage_cap = 0;
       const size_t cap = n * 2 + 1024;
       HIP_TRY(hipMalloc((void **)&s->cb_stage, cap * (4 + sizeof(ctclm::NgSlot))));
+      HIP_TRY(hipHostMalloc((void **)&s->cb_stage_hp, cap * (4 + sizeof(ctclm::NgSlot)), hipHostMallocDefault));
       s->cb_stage_cap = cap;
     }
-    s->cb_stage_h.resize(n * (4 + sizeof(ctclm::NgSlot)));
-    uint32_t *hi = (uint32_t *)s->cb_stage_h.data();
-    ctclm::NgSlot *hsl = (ctclm::NgSlot *)(s->cb_stage_h.data() + n * 4);
+    if (!s->cb_stage_ev) HIP_TRY(hipEventCreateWithFlags(&s->cb_stage_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventSynchronize(s->cb_stage_ev));  // (the previous copy out of this block -- possibly queued by a call that has returned)
+    uint32_t *hi = (uint32_t *)s->cb_stage_hp;
+    ctclm::NgSlot *hsl = (ctclm::NgSlot *)(s->cb_stage_hp + n * 4);
     for (size_t k = 0; k < n; ++k) { hi[k] = c.dirty[k]; hsl[k] = h.ng[c.dirty[k]]; }
-    HIP_TRY(hipMemcpy(s->cb_stage, s->cb_stage_h.data(), s->cb_stage_h.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(s->cb_stage, s->cb_stage_hp, n * (4 + sizeof(ctclm::NgSlot)), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(s->cb_stage_ev, stream));
     hipLaunchKernelGGL(cb_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (ctclm::NgSlot *)s->cb_ng, (const uint32_t *)s->cb_stage,
                        (const ctclm::NgSlot *)(s->cb_stage + n * 4), (unsigned)n);
     HIP_TRY(hipGetLastError());

@@ -930,6 +930,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   // 10.94 -> 10.70 ms; the kernels sit at the scalar-register limit), so that case gets a build without them and the
   // streamed case keeps the build it had.
   constexpr int XP = PROF == 4 ? 0 : PROF == 5 ? 3 : PROF;
+  // (every instantiation for which this holds is listed, with its twin, in ctcdecode_amd.hip streamed_input_twin: the launch code swaps them)
   constexpr bool kNoStreamedInput = (PROF == 0 || PROF == 3) && LAYOUT == 1 && NT == 1024 && (LM == 0 || LM == 2) && !PRUNED && BIG == 0 && (!OCC2 || LM == 0);
   DevX<XP, BIG != 0, NT> x{red, 0, prof, 0, (PROF == 1 && a.dbg && b == 0) ? a.dbg : nullptr, 1 + 4 * a.K,
                     (PROF == 2 && b == 0 && a.tl) ? tlbuf : nullptr, tlcnt, kTlCap, a.tl_f0, a.tl_nf};

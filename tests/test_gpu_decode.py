@@ -1179,3 +1179,36 @@ def test_decode_pipeline_two_launches_in_flight(torch_mod):
         pipe.drain()
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     assert ctcdecode_amd.DecodePipeline.inflight_for(ncu // 2) == 2 and ctcdecode_amd.DecodePipeline.inflight_for(ncu) == 1
+    # a failed batch (a scorer callback that raises) fails ITS ticket -- every time it is asked -- and nothing else: the slot takes the
+    # next batch, the neighbours' results are intact, drain() reports a failure nobody has collected
+    if getattr(ctcdecode_amd, "HAVE_LM", False):
+        lab4 = ["_", "a", "b", " "]
+        state = {"boom": False}
+
+        class Boom(Exception):
+            pass
+
+        def cb(words):
+            if state["boom"]:
+                raise Boom("no model today")
+            return -1.0
+
+        scs = [ctcdecode_amd.CallbackScorer(cb, ["a", "ab", "ba"], 2, lab4, alpha=1.0, beta=0.5) for _ in range(2)]
+        it = iter(scs)
+        pipe = ctcdecode_amd.DecodePipeline(lambda: ctcdecode_amd.CTCBeamDecoder(lab4, scorer=next(it), beam_width=8, log_probs_input=True, device="cuda:0"), inflight=2)
+        xs = [torch.from_numpy(ou.synth_logprobs(2, 30, 4, 700 + i, blank_bias=0.5)).cuda() for i in range(4)]
+        t0 = pipe.submit(xs[0])
+        state["boom"] = True
+        try:
+            t1 = pipe.submit(xs[1])   # (a callback scorer decodes inside submit: the exception may surface here ...)
+        except Boom:
+            t1 = None
+        state["boom"] = False
+        t2 = pipe.submit(xs[2])
+        t3 = pipe.submit(xs[3])       # the slot of the failed batch is usable
+        if t1 is not None:            # (... or it is kept on the ticket)
+            for _ in range(2):
+                with pytest.raises(Boom):
+                    pipe.result(t1)
+        assert len(pipe.result(t0)) == 4 and len(pipe.result(t2)) == 4 and len(pipe.result(t3)) == 4
+        pipe.drain()
