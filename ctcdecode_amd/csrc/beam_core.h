@@ -205,7 +205,7 @@ constexpr int kExpress = 32;
 // peaky acoustic posteriors.
 enum Event { EV_FRAMES, EV_CANDIDATES, EV_EXACT, EV_INTERNAL, EV_PINNED, EV_LPC_UPDATE, EV_DEAD_PARENT, EV_REVIVE_CAND, EV_REVIVED, EV_WALK,
              EV_WALK_HOPS, EV_FAST_SELECT, EV_SINGLE_KEY, EV_BUCKET_KEYS, EV_SPEC_OK, EV_SPEC_UNDER, EV_SPEC_OVER, EV_SPEC_OTHER, EV_SPEC_HOT,
-             EV_SLOW_BELOW, EV_SLOW_CROWDED, EV_SLOW_SINGLE, EV_SLOW_ROUNDS, EV_TIE_FRAMES, EV_TIE_KEYS, EV_TIE_BIG, EV_TIE_UNSETTLED, EV_COUNT };
+             EV_SLOW_BELOW, EV_SLOW_CROWDED, EV_SLOW_SINGLE, EV_SLOW_ROUNDS, EV_TIE_FRAMES, EV_TIE_KEYS, EV_TIE_BIG, EV_WIDE_LIST, EV_COUNT };
 
 struct Work {
   // The beam is double-buffered: step t reads the copy of parity p and writes the other one.  cur / nxt are re-derived
@@ -1091,28 +1091,30 @@ struct Decoder {
   // of them (VAR_TAU), G = gsum + #bucket keys above tau, E = #keys equal to tau.  `direct` (first round only): the
   // listing pass also records, one bit per slot, every key ABOVE the bucket, and the ranking threads add the bucket's
   // own survivors, so the caller only has to expand the bitmap.  inb = #keys in the bucket (<= kListCap).
+  // lst / lsl: where the bucket's keys and slots are listed -- w.list / w.lslot (kListCap entries), or, for a crowded bucket of a beam
+  // without a scorer, the block of the NEXT beam (wide_list_cap() entries: nothing lives there between two emissions).
   template <bool COMPACT = false>
-  CTC_HD void rank_bucket(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb) {
+  CTC_HD void rank_bucket(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb, uint32_t *lst, int *lsl) {
     const int tid = x.tid(), nt = x.nt();
-    CTC_ASSUME(inb >= 1 && inb <= kListCap);
+    CTC_ASSUME(inb >= 1);
     // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
-    x.template list_bucket<kTailZero, COMPACT>(S, w.skey, b32, bspan, direct, w.bitmap, w.list, w.lslot, &pv[P_LCOUNT]);
-    for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
+    x.template list_bucket<kTailZero, COMPACT>(S, w.skey, b32, bspan, direct, w.bitmap, lst, lsl, &pv[P_LCOUNT]);
+    for (int q = tid; q < 4; q += nt) lst[inb + q] = 0;  // pad to a multiple of four, below every real entry
     x.sync();
     x.mark(14);
-    // a long list (wide beams: up to kListCap keys share the bucket) is ranked by eight lanes per key, each comparing an
-    // eighth of the list; a short one by one lane per key
+    // a long list (wide beams: up to kListCap keys share the bucket, a crowded bucket's wide list more) is ranked by eight lanes per
+    // key, each comparing an eighth of the list; a short one by one lane per key
     const bool wide_rank = !SMALLV && inb > 32 && nt >= 8 * kListCap;
     // (fixed-layout class at 1024 threads: four lanes per key, each comparing a quarter of the list -- some twenty keys share
     //  the bucket on ordinary input, and the ranking is a single-wave stage: five rounds of loads and compares become two)
     const bool quad_rank = SMALLV && !COMPACT && x.nt_is(1024);
     const int psh = wide_rank ? 3 : quad_rank ? 2 : 0;
-    for (int q0 = tid; q0 < (wide_rank ? 8 * kListCap : inb << psh); q0 += nt) {
+    for (int q0 = tid; q0 < (wide_rank ? 8 * (inb > kListCap ? inb : kListCap) : inb << psh); q0 += nt) {
       const int q = q0 >> psh, part = q0 & ((1 << psh) - 1), stride = 4 << psh;
-      const uint32_t mine = q < inb ? w.list[q] : 0u;
+      const uint32_t mine = q < inb ? lst[q] : 0u;
       int g = 0, e = 0;
       for (int r = 4 * part; r < inb; r += stride) {
-        const uint32_t o0 = w.list[r], o1 = w.list[r + 1], o2 = w.list[r + 2], o3 = w.list[r + 3];
+        const uint32_t o0 = lst[r], o1 = lst[r + 1], o2 = lst[r + 2], o3 = lst[r + 3];
         g += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
         e += (o0 == mine) + (o1 == mine) + (o2 == mine) + (o3 == mine);
       }
@@ -1127,13 +1129,18 @@ struct Decoder {
         w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gsum + g; w.vars[VAR_E] = e;
       }
       if (direct && g < want) {  // key >= tau: survives (unless equal scores straddle the boundary -- caller's business)
-        const int sl = w.lslot[q];
+        const int sl = lsl[q];
         x.atomic_or(&w.bitmap[sl >> 5], 1u << (sl & 31));
       }
     }
     x.sync();
   }
 
+  // entries of the wide bucket list (keys, then slots, in the next beam's block: w.beam_blk bytes from w.nxt.node)
+  CTC_HD int wide_list_cap() const {
+    const long long c = (long long)(w.beam_blk / 8) - 8;
+    return c >= 1024 ? 1024 : c <= kListCap ? 0 : (int)(c & ~3LL);
+  }
   CTC_HD bool select_kth(int S, int K, int *pv, const Window &wd) {
     const int tid = x.tid(), nt = x.nt();
     // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
@@ -1146,11 +1153,27 @@ struct Decoder {
     x.mark(13);
     // The usual outcome: the first histogram isolates a bucket with a handful of keys, several values wide.  Everything
     // about it fits 32-bit arithmetic (the window's top is the previous best key, below 2^32).
-    if (CTC_USUAL(fb[0] >= 0 && fb[3] <= kListCap && (wd.shift != 0 || fb[0] == kBins - 1))) {
+    // Round 6, measured and left off (CTC_EXP_WIDE_LIST): a CROWDED bucket (more than kListCap keys: at beam 500 one frame in three --
+    // float32 scores near 10^3 are 10^-4 apart, and the children of equal prefixes inherit equal scores; 256 keys on average) listed
+    // once, as the usual bucket is, into a list that borrows the next beam's block, and ranked there by all sixteen waves, so that the
+    // frame stays on this path.  Exact (tests/sweeps/cpu_wide_list_sweep.py: 9 912 configurations / 96 k such frames against the
+    // reference, 0 mismatches) and SLOWER: configs[2] per-GPU shape 39.85 -> 41.2 ms.  The phase timers say why
+    // (profiles/r06r / r06t_phase_beam500*.json): listing 256 members costs the gather pass +0.9 us per frame, while the path it
+    // replaces -- a second histogram over the S slots, which ends on a single key value, and one marking pass -- was worth 0.1 us.
+    // The select's share of this kernel (25 %) is the two passes over 15 500 slot keys every frame makes, not the crowded frames.
+#if defined(CTC_EXP_WIDE_LIST)
+    const int wcap = (!SMALLV && !LM) ? wide_list_cap() : 0;
+#else
+    constexpr int wcap = 0;
+#endif
+    const bool bucket_ok = fb[0] >= 0 && (wd.shift != 0 || fb[0] == kBins - 1);
+    const bool wide = bucket_ok && fb[3] > kListCap && fb[3] <= wcap;
+    if (CTC_USUAL(bucket_ok && (fb[3] <= kListCap || wide))) {
       const uint32_t b32 = wd.lo + ((uint32_t)fb[0] << wd.shift);
       const uint32_t bspan = fb[0] == kBins - 1 ? 0xFFFFFFFFu - b32 : (1u << wd.shift) - 1u;
-      if (tid == 0) { x.count(EV_FAST_SELECT, 1); x.count(EV_BUCKET_KEYS, fb[3]); if (fb[3] == 1) x.count(EV_SINGLE_KEY, 1); }
-      rank_bucket(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3]);
+      if (tid == 0) { x.count(EV_FAST_SELECT, 1); x.count(EV_BUCKET_KEYS, fb[3]); if (fb[3] == 1) x.count(EV_SINGLE_KEY, 1); if (wide) x.count(EV_WIDE_LIST, 1); }
+      uint32_t *wl = reinterpret_cast<uint32_t *>(w.nxt.node);
+      rank_bucket(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3], wide ? wl : w.list, wide ? reinterpret_cast<int *>(wl + wcap + 4) : w.lslot);
       return true;
     }
     // Rare: the K-th key lies below the window, the bucket is crowded, or it is a single key value.
@@ -1180,7 +1203,7 @@ struct Decoder {
         else { if (tid == 0) x.count(EV_SLOW_CROWDED, 1); gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
       }
       if (!again) {  // exact rank inside the bucket, on offsets from its base
-        rank_bucket<true>(S, pv, (uint32_t)blo, (uint32_t)(bhi - blo - 1), first, need - above, gbase + above, inb);
+        rank_bucket<true>(S, pv, (uint32_t)blo, (uint32_t)(bhi - blo - 1), first, need - above, gbase + above, inb, w.list, w.lslot);
         return first;
       }
       // another histogram round over [lo, hi)

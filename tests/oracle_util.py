@@ -174,7 +174,8 @@ def build_core_host():
     if os.path.exists(CORE_HOST_SO) and all(os.path.getmtime(CORE_HOST_SO) >= os.path.getmtime(p) for p in deps):
         return CORE_HOST_SO
     os.makedirs(os.path.dirname(CORE_HOST_SO), exist_ok=True)
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-DCTC_ASSUME_CHECKED", src, "-o", CORE_HOST_SO, "-lpthread"], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-DCTC_ASSUME_CHECKED"] + os.environ.get("CTC_HOST_EXTRA_FLAGS", "").split()
+                   + [src, "-o", CORE_HOST_SO, "-lpthread"], check=True)
     return CORE_HOST_SO
 
 
