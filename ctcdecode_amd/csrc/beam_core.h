@@ -318,7 +318,9 @@ CTC_HD size_t carve(Work &w, char *base, char *far, const Dims &d, size_t *far_b
 #endif
   w.bitmap = carve_ptr<uint32_t>(huge ? q : p, 2 * ((S + 63) / 64 + 17));
   w.wpre = huge ? carve_ptr<uint32_t>(q, (S + 63) / 64 + 2) : reinterpret_cast<uint32_t *>(w.bins);
-  w.fin = carve_ptr<int>(BIG ? q : p, K);  // (last / exact / danger frames and finish() only: HBM scratch in the wide-beam layouts)
+  // (last / exact / danger frames and finish() only: HBM scratch in the wide-beam layouts.  With a scorer: two copies -- behind the
+  //  host-side hook a frame can be abandoned after it has written the NEXT beam's order, Decoder::fin_cur / fin_nxt)
+  w.fin = carve_ptr<int>(BIG ? q : p, d.lm ? 2 * K : K);
   w.apos = carve_ptr<int>(BIG ? q : p, K);  // (read in danger mode only: HBM scratch in the wide-beam layouts)
   w.sstack = carve_ptr<int>(p, 3 * (2 * 32 + 2));
   w.vars = carve_ptr<int>(p, VAR_COUNT);
@@ -598,6 +600,11 @@ struct Decoder {
   // (CB): as a run-time flag the hook's checks and the state they keep alive cost the built-in scorer's kernels 11 % per frame
   // (12.36 against 11.16 ms at the configs[4] shape); callback scorers get instantiations of their own.
   static constexpr bool lm_cb = LM && CB;
+  // fin[]: the order std::nth_element left the beam in (read by danger mode and by finish()).  Behind the scorer hook the frame that
+  // writes the next beam's order may be abandoned and run again: it writes the copy of the other parity, which becomes current only
+  // when the frame commits (st_par flips).
+  CTC_HD int *fin_cur() const { return w.fin + (lm_cb ? st_par * d.K : 0); }
+  CTC_HD int *fin_nxt() const { return w.fin + (lm_cb ? (st_par ^ 1) * d.K : 0); }
   // get_log_cond_prob through the tables.  With a callback scorer a value that is not cached yet comes back as NaN: the pair
   // is queued for the host, the frame is marked (it will not be committed: step() / finish() return ST_NEED_HOST) and the
   // caller's state is left where it was; a cached "out of vocabulary" answer (-inf) becomes the reference's OOV_SCORE.
@@ -800,8 +807,9 @@ struct Decoder {
   CTC_HD void lm_sorted_order(const Beam &b, int n) {
     const int tid = x.tid(), nt = x.nt();
     uint64_t *pk = sort_scratch();
+    const int *fin = fin_cur();
     for (int p = tid; p < n; p += nt) {
-      const int a = w.fin[p];
+      const int a = fin[p];
       pk[p] = (key48(ord_f32(b.score[a]), mk_info(b.ch[a], 0, 0)) << 16) | (uint64_t)a;
     }
     x.sync();
@@ -841,6 +849,10 @@ struct Decoder {
       w.vars[VAR_LMQ] = 0;
       w.apos[0] = 0; w.fin[0] = 0;
     }
+    // (behind the scorer hook an utterance is parked -- fin[] saved -- at any frame, long before a frame has had a reason to write it:
+    //  both copies start as the identity instead of whatever the memory held)
+    if (lm_cb)
+      for (int i = x.tid(); i < 2 * d.K; i += x.nt()) w.fin[i] = i < d.K ? i : i - d.K;
     st_n = 1; st_pool = 1; st_wlog = 32;  // first select looks at the whole key range
     st_maxkey = ord_f32(0.f);
     st_minkey = ord_f32(0.f);
@@ -866,12 +878,14 @@ struct Decoder {
     Beam &b = w.cur;
     int *ia[9] = {b.node, b.par, b.ch, b.dep, b.lcp, b.via, b.viaanc, b.viach, b.up};
     float *fa[4] = {b.bprev, b.nbprev, b.score, b.lpc};
+    if (lm_cb)  // (the part of the order array the parked beam does not reach: defined, as after init())
+      for (int i = st_n + tid; i < K; i += nt) fin_cur()[i] = i;
     for (int i = tid; i < st_n; i += nt) {
       for (int a = 0; a < 9; ++a) ia[a][i] = ss.arrays[a * K + i];
       for (int a = 0; a < 4; ++a) fa[a][i] = ctcmath::bits_to_f32((uint32_t)ss.arrays[(9 + a) * K + i]);
       const int f = ss.arrays[13 * K + i];  // the last frame of every chunk records the order std::nth_element left:
-      w.fin[i] = f;                          // array position i holds beam entry f
-      w.apos[f] = i;
+      fin_cur()[i] = f;                      // array position i holds beam entry f
+      if (!lm_cb || (unsigned)f < (unsigned)K) w.apos[f] = i;  // (hook: a state parked before any frame wrote the order -- see init())
       if (LM) {
         int *la[kBeamArraysLm] = {b.lmst, b.lmcl, b.acc_lo, b.acc_hi, b.dn, b.dmlo, b.dmhi, b.dfc, b.spc_lo, b.spc_hi, b.spst, b.spcl};
         for (int a = 0; a < kBeamArraysLm; ++a) la[a][i] = ss.arrays[(kStateArrays + a) * K + i];
@@ -918,7 +932,7 @@ struct Decoder {
     for (int i = tid; i < st_n; i += nt) {
       for (int a = 0; a < 9; ++a) ss.arrays[a * K + i] = ia[a][i];
       for (int a = 0; a < 4; ++a) ss.arrays[(9 + a) * K + i] = (int)ctcmath::f32_to_bits(fa[a][i]);
-      ss.arrays[13 * K + i] = w.fin[i];
+      ss.arrays[13 * K + i] = fin_cur()[i];
       if (LM) {
         const int *la[kBeamArraysLm] = {b.lmst, b.lmcl, b.acc_lo, b.acc_hi, b.dn, b.dmlo, b.dmhi, b.dfc, b.spc_lo, b.spc_hi, b.spst, b.spcl};
         for (int a = 0; a < kBeamArraysLm; ++a) ss.arrays[(kStateArrays + a) * K + i] = la[a][i];
@@ -1465,9 +1479,9 @@ struct Decoder {
     }
     auto cut = [&](float lp, float prefix_score) { return LM && full_beam && lp + prefix_score < min_cutoff; };
     if (LM && CTC_RARE(x.uni(w.vars[VAR_DANGER]) != 0)) {
-      // (a frame that is abandoned because the callback scorer's cache missed has already overwritten the order the previous
-      //  frame left -- which only danger mode reads: the combination is refused rather than served wrong)
-      if (lm_cb) return ST_CB_DANGER;
+      // (behind the scorer hook a frame can be abandoned after it has written the next beam's order: that goes to the copy of the
+      //  other parity -- fin_nxt() --, so the order this frame reads is the one the last COMMITTED frame left.  Rounds 4-5 refused
+      //  the combination: ST_CB_DANGER)
       lm_sorted_order(b, n);
     }
 
@@ -2192,11 +2206,16 @@ struct Decoder {
     }
     // the order std::nth_element left the survivors in (identity when it was not called: then the flag is looked up here)
     if (CTC_RARE(last || exact || (N <= K && x.uni(w.vars[VAR_DANGER]) != 0))) {
+      int *fin = fin_nxt();  // (current once this frame commits)
       for (int q = tid; q < n_new; q += nt) {
         const int r = exact ? rk[q] : q;
-        w.fin[q] = r;
+        fin[q] = r;
         w.apos[r] = q;
       }
+    } else if (lm_cb) {  // (two copies: a frame that leaves the order alone carries it over)
+      const int *fc = fin_cur();
+      int *fn = fin_nxt();
+      for (int q = tid; q < d.K; q += nt) fn[q] = fc[q];
     }
     // un-register this step's candidates from the rank table -- only once every wave has finished emitting (the emit
     // loop above still looks characters up in it)
@@ -2280,7 +2299,7 @@ struct Decoder {
     if (SMALLV) { CTC_ASSUME(n >= 1 && n <= kClsK); CTC_ASSUME(d.K <= kClsK); }
     const int nres = n < d.K ? n : d.K;
     if (!had_steps)
-      for (int k = tid; k < nres; k += nt) w.fin[k] = k;
+      for (int k = tid; k < nres; k += nt) fin_cur()[k] = k;
     x.sync();
     // The two std::sorts (ctc_beam_search_decoder.cpp:188-190, decoder_utils.cpp:59) order by (score desc, character
     // asc).  Equal float32 scores are common in a beam (it spans a few hundred ulps), so the order libstdc++ leaves
@@ -2337,7 +2356,7 @@ struct Decoder {
         if (CTC_RARE(lm_cb) && x.uni(w.vars[VAR_LMMISS]) != 0) return ST_NEED_HOST;  // (nothing has been written to the results yet)
       }
       for (int p = tid; p < nres; p += nt) {
-        const int a = w.fin[p];
+        const int a = fin_cur()[p];
         pk[p] = (key48(ord_f32(LM ? ext[a] : sc[a]), mk_info(ch[a], 0, 0)) << 16) | (uint64_t)a;
       }
       x.sync();
@@ -2351,12 +2370,12 @@ struct Decoder {
         x.sync();
       }
       sort_like_std(pk, nres, before);
-      for (int p = tid; p < nres; p += nt) w.fin[p] = (int)(pk[p] & 0xFFFFu);
+      for (int p = tid; p < nres; p += nt) fin_cur()[p] = (int)(pk[p] & 0xFFFFu);
     }
     if (tid == 0 && n_results) *n_results = nres;
     x.sync();
     for (int p = tid; p < nres; p += nt) {
-      const int j = w.fin[p];
+      const int j = fin_cur()[p];
       out_score[p] = LM ? -approx[j] : -b.score[j];  // decoder_utils.cpp:68 (approx_ctc = score without a scorer)
       out_len[p] = b.dep[j];
     }
@@ -2366,7 +2385,7 @@ struct Decoder {
     // (kExpress): segment 0 is the tail above the node's express ancestor, segment i >= 1 the kExpress labels below
     // the i-th express ancestor; segment-major order keeps the walks of one wave equally long.
     int *row_of = w.pinr, *owner = w.e;
-    for (int p = tid; p < nres; p += nt) row_of[w.fin[p]] = p;
+    for (int p = tid; p < nres; p += nt) row_of[fin_cur()[p]] = p;
     for (int j = tid; j < nres; j += nt) {  // owner[j]: the nearest earlier entry that shares less with its own predecessor
       int o = j - 1;
       const int l = b.lcp[j];

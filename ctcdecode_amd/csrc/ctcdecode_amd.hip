@@ -1715,10 +1715,13 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
     else if (big) fn = far_level == 2 ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false, 0, true>)
                                  : (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 1, 0, true, 0, true> : (const void *)ctc_beam_decode_kernel<0, 1, 0, false, 0, true>);
     if (hooked) {
-      if (big) return fail(CTCD_EUNSUPPORTED, "a callback scorer with a beam this wide (its kernels exist for the layouts that keep the whole workspace in LDS)");
       if (d->profile) return fail(CTCD_EUNSUPPORTED, "the instrumented kernel builds do not include the scorer hook");
       fn = fixed ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, 3> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, 3>)
                  : (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 0, true, 0, 3> : (const void *)ctc_beam_decode_kernel<0, 0, 0, false, 0, 3>);
+      // wide beams (round 6: the reference's scorer pointer works for any beam, binding.cpp:122-140): the hook's builds of the three wide-beam layouts
+      if (big && far_level == 3) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 3, 0, true, 0, 3> : (const void *)ctc_beam_decode_kernel<0, 3, 0, false, 0, 3>;
+      else if (big) fn = far_level == 2 ? (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 2, 0, true, 0, 3> : (const void *)ctc_beam_decode_kernel<0, 2, 0, false, 0, 3>)
+                                   : (pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 1, 0, true, 0, 3> : (const void *)ctc_beam_decode_kernel<0, 1, 0, false, 0, 3>);
     }
     if (d->profile && d->tl_armed) {  // (shape conditions checked above)
       if (!fixed) return fail(CTCD_EUNSUPPORTED, "barrier timeline: beam <= 128, <= 32 labels");

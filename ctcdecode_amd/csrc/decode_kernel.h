@@ -1068,7 +1068,8 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(0, 1, 0, false, 1024, false, false, 9) X(0, 1, 0, true, 1024, false, false, 10) X(2, 1, 0, false, 1024, false, false, 11) \
   X(4, 0, 1, false, 1024, false, false, 3) X(5, 0, 1, false, 1024, false, false, 5) X(4, 0, 1, false, 1024, 2, false, 7) X(4, 0, 1, false, 1024, false, true, 9) \
   X(0, 0, 2, true, 1024, false, false, 0) \
-  X(3, 0, 1, false, 1024, false, false, 1) X(3, 0, 1, true, 1024, false, false, 2) X(0, 0, 1, false, 1024, 3, false, 8) X(0, 0, 1, true, 1024, 3, false, 9) X(0, 0, 0, false, 0, 3, false, 10) X(0, 0, 0, true, 0, 3, false, 4)
+  X(3, 0, 1, false, 1024, false, false, 1) X(3, 0, 1, true, 1024, false, false, 2) X(0, 0, 1, false, 1024, 3, false, 8) X(0, 0, 1, true, 1024, 3, false, 9) X(0, 0, 0, false, 0, 3, false, 10) X(0, 0, 0, true, 0, 3, false, 4) \
+  X(0, 1, 0, false, 0, 3, false, 0) X(0, 1, 0, true, 0, 3, false, 1) X(0, 2, 0, false, 0, 3, false, 2) X(0, 2, 0, true, 0, 3, false, 3) X(0, 3, 0, false, 0, 3, false, 11) X(0, 3, 0, true, 0, 3, false, 5)
 #endif
 
 }  // namespace ctcdk

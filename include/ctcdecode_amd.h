@@ -139,8 +139,8 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *w
  *   the callback give bit-identical output).  Accepted by ctcd_beam_decode_lm, ctcd_beam_decode_lm_host,
  *   ctcd_beam_decode_to_host, ctcd_beam_decode_compact (since round 5: the compact multi-GPU gather works with it) and
  *   ctcd_stream_create_lm / ctcd_stream_decode.
- *   Not supported with it (CTCD_EUNSUPPORTED): rows that hold +-inf or overflow float32 sums; beams whose workspace does not fit
- *   one workgroup's LDS (the wide-beam layouts: beyond roughly beam_width * (candidates + 2) = 20 000 slots).
+ *   Since round 6 without shape restrictions: rows that hold +-inf or overflow float32 sums, and beams of any width the decoder
+ *   takes (the wide-beam layouts), decode behind a callback as they do with the built-in tables.
  *   Decodes that share one callback scorer are serialised (its cache is one object) and the callback runs under that lock:
  *   a callback that itself decodes with the same scorer deadlocks.  A ctcd_stream_decode call that fails half-way (the
  *   callback reported an error) leaves the streams of that call unusable: destroy them.

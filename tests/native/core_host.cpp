@@ -350,7 +350,10 @@ extern "C" int ctccore_decode_lm_cb_f32(const float *probs, const int32_t *seq_l
   d.K = beam; d.V = V; d.Vc_max = V; d.use_rank_table = 0; d.lm = 1;
   Work w;
   size_t far_bytes = 0;
-  std::vector<char> mem(carve<0>(w, nullptr, nullptr, d, &far_bytes) + 64);
+  // CTC_HOST_BIG=1|2|3: the wide-beam layouts behind the hook as well (round 6: the hook's kernels exist for them)
+  const int flevel = getenv("CTC_HOST_BIG") ? getenv("CTC_HOST_BIG")[0] - '0' : 0;
+  std::vector<char> mem((flevel == 3 ? carve<3>(w, nullptr, nullptr, d, &far_bytes) : flevel == 2 ? carve<2>(w, nullptr, nullptr, d, &far_bytes)
+                         : flevel == 1 ? carve<1>(w, nullptr, nullptr, d, &far_bytes) : carve<0>(w, nullptr, nullptr, d, &far_bytes)) + 64);
   std::vector<char> far(far_bytes + 64);
   std::vector<ctclm::MissEntry> miss(65536);
   unsigned nmiss = 0;
@@ -368,14 +371,22 @@ extern "C" int ctccore_decode_lm_cb_f32(const float *probs, const int32_t *seq_l
       view.cb = 1; view.cb_miss = miss.data(); view.cb_count = &nmiss; view.cb_cap = (uint32_t)miss.size(); view.cb_ring = 0;
       nmiss = 0;
       const int done = hdr[SH_FRAMES];
-      carve<0>(w, mem.data(), far.data(), d, nullptr);
+      if (flevel == 3) carve<3>(w, mem.data(), far.data(), d, nullptr);
+      else if (flevel == 2) carve<2>(w, mem.data(), far.data(), d, nullptr);
+      else if (flevel == 1) carve<1>(w, mem.data(), far.data(), d, nullptr);
+      else carve<0>(w, mem.data(), far.data(), d, nullptr);
       HostX x;
       x.item_ = b;
+      x.far_ = flevel != 0;
       StreamState ss{hdr.data(), arrays.data(), 1};
       const OutRefs outs{out_tokens, out_timesteps, out_scores, out_lens, n_results, beam, T, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, 0u};
       const float *rows = in + ((size_t)b * T + done) * V, *raw = probs + ((size_t)b * T + done) * V;
       int st;
-      if (wordlm) st = decode_utterance<true, false, true, false, false, false, true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
+      if (flevel == 3) st = decode_utterance<true, false, true, true, true, true, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
+                                     (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss, &view, raw, log_input);
+      else if (flevel) st = decode_utterance<true, false, true, true, true, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
+                                     (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss, &view, raw, log_input);
+      else if (wordlm) st = decode_utterance<true, false, true, false, false, false, true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
                                      (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss, &view, raw, log_input);
       else st = decode_utterance<true, false, true, false, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len - done, pool.data(), pool_up.data(),
                                      (int)pool.size(), ctcmath::host_tables().w, &outs, b, &ss, &view, raw, log_input);

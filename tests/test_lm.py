@@ -376,6 +376,29 @@ def test_scorer_hook_random_sweep():
         ou.assert_same(b, a, "it %d %s" % (it, os.path.basename(arpa)))
 
 
+def test_scorer_hook_degenerate_rows():
+    """Round 6: rows with whole frames of -inf / overflowing sums behind the hook (rounds 4-5 refused them: ST_CB_DANGER).  In danger mode
+    a frame reads the order std::nth_element left the previous beam in; a frame abandoned at a cache miss has already written the NEXT
+    beam's order -- into the copy of the other parity (beam_core.h fin_cur / fin_nxt), so running it again reads what the last committed
+    frame left.  Callback path == built-in path of the same core, bit for bit; the built-in path against the oracle is
+    test_product_core_with_lm_degenerate_inputs."""
+    import degenerate_util as du
+
+    rng = np.random.default_rng(2026)
+    models = [("abcd_words.arpa", ["_", "a", "b", "c", "d", "'", " "]), ("chars.arpa", ["_", "a", "b", "c", "d", "'", "é", " "]), ("test.arpa", LABELS29)]
+    resumed = 0
+    for it in range(90):
+        arpa, labels = models[it % 3]
+        meta, lp = du.make_case(rng, V=len(labels), labels_space=labels.index(" "))
+        alpha, beta = float(rng.choice([0.0, 0.3, 1.0, 2.5])), float(rng.choice([-1.0, 0.0, 0.5, 1.5]))
+        path = os.path.join(DATA, arpa)
+        a = ou.decode_core_host_lm(lp, alpha, beta, path, labels, beam=meta["K"], cutoff_top_n=len(labels), blank_id=0, threads=1)
+        b = ou.decode_core_host_lm_cb(lp, alpha, beta, path, labels, beam=meta["K"], blank_id=0)
+        ou.assert_same(b, a, "case %d %s %s alpha=%g beta=%g" % (it, arpa, meta, alpha, beta))
+        resumed += b["resumptions"]
+    assert resumed > 100
+
+
 def test_scorer_hook_order_one_word_model():
     """a callback scorer of order 1 (windows of one word, no history) over a WORD model -- a prefix that ends in a
     partial non-word scores its "</s>" window from the callback's empty history, not from the built-in automaton's state 0
