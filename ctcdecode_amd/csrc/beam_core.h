@@ -176,6 +176,7 @@ enum {
   VAR_QSTAT = VAR_SPEC + 9,   // entries of the launch's final beam with descendants in it (the shape statistic the host reads: chains or bushes)
   VAR_LMMISS = VAR_SPEC + 8,  // host-side scorer hook: this frame asked for something the cache does not hold (sticky within a launch)
   VAR_LMQ = VAR_SPEC + 10,    // ... and how many pairs the utterance has queued since init() / load_state()
+  VAR_HOTN = VAR_SPEC + 4,    // wide-beam layouts (kHotPre; they have no speculative select: the slot is theirs): keys pre-listed by phase B
   VAR_COUNT = VAR_SPEC + 12
 };
 constexpr int kBins = 1024;     // histogram buckets of the select
@@ -205,7 +206,7 @@ constexpr int kExpress = 32;
 // peaky acoustic posteriors.
 enum Event { EV_FRAMES, EV_CANDIDATES, EV_EXACT, EV_INTERNAL, EV_PINNED, EV_LPC_UPDATE, EV_DEAD_PARENT, EV_REVIVE_CAND, EV_REVIVED, EV_WALK,
              EV_WALK_HOPS, EV_FAST_SELECT, EV_SINGLE_KEY, EV_BUCKET_KEYS, EV_SPEC_OK, EV_SPEC_UNDER, EV_SPEC_OVER, EV_SPEC_OTHER, EV_SPEC_HOT,
-             EV_SLOW_BELOW, EV_SLOW_CROWDED, EV_SLOW_SINGLE, EV_SLOW_ROUNDS, EV_TIE_FRAMES, EV_TIE_KEYS, EV_TIE_BIG, EV_WIDE_LIST, EV_COUNT };
+             EV_SLOW_BELOW, EV_SLOW_CROWDED, EV_SLOW_SINGLE, EV_SLOW_ROUNDS, EV_TIE_FRAMES, EV_TIE_KEYS, EV_TIE_BIG, EV_WIDE_LIST, EV_HOT_LIST, EV_COUNT };
 
 struct Work {
   // The beam is double-buffered: step t reads the copy of parity p and writes the other one.  cur / nxt are re-derived
@@ -522,6 +523,24 @@ struct Decoder {
   // (rehistogram()): same survivors either way, by construction.
   // (round 6: pruned candidate lists as well -- the row's largest log-probability is then simply its first candidate's)
   static constexpr bool kSpec = SMALLV && !LM && !LAZY && X::kSpecSelect;
+  // Wide beams without a scorer (round 6; measured and left off: CTC_EXP_HOT_PRELIST): phase B pre-lists the candidates at or above a
+  // threshold predicted from the previous frame (the speculative select's anchor -- previous best score + this row's best label
+  // log-probability -- minus 1.5 x the last distance anchor -> K-th key) in the next beam's block; if the K-th key's bucket turns out to lie
+  // at or above that threshold, the bucket is listed and the keys above it are marked FROM THAT LIST (1 000-1 700 entries) instead of by the
+  // pass over all S slot keys (15 500 at beam 500).  The prediction holds in 88 % of the frames that stay on the select's fast path (66 % of
+  // all; host build) and the outputs are identical -- and the kernel is SLOWER: configs[2] per-GPU shape 39.9 -> 41.65 ms, beam 300 14.44 ->
+  // 15.07 (profiles/r06x_cfg2_prelist.txt).  Phase B is the critical, issue-bound phase of this kernel (its fourteen child waves: 8 k of a
+  // frame's 31 k clocks at beam 400), and 1 000-1 700 appends per frame -- returning atomics on ONE LDS word -- queue behind each other there;
+  // the wave-aggregated form costs ~12 instructions in nearly every pass of a 40-instruction loop (one candidate in nine is hot: every
+  // wave-pass has one).  The listing pass it saves (3.9 k clocks on sixteen waves) is cheaper than anything that touches phase B.
+#if defined(CTC_EXP_HOT_PRELIST)
+  static constexpr bool kHotPre = LAZY && !LM && !SMALLV && !HUGE;
+#else
+  static constexpr bool kHotPre = false;
+#endif
+  struct HotPre { uint32_t thr; int cap; uint32_t *key; int *slot; };
+  uint32_t st_gap = 0;  // distance anchor -> K-th key of the last frame that had more candidates than places (0: no prediction)
+  uint32_t hot_anchor = 0;
   // Round 6: phase A1 of frame t + 1 reads nothing but the NEW beam's depth / LCP arrays, and the emission of frame t keeps six
   // of the sixteen waves busy.  The emission therefore writes those two arrays first, a barrier follows, and eight of the idle
   // waves run phase A1 of the next frame while the role waves finish the emission (pool appends, probabilities, best key); the
@@ -1053,6 +1072,14 @@ struct Decoder {
     }
     return wd;
   }
+  // ... and, in the wide-beam layouts, its place in the pre-list when it reaches the predicted threshold (thr >= wd.lo)
+  CTC_HD void hist_add(const Window &wd, uint32_t key, const HotPre &hp, int slot) const {
+    hist_add(wd, key);
+    if (kHotPre && key >= hp.thr) {
+      const int p = x.atomic_add(&w.vars[VAR_HOTN], 1);
+      if (p < hp.cap) { hp.key[p] = key; hp.slot[p] = slot; }
+    }
+  }
   CTC_HD void hist_add(const Window &wd, uint32_t key) const {  // first-round histogram contribution of one candidate
     if (key >= wd.lo) {
       const uint32_t bk = (key - wd.lo) >> wd.shift;
@@ -1105,12 +1132,79 @@ struct Decoder {
   // of them (VAR_TAU), G = gsum + #bucket keys above tau, E = #keys equal to tau.  `direct` (first round only): the
   // listing pass also records, one bit per slot, every key ABOVE the bucket, and the ranking threads add the bucket's
   // own survivors, so the caller only has to expand the bitmap.  inb = #keys in the bucket (<= kListCap).
+  template <bool COMPACT = false>
+  CTC_HD void rank_bucket(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb) {
+    const int tid = x.tid(), nt = x.nt();
+    CTC_ASSUME(inb >= 1 && inb <= kListCap);
+    // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
+    x.template list_bucket<kTailZero, COMPACT>(S, w.skey, b32, bspan, direct, w.bitmap, w.list, w.lslot, &pv[P_LCOUNT]);
+    for (int q = tid; q < 4; q += nt) w.list[inb + q] = 0;  // pad to a multiple of four, below every real entry
+    x.sync();
+    x.mark(14);
+    // a long list (wide beams: up to kListCap keys share the bucket) is ranked by eight lanes per key, each comparing an
+    // eighth of the list; a short one by one lane per key
+    const bool wide_rank = !SMALLV && inb > 32 && nt >= 8 * kListCap;
+    // (fixed-layout class at 1024 threads: four lanes per key, each comparing a quarter of the list -- some twenty keys share
+    //  the bucket on ordinary input, and the ranking is a single-wave stage: five rounds of loads and compares become two)
+    const bool quad_rank = SMALLV && !COMPACT && x.nt_is(1024);
+    const int psh = wide_rank ? 3 : quad_rank ? 2 : 0;
+    for (int q0 = tid; q0 < (wide_rank ? 8 * kListCap : inb << psh); q0 += nt) {
+      const int q = q0 >> psh, part = q0 & ((1 << psh) - 1), stride = 4 << psh;
+      const uint32_t mine = q < inb ? w.list[q] : 0u;
+      int g = 0, e = 0;
+      for (int r = 4 * part; r < inb; r += stride) {
+        const uint32_t o0 = w.list[r], o1 = w.list[r + 1], o2 = w.list[r + 2], o3 = w.list[r + 3];
+        g += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
+        e += (o0 == mine) + (o1 == mine) + (o2 == mine) + (o3 == mine);
+      }
+      if (wide_rank) {
+        g = x.sum8(g); e = x.sum8(e);
+        if (part != 0 || q >= inb) continue;
+      } else if (quad_rank) {
+        g = x.sum4(g); e = x.sum4(e);
+        if (part != 0) continue;
+      }
+      if (g < want && want <= g + e) {  // every holder of the K-th key writes the same values
+        w.vars[VAR_TAU] = (int)(b32 + (mine - 1u)); w.vars[VAR_G] = gsum + g; w.vars[VAR_E] = e;
+      }
+      if (direct && g < want) {  // key >= tau: survives (unless equal scores straddle the boundary -- caller's business)
+        const int sl = w.lslot[q];
+        x.atomic_or(&w.bitmap[sl >> 5], 1u << (sl & 31));
+      }
+    }
+    x.sync();
+  }
+
+  // The same with the lists' places as arguments (the wide-beam layouts' pre-list, kHotPre; the wide-list experiment) -- a function of
+  // its own: the north-star kernels keep rank_bucket's text, and with it their machine code (tools/kernel_hashes.sh; a reordered
+  // condition in select_kth and two pointer arguments here had cost configs[1] 2.8 %).
   // lst / lsl: where the bucket's keys and slots are listed -- w.list / w.lslot (kListCap entries), or, for a crowded bucket of a beam
   // without a scorer, the block of the NEXT beam (wide_list_cap() entries: nothing lives there between two emissions).
   template <bool COMPACT = false>
-  CTC_HD void rank_bucket(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb, uint32_t *lst, int *lsl) {
+  CTC_HD void rank_bucket_ext(int S, int *pv, uint32_t b32, uint32_t bspan, bool direct, int want, int gsum, int inb, uint32_t *lst, int *lsl,
+                          const HotPre *hot, int hot_n) {
     const int tid = x.tid(), nt = x.nt();
     CTC_ASSUME(inb >= 1);
+    if (kHotPre && hot != nullptr) {
+      // the same listing from phase B's pre-list (every key >= hot->thr <= b32 is in it): the bitmap starts empty, a key above the
+      // bucket sets its slot's bit, a member of the bucket takes a place in the list
+      const int nw = 2 * ((S + 63) / 64);
+      for (int i = tid; i < nw; i += nt) w.bitmap[i] = 0u;
+      x.sync();
+      for (int q = tid; q < hot_n; q += nt) {
+        const uint32_t k = hot->key[q], dk = k - b32;
+        const int sl = hot->slot[q];
+        if (k >= b32) {
+          if (dk <= bspan) {
+            const int p = x.atomic_add(&pv[P_LCOUNT], 1);
+            lst[p] = dk + 1u;
+            lsl[p] = sl;
+          } else {
+            x.atomic_or(&w.bitmap[sl >> 5], 1u << (sl & 31));
+          }
+        }
+      }
+    } else
     // one pass over the slots: bucket members are listed (key offset + slot); bit s of the bitmap = key above the bucket
     x.template list_bucket<kTailZero, COMPACT>(S, w.skey, b32, bspan, direct, w.bitmap, lst, lsl, &pv[P_LCOUNT]);
     for (int q = tid; q < 4; q += nt) lst[inb + q] = 0;  // pad to a multiple of four, below every real entry
@@ -1153,9 +1247,12 @@ struct Decoder {
   // entries of the wide bucket list (keys, then slots, in the next beam's block: w.beam_blk bytes from w.nxt.node)
   CTC_HD int wide_list_cap() const {
     const long long c = (long long)(w.beam_blk / 8) - 8;
-    return c >= 1024 ? 1024 : c <= kListCap ? 0 : (int)(c & ~3LL);
+#ifndef CTC_HOT_CAP
+#define CTC_HOT_CAP 3072
+#endif
+    return c >= CTC_HOT_CAP ? CTC_HOT_CAP : c <= kListCap ? 0 : (int)(c & ~3LL);
   }
-  CTC_HD bool select_kth(int S, int K, int *pv, const Window &wd) {
+  CTC_HD bool select_kth(int S, int K, int *pv, const Window &wd, const HotPre &hp) {
     const int tid = x.tid(), nt = x.nt();
     // -> [0] bucket b* holding the need-th largest key (-1: below the window), [1] #keys in buckets above b*,
     //    [2] #keys in the window, [3] #keys in b*.  Two-level: sums of 16 buckets locate the group, then the bucket.
@@ -1167,6 +1264,7 @@ struct Decoder {
     x.mark(13);
     // The usual outcome: the first histogram isolates a bucket with a handful of keys, several values wide.  Everything
     // about it fits 32-bit arithmetic (the window's top is the previous best key, below 2^32).
+#if defined(CTC_EXP_WIDE_LIST)
     // Round 6, measured and left off (CTC_EXP_WIDE_LIST): a CROWDED bucket (more than kListCap keys: at beam 500 one frame in three --
     // float32 scores near 10^3 are 10^-4 apart, and the children of equal prefixes inherit equal scores; 256 keys on average) listed
     // once, as the usual bucket is, into a list that borrows the next beam's block, and ranked there by all sixteen waves, so that the
@@ -1175,11 +1273,7 @@ struct Decoder {
     // (profiles/r06r / r06t_phase_beam500*.json): listing 256 members costs the gather pass +0.9 us per frame, while the path it
     // replaces -- a second histogram over the S slots, which ends on a single key value, and one marking pass -- was worth 0.1 us.
     // The select's share of this kernel (25 %) is the two passes over 15 500 slot keys every frame makes, not the crowded frames.
-#if defined(CTC_EXP_WIDE_LIST)
     const int wcap = (!SMALLV && !LM) ? wide_list_cap() : 0;
-#else
-    constexpr int wcap = 0;
-#endif
     const bool bucket_ok = fb[0] >= 0 && (wd.shift != 0 || fb[0] == kBins - 1);
     const bool wide = bucket_ok && fb[3] > kListCap && fb[3] <= wcap;
     if (CTC_USUAL(bucket_ok && (fb[3] <= kListCap || wide))) {
@@ -1187,9 +1281,32 @@ struct Decoder {
       const uint32_t bspan = fb[0] == kBins - 1 ? 0xFFFFFFFFu - b32 : (1u << wd.shift) - 1u;
       if (tid == 0) { x.count(EV_FAST_SELECT, 1); x.count(EV_BUCKET_KEYS, fb[3]); if (fb[3] == 1) x.count(EV_SINGLE_KEY, 1); if (wide) x.count(EV_WIDE_LIST, 1); }
       uint32_t *wl = reinterpret_cast<uint32_t *>(w.nxt.node);
-      rank_bucket(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3], wide ? wl : w.list, wide ? reinterpret_cast<int *>(wl + wcap + 4) : w.lslot);
+      // (the pre-list holds every key at or above its threshold unless it overflowed: usable when the bucket starts at or above it)
+      const int hot_n = kHotPre ? x.uni(w.vars[VAR_HOTN]) : 0;
+      const bool from_hot = kHotPre && !wide && hp.thr != 0xFFFFFFFFu && hp.thr <= b32 && hot_n <= hp.cap;
+      if (tid == 0 && from_hot) x.count(EV_HOT_LIST, 1);
+      rank_bucket_ext(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3], wide ? wl : w.list, wide ? reinterpret_cast<int *>(wl + wcap + 4) : w.lslot,
+                  from_hot ? &hp : nullptr, hot_n);
       return true;
     }
+#else
+    (void)hp;
+    if (CTC_USUAL(fb[0] >= 0 && fb[3] <= kListCap && (wd.shift != 0 || fb[0] == kBins - 1))) {
+      const uint32_t b32 = wd.lo + ((uint32_t)fb[0] << wd.shift);
+      const uint32_t bspan = fb[0] == kBins - 1 ? 0xFFFFFFFFu - b32 : (1u << wd.shift) - 1u;
+      if (tid == 0) { x.count(EV_FAST_SELECT, 1); x.count(EV_BUCKET_KEYS, fb[3]); if (fb[3] == 1) x.count(EV_SINGLE_KEY, 1); }
+      if (kHotPre) {
+        // (the pre-list holds every key at or above its threshold unless it overflowed: usable when the bucket starts at or above it)
+        const int hot_n = x.uni(w.vars[VAR_HOTN]);
+        const bool from_hot = hp.thr != 0xFFFFFFFFu && hp.thr <= b32 && hot_n <= hp.cap;
+        if (tid == 0 && from_hot) x.count(EV_HOT_LIST, 1);
+        rank_bucket_ext(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3], w.list, w.lslot, from_hot ? &hp : nullptr, hot_n);
+      } else {
+        rank_bucket(S, pv, b32, bspan, true, K - fb[1], fb[1], fb[3]);
+      }
+      return true;
+    }
+#endif
     // Rare: the K-th key lies below the window, the bucket is crowded, or it is a single key value.
     uint64_t lo = wd.lo, hi = (uint64_t)1 << 32;  // current key range [lo, hi)
     int shift = wd.shift;
@@ -1217,7 +1334,7 @@ struct Decoder {
         else { if (tid == 0) x.count(EV_SLOW_CROWDED, 1); gbase += above; need -= above; lo = blo; hi = bhi; }  // too crowded: histogram the bucket itself
       }
       if (!again) {  // exact rank inside the bucket, on offsets from its base
-        rank_bucket<true>(S, pv, (uint32_t)blo, (uint32_t)(bhi - blo - 1), first, need - above, gbase + above, inb, w.list, w.lslot);
+        rank_bucket<true>(S, pv, (uint32_t)blo, (uint32_t)(bhi - blo - 1), first, need - above, gbase + above, inb);
         return first;
       }
       // another histogram round over [lo, hi)
@@ -1466,6 +1583,13 @@ struct Decoder {
     int *surv = w.surv, *rk = w.surv + K, *ord = w.surv + 2 * K;
     Window wd{1u, 0};
     if (!kSpec) wd = first_window();
+    HotPre hp{0xFFFFFFFFu, 0, nullptr, nullptr};
+    if (kHotPre) {
+      hp.cap = wide_list_cap();
+      hp.key = reinterpret_cast<uint32_t *>(w.nxt.node);
+      hp.slot = reinterpret_cast<int *>(hp.key + hp.cap + 4);
+      if (x.tid() == 0) w.vars[VAR_HOTN] = 0;  // (phase B is two barriers away)
+    }
     // LM tier: candidates whose (prefix score + label log-prob) falls below the worst prefix's score plus the blank's
     // log-prob (minus beta) are skipped once the beam is full (ctc_beam_search_decoder.cpp:74-82,93-95).  The prefixes
     // are visited best first there and the loop breaks at the first miss; scores only fall from there on and float
@@ -1576,6 +1700,19 @@ struct Decoder {
     x.mark(0);
     const int npin_total = pv[P_NPIN];  // final since the barrier above; requested here so that phase C does not wait for it
     const uint32_t thr = kSpec ? (uint32_t)x.uni(w.vars[VAR_SPEC + SP_THR]) : 0xFFFFFFFFu;  // (written between the barriers of phase A: spec_predict)
+    if (kHotPre) {
+      // the pre-list's threshold: the speculative select's anchor -- the previous best score plus this row's best label log-probability,
+      // which takes the row's own swing out of the distance -- minus 1.25 x the distance anchor -> K-th key the last frame showed
+      hot_anchor = ord_f32(unord_f32(st_maxkey) + ctcmath::bits_to_f32((uint32_t)x.uni(w.vars[VAR_ROWMAX])));
+      if (st_gap != 0 && hp.cap > 0 && small_vocab && st_wlog < 32) {
+#ifndef CTC_HOT_MARGIN_SHIFT
+#define CTC_HOT_MARGIN_SHIFT 1
+#endif
+        const uint64_t reach = (uint64_t)st_gap + (st_gap >> CTC_HOT_MARGIN_SHIFT) + 2;
+        const uint32_t t = (uint64_t)hot_anchor > reach ? (uint32_t)(hot_anchor - reach) : 1u;
+        hp.thr = t < wd.lo ? wd.lo : t;
+      }
+    }
 
     // ---- B: score every candidate, lay it out in DFS (Euler-tour) slot order and count it into the select histogram.
     // B1 (beam entries themselves + revived children) and B2 (brand-new children) are independent: with enough
@@ -1656,7 +1793,7 @@ struct Decoder {
         if (kSpec) {
           x.hot_append(k0 >= thr, k0, s0, w.list, w.lslot, &w.vars[VAR_G]);  // (a revived node: rare)
           x.hot_append_wave(k1 >= thr, k1, s0 + 1, w.list, w.lslot, &w.vars[VAR_G]);
-        } else if (small_vocab) { hist_add(wd, k0); hist_add(wd, k1); }
+        } else if (small_vocab) { hist_add(wd, k0, hp, s0); hist_add(wd, k1, hp, s0 + 1); }
         if (LM && upd_node >= 0) set_node_time(upd_node, c, in.t, upd_lp);
         if (LM && CTC_RARE(upd_xn >= 0)) set_node_time(upd_xn, upd_xc, in.t, upd_xlp);
       }
@@ -1772,7 +1909,7 @@ struct Decoder {
             }
             const bool hotk = kSpec && k >= thr;
             const auto tk = x.hot_issue(hotk, &w.vars[VAR_G]);
-            if (!kSpec && !(kLmOverlap && deferred)) hist_add(wd, k);
+            if (!kSpec && !(kLmOverlap && deferred)) hist_add(wd, k, hp, s);
             i += ng; ci += (uint32_t)ng;
             act = ci < ci_end;
             if (act) cur = fetch(i);
@@ -1803,7 +1940,7 @@ struct Decoder {
           w.skey[s] = k;
           if (!LAZY) w.sinfo[s] = exists ? kHoleInfo : mk_info(c, T_CHILD, i);
           if (kSpec) x.hot_append(k >= thr, k, s, w.list, w.lslot, &w.vars[VAR_G]);
-          else if (small_vocab) hist_add(wd, k);
+          else if (small_vocab) hist_add(wd, k, hp, s);
         }
       }
       if (LM) x.wave_add(&pv[P_NCAND], ncand);
@@ -1865,7 +2002,7 @@ struct Decoder {
       x.count(spec_done ? EV_SPEC_OK : hot < K ? EV_SPEC_UNDER : hot > kHotCap ? EV_SPEC_OVER : EV_SPEC_OTHER, 1);
     }
     if (CTC_USUAL(N > K) && !spec_done) {  // ctc_beam_search_decoder.cpp:150
-      have_bitmap = select_kth(S, K, pv, wd);
+      have_bitmap = select_kth(S, K, pv, wd, hp);
       int tv[4];
       x.uni4(&w.vars[VAR_TAU], tv);
       tau = (uint32_t)tv[0];
@@ -2224,7 +2361,7 @@ struct Decoder {
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
     }
     if (stage && tid < d.V) w.clpbuf[((in.t + 1) & 1) * d.Vc_max + tid] = stage_val;
-    if (kSpec && stage) x.row_max_store(&w.vars[VAR_ROWMAX], stage_val, d.V);
+    if ((kSpec || kHotPre) && stage) x.row_max_store(&w.vars[VAR_ROWMAX], stage_val, d.V);
     x.mark(7);
     x.sync_full();  // pool writes of this step (global memory) are visible to every wave from here on
     x.mark(9);
@@ -2244,10 +2381,12 @@ struct Decoder {
       // anchor (the previous best key) to this step's K-th key, rounded up to a power of two.
       if (!kSpec) {  // (speculative select: one thread keeps the window and the prediction in LDS -- spec_learn / spec_predict)
         int wl = 32;
+        st_gap = 0;
         if (N > K) {
           const uint32_t gap = st_maxkey > tau ? st_maxkey - tau : 0;
           wl = (gap ? 32 - __builtin_clz(gap) : 0) + 1;  // = ceil(log2(gap + 1)) + 1
           wl = wl < 10 ? 10 : (wl > 32 ? 32 : wl);
+          st_gap = kHotPre ? (hot_anchor > tau ? hot_anchor - tau : 0u) : gap;
         }
         st_wlog = wl;
         st_maxkey = (uint32_t)x.uni(pv[P_NMAXKEY]);
@@ -2568,7 +2707,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
   }
   if (IDENT && prefetch && len > 0) {  // frame 0 goes straight to LDS; from then on step() stages frame t+1
     if (tid < d.V) { w.clpbuf[(t0 & 1) * d.Vc_max + tid] = pre_lp; dec.note_lp(pre_lp); }  // (the launch's first row: checked here)
-    if (Dec0::kSpec) x.row_max_store(&w.vars[VAR_ROWMAX], pre_lp, d.V);
+    if (Dec0::kSpec || Dec0::kHotPre) x.row_max_store(&w.vars[VAR_ROWMAX], pre_lp, d.V);
     x.sync();
   }
   for (int t = 0; t < len; ++t) {
@@ -2607,7 +2746,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
           if (t + 1 < len && Dec::lp_bad(rows[(size_t)(t + 1) * d.V + r])) { next_cnt = tid + 1; next_val = -__builtin_huge_valf(); }
         }
         x.sync();
-        if (Dec0::kSpec) {  // (rows that are not prefetched -- workgroups narrower than the vocabulary: the host build of the tests)
+        if (Dec0::kSpec || Dec0::kHotPre) {  // (rows that are not prefetched -- workgroups narrower than the vocabulary: the host build of the tests)
           if (tid == 0) {
             float mx = w.clp[0];
             for (int r = 1; r < d.V; ++r) mx = w.clp[r] > mx ? w.clp[r] : mx;
@@ -2624,7 +2763,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
           w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid;
           if (t == 0) dec.note_lp(pre_lp);
           // (speculative select: the anchor of this frame's prediction -- the list is in descending order, decoder_utils.cpp:23-24)
-          if (Dec0::kSpec && tid == 0) w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(pre_lp);
+          if ((Dec0::kSpec || Dec0::kHotPre) && tid == 0) w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(pre_lp);
         }
         if (t + 1 < len) {
           pre_cnt = pr->cnt[t + 1];
@@ -2641,7 +2780,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
           w.clp[r] = v;
           w.rank_of[c] = (int16_t)r;
           if (t == 0) dec.note_lp(v);
-          if (Dec0::kSpec && r == 0) w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(v);
+          if ((Dec0::kSpec || Dec0::kHotPre) && r == 0) w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(v);
         }
         if (t + 1 < len) {
           const int cn = x.uni(pr->cnt[t + 1]);

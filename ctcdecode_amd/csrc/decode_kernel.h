@@ -1041,6 +1041,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
 }
 
 // Every instantiation the library launches: X(PROF, BIG, LAYOUT, PRUNED, NT, LM, OCC2, translation-unit group).
+// (Groups 0-3 hold the headline families; new instantiations go elsewhere so that those translation units stay as they are.)
 // decode_kernels.hip instantiates the ones of its group (-DCTC_KERNEL_GROUP=g); ctcdecode_amd.hip declares them all extern.
 #define CTC_KERNEL_GROUPS 12
 #if defined(CTC_QUICK_BUILD) && CTC_QUICK_BUILD == 2  // experiment builds of the LM tier: its north-star class kernel and the timeline twin
@@ -1069,7 +1070,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(4, 0, 1, false, 1024, false, false, 3) X(5, 0, 1, false, 1024, false, false, 5) X(4, 0, 1, false, 1024, 2, false, 7) X(4, 0, 1, false, 1024, false, true, 9) \
   X(0, 0, 2, true, 1024, false, false, 0) \
   X(3, 0, 1, false, 1024, false, false, 1) X(3, 0, 1, true, 1024, false, false, 2) X(0, 0, 1, false, 1024, 3, false, 8) X(0, 0, 1, true, 1024, 3, false, 9) X(0, 0, 0, false, 0, 3, false, 10) X(0, 0, 0, true, 0, 3, false, 4) \
-  X(0, 1, 0, false, 0, 3, false, 0) X(0, 1, 0, true, 0, 3, false, 1) X(0, 2, 0, false, 0, 3, false, 2) X(0, 2, 0, true, 0, 3, false, 3) X(0, 3, 0, false, 0, 3, false, 11) X(0, 3, 0, true, 0, 3, false, 5)
+  X(0, 1, 0, false, 0, 3, false, 6) X(0, 1, 0, true, 0, 3, false, 7) X(0, 2, 0, false, 0, 3, false, 8) X(0, 2, 0, true, 0, 3, false, 9) X(0, 3, 0, false, 0, 3, false, 11) X(0, 3, 0, true, 0, 3, false, 5)
 #endif
 
 }  // namespace ctcdk

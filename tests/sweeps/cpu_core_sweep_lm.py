@@ -1,4 +1,7 @@
-"""CPU sweep of the LM tier: host build of the product core against the restated oracle.  python tests/sweeps/cpu_core_sweep_lm.py <seed> <seconds>"""
+"""CPU sweep of the LM tier: host build of the product core against the restated oracle.
+    python tests/sweeps/cpu_core_sweep_lm.py <seed> <seconds> [--degenerate] [--hook]
+--hook: the same core behind the host-side scorer hook (a callback asking the built-in tables; unpruned rows) must equal the built-in path,
+degenerate rows included (round 6); CTC_HOST_BIG=1|2|3 runs the hook on the wide-beam layouts."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -28,10 +31,17 @@ while time.time() - t0 < budget:
     kw = dict(seq_lens=sl, beam=K, cutoff_top_n=top_n, blank_id=0)
     path = os.path.join(DATA, arpa)
     try:
+        if "--hook" in sys.argv:
+            kw["cutoff_top_n"] = V
+            a = ou.decode_core_host_lm(lp, alpha, beta, path, labels, threads=1, **kw)
+            b = ou.decode_core_host_lm_cb(lp, alpha, beta, path, labels, seq_lens=sl, beam=K, blank_id=0)
+            ou.assert_same(b, a, "x")
+            n += 1
+            continue
         sc = ou.Scorer(alpha, beta, path, labels, "restated")
         ou.assert_same(ou.decode_core_host_lm(lp, alpha, beta, path, labels, **kw), ou.decode(lp, scorer=sc, **kw), "x")
     except AssertionError:
         bad += 1
         print("MISMATCH", dict(arpa=arpa, K=K, T=T, alpha=alpha, beta=beta, quant=quant, seed=seed, top_n=top_n, sl=None if sl is None else sl.tolist()), flush=True)
     n += 1
-print("done: %d LM configurations, %d mismatches" % (n, bad))
+print("done: %d LM configurations%s%s, %d mismatches" % (n, " behind the scorer hook" if "--hook" in sys.argv else "", " (degenerate rows)" if "--degenerate" in sys.argv else "", bad))

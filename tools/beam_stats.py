@@ -20,7 +20,7 @@ NAMES = ["frames", "candidates", "exact replays", "entries with in-beam descenda
          "pool walks", "hops of those walks", "selects on the fast path", "... whose bucket holds a single key", "keys in the K-th key's bucket",
          "speculative select: settled the frame", "... too few hot keys", "... too many hot keys", "... handed back (ties, last frame, danger mode)", "hot keys",
          "histogram select: K-th key below the window", "... crowded bucket (more than 128 keys), another round", "... ended on a single key value", "... rounds of the slow path",
-         "frames with several candidates on the K-th score", "... such candidates", "... more than 128 of them", "selects on the fast path whose crowded bucket was ranked from the wide list"]
+         "frames with several candidates on the K-th score", "... such candidates", "... more than 128 of them", "selects on the fast path whose crowded bucket was ranked from the wide list", "selects on the fast path listed from phase B's pre-list"]
 
 
 def main():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One launch each of the kernels bench.py's headline does not touch, for rocprofv3 (kernel stats / FETCH_SIZE / WRITE_SIZE):
-the LM instantiation of the decode kernel (configs[4] per-GPU shape, tests/data/test.arpa), log_softmax_rows_kernel (raw-logit
-input at configs[3]'s B=64, T=500, V=10000), expand_compact_kernel (one 256-utterance configs[1] batch), the two-workgroups-per-CU
+the LM instantiation of the decode kernel (configs[4] per-GPU shape, tests/data/test.arpa), the raw-logit kernels at configs[3]'s B=64, T=500,
+V=10000 (prune_logits_wg_kernel, log_softmax_rows_wg_kernel, and the one-wave log_softmax_rows_kernel + separate prune they replace), expand_compact_kernel (one 256-utterance configs[1] batch), the two-workgroups-per-CU
 build (512 utterances), and -- as the calibration of the HBM byte counters MI355X_MICROARCH.md asks for -- a float4 copy of
 exactly 1 GiB (torch's vectorised copy kernel).  Prints one JSON line with HIP-event / wall timings.
     python tools/profile_extras.py [--only lm,softmax,expand,occ2,copy]"""
@@ -50,8 +50,18 @@ def main():
     if "softmax" in want:
         x = torch.randn((64, 500, 10000), generator=g).to(dev)
         dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(10000)], cutoff_top_n=40, cutoff_prob=0.99, beam_width=100, logits_input=True, device=dev)
+        dec.set_timing(True)
         ms = timed(lambda: dec.decode_device(x, None))
-        out["logits_configs3_shape"] = {"wall_ms": round(ms, 3), "softmax_bytes_in_plus_out": 2 * x.numel() * 4}
+        # (round 6: in front of a prune the logits go through ONE kernel, prune_logits_wg_kernel; the stand-alone normalisation --
+        #  log_softmax_rows_wg_kernel -- and the two-pass form it replaces are launched as well so that all of them show up in the trace)
+        out["logits_configs3_shape"] = {"wall_ms": round(ms, 3), "fused_prune_kernel_ms": round(dec.last_prune_ms(), 3), "logits_bytes_in": x.numel() * 4}
+        y = dec.log_softmax(x)
+        ms = timed(lambda: dec.log_softmax(x))
+        out["log_softmax_configs3_rows"] = {"wall_ms_incl_output_alloc": round(ms, 3), "softmax_bytes_in_plus_out": 2 * x.numel() * 4}
+        dec.set_fused_logits(False)
+        ms = timed(lambda: dec.decode_device(x, None))
+        out["logits_configs3_shape_two_pass_one_wave_kernels"] = {"wall_ms": round(ms, 3), "separate_prune_kernel_ms": round(dec.last_prune_ms(), 3)}
+        del y
     if "expand" in want:
         lp = torch.randn((256, 1000, 29), generator=g).log_softmax(-1).to(dev)
         dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(29)], cutoff_top_n=29, beam_width=100, log_probs_input=True, device=dev)

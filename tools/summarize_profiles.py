@@ -42,7 +42,7 @@ def main():
     head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
     stats_md(os.path.join(src, "prof", "trace_kernel_stats.csv"), dst + "_kernel_stats", "`python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-pmc` (configs[1]: B=256, T=1000, V=29, beam 100); tree " + head)
     stats_md(os.path.join(src, "prof_cfg", "trace_kernel_stats.csv"), dst + "_other_configs_kernel_stats", "`python tools/bench_configs.py --only 234 --reps 1` (configs[2] per-GPU shape: beam 500, T 2000; configs[3]: V=10000 pruned; configs[4] shape without LM)")
-    stats_md(os.path.join(src, "prof_extras", "trace_kernel_stats.csv"), dst + "_extras_kernel_stats", "`python tools/profile_extras.py`: LM instantiation (configs[4] per-GPU shape, test.arpa), two-workgroups-per-CU build (512 utterances), log_softmax_rows_kernel (B=64, T=500, V=10000 logits), expand_compact_kernel (256 x 100 x 1000), 1 GiB device copy (counter calibration)")
+    stats_md(os.path.join(src, "prof_extras", "trace_kernel_stats.csv"), dst + "_extras_kernel_stats", "`python tools/profile_extras.py`: LM instantiation (configs[4] per-GPU shape, test.arpa), two-workgroups-per-CU build (512 utterances), the raw-logit kernels at B=64, T=500, V=10000 (prune_logits_wg_kernel, log_softmax_rows_wg_kernel, the one-wave pair they replace), expand_compact_kernel (256 x 100 x 1000), 1 GiB device copy (counter calibration)")
     pmc = {"unit": "KiB per launch as rocprofv3 reports FETCH_SIZE / WRITE_SIZE (separate --pmc passes)", "kernels": {}}
     cal = {}
     for group, sub in (("bench", "pmc_%s"), ("other_configs", "pmc_cfg_%s"), ("extras", "pmc_extras_%s")):
