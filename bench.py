@@ -302,7 +302,7 @@ def synth_transcript_rows(torch, B, T, labels, words, seed, boost=7.0):
     return lg.log_softmax(-1)
 
 
-def time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, B=128, T=1500, K=100, alpha=0.5, beta=1.0, transcripts=False):
+def time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, B=128, T=1500, K=100, alpha=0.5, beta=1.0, transcripts=False, threads=1):
     """what the host-side scorer hook costs at the configs[4] per-GPU shape.  The built-in tables of `arpa`
     sit behind the hook as a NATIVE callback (ctcd_scorer_cond_log10 has the callback's signature: no Python in the loop), so
     results and cache contents are the built-in scorer's and the difference in time is the hook's: cold (fresh scorer: every
@@ -335,6 +335,9 @@ def time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, B=128, T=1500, K=1
             want.append(r)
         out["built-in tables"] = {"call_ms": round(dt * 1e3, 3), "kernel_ms": round(ref.last_kernel_ms(), 3)}
         sc = ctcdecode_amd.CallbackScorer.from_c(fn_addr, inner.value, arpa_unigrams(arpa), order, labels, alpha=alpha, beta=beta, device=dev)
+        if threads > 1:  # (the built-in tables are read-only: the callback may be asked from several threads at once)
+            sc.set_callback_threads(threads)
+            out["callback_threads"] = threads
         dec = ctcdecode_amd.CTCBeamDecoder(labels, scorer=sc, cutoff_top_n=V, beam_width=K, log_probs_input=True, device=dev)
         calls0, secs0 = 0, 0.0
         for name, lp, w in (("cold (fresh scorer)", lps[0], want[0]), ("second batch of other utterances (lukewarm)", lps[1], want[1]), ("first batch again (warm)", lps[0], want[0])):
@@ -604,6 +607,8 @@ def other_configs(torch, ctcdecode_amd, dev, traffic_consts=None):
             try:
                 out["scorer hook, transcript-like rows (generated 50k-word model behind a native callback)"] = time_scorer_hook(
                     torch, ctcdecode_amd, dev, big, ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)], transcripts=True)
+                out["scorer hook, the same with eight callback threads (ctcd_scorer_set_callback_threads: the built-in tables are read-only)"] = time_scorer_hook(
+                    torch, ctcdecode_amd, dev, big, ["_", "'", " "] + [chr(ord("a") + i) for i in range(26)], transcripts=True, threads=8)
             except Exception as e:
                 out["scorer hook (50k-word model)"] = {"error": str(e)[:300]}
         except Exception as e:

@@ -114,6 +114,14 @@ class CallbackScorer(object):
         """Time spent inside the callback so far (an estimate: every 16th call is timed)."""
         return float(_native.lib.ctcd_scorer_callback_seconds(self.handle))
 
+    def set_callback_threads(self, threads):
+        """A NATIVE callback that may be called from several threads at once (``from_c`` over a read-only model): ``threads - 1``
+        helper threads ask beside the calling one while a launch waits for its answers (``ctcd_scorer_set_callback_threads``).
+        Refused for Python callables: the interpreter lock would serialise them."""
+        if self._fn is not None and int(threads) != 1:
+            raise ValueError("callback threads are for native callbacks (CallbackScorer.from_c): a Python callable runs under the interpreter lock")
+        _native.check(_native.lib.ctcd_scorer_set_callback_threads(self.handle, int(threads)))
+
     def _raise_pending(self):
         e, self._error = self._error, None
         if e is not None:

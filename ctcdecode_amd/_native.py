@@ -17,7 +17,7 @@ COND_LOG10_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(c
 RESULT_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p))
 
 SYMBOLS = ["ctcd_log_softmax", "ctcd_compact_label_capacity", "ctcd_beam_decode_compact", "ctcd_expand_compact", "ctcd_beam_decode_to_host", "ctcd_scorer_create", "ctcd_scorer_destroy", "ctcd_scorer_is_character_based", "ctcd_scorer_max_order", "ctcd_scorer_dict_size",
-           "ctcd_scorer_reset_params", "ctcd_scorer_cond_log_prob", "ctcd_scorer_create_callback", "ctcd_scorer_cond_log10", "ctcd_scorer_callback_calls", "ctcd_scorer_callback_seconds", "ctcd_beam_decode_lm", "ctcd_beam_decode_lm_host", "ctcd_stream_create_lm",
+           "ctcd_scorer_reset_params", "ctcd_scorer_cond_log_prob", "ctcd_scorer_create_callback", "ctcd_scorer_cond_log10", "ctcd_scorer_callback_calls", "ctcd_scorer_callback_seconds", "ctcd_scorer_set_callback_threads", "ctcd_beam_decode_lm", "ctcd_beam_decode_lm_host", "ctcd_stream_create_lm",
            "ctcd_create", "ctcd_destroy", "ctcd_beam_decode", "ctcd_beam_decode_host", "ctcd_check_status", "ctcd_fetch_status_async", "ctcd_stream_create", "ctcd_stream_destroy", "ctcd_stream_frames", "ctcd_stream_decode", "ctcd_stream_decode_to_host", "ctcd_last_prune_host_rows", "ctcd_last_prune_flagged_rows", "ctcd_last_scorer_rounds", "ctcd_last_scorer_waits", "ctcd_set_scorer_wait",
            "ctcd_set_threads", "ctcd_set_cu_sharing", "ctcd_set_subtree_search", "ctcd_last_subtree_search", "ctcd_debug_set_host_path", "ctcd_set_timing", "ctcd_last_kernel_ms", "ctcd_last_prune_ms", "ctcd_debug_math_check", "ctcd_debug_set_profile", "ctcd_debug_set_fixed_layout", "ctcd_debug_set_prune_resolve", "ctcd_debug_set_fused_logits", "ctcd_debug_prune_rows", "ctcd_debug_timeline", "ctcd_debug_timeline_cap", "ctcd_debug_get_profile", "ctcd_debug_beam_dump", "ctcd_workgroup_lds_bytes", "ctcd_last_error", "ctcd_version"]
 
@@ -106,6 +106,8 @@ def _load():
     lib.ctcd_scorer_callback_calls.restype = ctypes.c_longlong
     lib.ctcd_scorer_callback_seconds.argtypes = [ctypes.c_void_p]
     lib.ctcd_scorer_callback_seconds.restype = ctypes.c_double
+    lib.ctcd_scorer_set_callback_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.ctcd_scorer_set_callback_threads.restype = ctypes.c_int
     lib.ctcd_stream_create_lm.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     return lib
 

@@ -522,7 +522,13 @@ struct Decoder {
   // boundary, the last frame, danger mode -- falls back to the histogram select, which first has to build its histogram
   // (rehistogram()): same survivors either way, by construction.
   // (round 6: pruned candidate lists as well -- the row's largest log-probability is then simply its first candidate's)
-  static constexpr bool kSpec = SMALLV && !LM && !LAZY && X::kSpecSelect;
+  // (round 6, measured and left off -- X::kSpecLm, -DCTC_EXP_SPEC_LM: the scorer's fixed-layout kernels as well.  Nothing in the scheme depends
+  //  on where a candidate's score comes from, and the outputs are identical (GPU: three input kinds at the configs[4] shape; host sweeps) --
+  //  but a dictionary leaves ~ 2 K live candidates per frame (206 at beam 100 with test.arpa), the K-th key lies in the bulk of them, the
+  //  band "between K and 128 hot keys" is hit by 61 % of the frames only and their lists average 146 keys (the slow ranking form): kernel
+  //  10.65 -> 10.93 ms on random rows, 10.61 -> 10.83 peaky, 9.72 -> 10.01 blank-dominated.  Not behind the scorer hook in any case: a frame
+  //  that is abandoned and run again would have to restore the list.)
+  static constexpr bool kSpec = SMALLV && (!LM || (X::kSpecLm && !CB)) && !LAZY && X::kSpecSelect;
   // Wide beams without a scorer (round 6; measured and left off: CTC_EXP_HOT_PRELIST): phase B pre-lists the candidates at or above a
   // threshold predicted from the previous frame (the speculative select's anchor -- previous best score + this row's best label
   // log-probability -- minus 1.5 x the last distance anchor -> K-th key) in the next beam's block; if the K-th key's bucket turns out to lie
@@ -1828,7 +1834,8 @@ struct Decoder {
           const int sl = w.cstart[k] + rn;
           w.skey[sl] = key;
           if (!LAZY) w.sinfo[sl] = live ? mk_info(lm_space, T_CHILD, k) : kHoleInfo;
-          hist_add(wd, key);
+          if (kSpec) x.hot_append(key >= thr, key, sl, w.list, w.lslot, &w.vars[VAR_G]);
+          else hist_add(wd, key);
         }
       }
       x.wave_add(&pv[P_NCAND], ncand);

@@ -1137,6 +1137,70 @@ struct ctcd_stream {
 
 // The external scorer (ctcdecode/src/scorer.h:41-110, created by paddle_get_scorer, binding.cpp:143-150): built on the host
 // from the ARPA file (lm_build.h), its tables mirrored into the HBM of one device (lm_tables.h).
+// Helper threads of a callback scorer whose callback may be called from several threads at once (ctcd_scorer_set_callback_threads): while a
+// waiting launch is being served they spin on a generation counter, take every P-th window of the batch the serving thread publishes and
+// report once per batch; between launches they sleep.  The serving thread takes its own share, so P threads ask P windows at a time.
+struct CbAskPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool active = false, stop = false;           // (under mu)
+  std::atomic<unsigned long long> gen{0};      // batches published
+  std::atomic<int> acks{0};                    // helpers done with the current batch
+  ctclm::CallbackLm *cl = nullptr;
+  ctclm::CallbackLm::Ask *batch = nullptr;
+  int n = 0;
+  int parts() const { return (int)th.size() + 1; }
+  void worker(int w) {
+    unsigned long long seen = gen.load(std::memory_order_acquire);
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return active || stop; });
+        if (stop) return;
+      }
+      for (unsigned spin = 0;; ++spin) {
+        const unsigned long long g = gen.load(std::memory_order_acquire);
+        if (g != seen) {
+          seen = g;
+          const int P = parts();
+          for (int i = w; i < n; i += P) cl->ask(batch[i]);
+          acks.fetch_add(1, std::memory_order_release);
+          spin = 0;
+        } else if ((spin & 4095) == 4095) {
+          std::lock_guard<std::mutex> lk(mu);
+          if (!active || stop) break;
+        }
+        __builtin_ia32_pause();
+      }
+    }
+  }
+  void start(int threads, ctclm::CallbackLm *c) {
+    shutdown();
+    cl = c;
+    stop = false;
+    for (int w = 1; w < threads; ++w) th.emplace_back([this, w] { worker(w); });
+  }
+  void shutdown() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; active = false; }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+    th.clear();
+  }
+  void begin() { if (th.empty()) return; { std::lock_guard<std::mutex> lk(mu); active = true; } cv.notify_all(); }
+  void end() { if (th.empty()) return; std::lock_guard<std::mutex> lk(mu); active = false; }
+  // asks batch[0 .. n): this thread's share here, the helpers' shares beside it (all of them in this thread when the batch is short)
+  void ask_all(ctclm::CallbackLm::Ask *b, int count) {
+    if (th.empty() || count < 4) { for (int i = 0; i < count; ++i) cl->ask(b[i]); return; }
+    batch = b; n = count;
+    acks.store(0, std::memory_order_relaxed);
+    gen.fetch_add(1, std::memory_order_release);
+    const int P = parts();
+    for (int i = 0; i < count; i += P) cl->ask(b[i]);
+    while (acks.load(std::memory_order_acquire) != P - 1) __builtin_ia32_pause();
+  }
+};
+
 struct ctcd_scorer {
   ctclm::HostScorer host;
   int device = 0;
@@ -1159,9 +1223,12 @@ struct ctcd_scorer {
   std::vector<uint32_t> live_stamp;           // per cache slot: the waiting launch whose log holds it
   std::vector<unsigned long long> live_memo;  // (state, word) pairs recently put into / found in that log (direct-mapped, 512 KB)
   uint32_t live_launch = 0;
+  CbAskPool ask_pool;                         // helper threads of a thread-safe callback (none unless asked for)
 };
 constexpr uint32_t kCbMissCap = 1u << 18;  // queued (state, word) pairs per round (2 MB); more are dropped and asked again
-constexpr uint32_t kCbLogCap = 1u << 20;   // cache slots one waiting launch can be handed (20 MB of page-locked memory)
+constexpr uint32_t kCbLogCap = 1u << 21;   // cache slots one waiting launch can be handed (40 MB of page-locked memory)
+constexpr size_t kCbLiveSlots0 = (size_t)1 << 22;   // a waiting launch cannot have its tables moved: they start with room for 2 M windows (64 MB of HBM) ...
+constexpr size_t kCbLiveStates0 = (size_t)1 << 22;  // ... and 4 M states (two zeroed arrays, 32 MB)
 constexpr uint32_t kCbLiveItems = 1u << 16;
 constexpr size_t kLiveOffDone = 256, kLiveOffAns = kLiveOffDone + (size_t)kCbLiveItems * 4, kLiveOffMiss = kLiveOffAns + (size_t)kCbLiveItems * 4,
                  kLiveOffIdx = kLiveOffMiss + (size_t)kCbMissCap * sizeof(ctclm::MissEntry), kLiveOffSlot = kLiveOffIdx + (size_t)kCbLogCap * 4,
@@ -1816,6 +1883,7 @@ void ctcd_scorer_destroy(ctcd_scorer *s) {
   if (s->h_live) (void)hipHostFree(s->h_live);
   if (s->cb_stage_hp) (void)hipHostFree(s->cb_stage_hp);
   if (s->cb_stage_ev) (void)hipEventDestroy(s->cb_stage_ev);
+  s->ask_pool.shutdown();
   delete s->cbl;
   delete s;
 }
@@ -1869,7 +1937,7 @@ static int cb_sync(ctcd_scorer *s, hipStream_t stream = nullptr) {
   if (s->cb_st_cap < h.st_bo.size()) {  // every state backs off to the empty context with weight 0: two zeroed arrays
     if (s->cb_st) (void)hipFree(s->cb_st);
     s->cb_st = nullptr;
-    const size_t cap = std::max<size_t>(h.st_bo.size() * 2, (size_t)1 << 20);  // (head room: a waiting launch cannot have them replaced)
+    const size_t cap = std::max<size_t>(h.st_bo.size() * 2, s->h_live ? kCbLiveStates0 : (size_t)1 << 20);  // (head room: a waiting launch cannot have them replaced)
     HIP_TRY(hipMalloc((void **)&s->cb_st, cap * 8));
     HIP_TRY(hipMemset(s->cb_st, 0, cap * 8));
     s->cb_st_cap = cap;
@@ -1893,6 +1961,7 @@ int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, in
   ctcd_scorer *s = new ctcd_scorer;
   s->device = device_id;
   s->cbl = new ctclm::CallbackLm;
+  s->ask_pool.cl = s->cbl;
   if (!s->cbl->build(alpha, beta, max_order, voc, lab, (ctclm::CondLog10Fn)fn, user)) {
     const std::string msg = s->cbl->hs.error;
     ctcd_scorer_destroy(s);
@@ -1935,6 +2004,10 @@ int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, in
     if (s->h_live) (void)hipHostFree(s->h_live);
     s->h_live = nullptr; s->d_live = nullptr;
     (void)hipGetLastError();
+  }
+  if (s->h_live) {  // (a waiting launch cannot have its tables moved: they get their room here, not in the first decode)
+    s->cbl->grow(kCbLiveSlots0);
+    s->live_stamp.assign(s->cbl->hs.ng.size(), 0u);
   }
   const int rc = cb_sync(s);
   if (rc) { ctcd_scorer_destroy(s); return rc; }
@@ -1980,6 +2053,13 @@ int ctcd_scorer_cond_log10(const ctcd_scorer *s, const char *const *words, int n
   *log10_prob = p;
   return 0;
 }
+int ctcd_scorer_set_callback_threads(ctcd_scorer *s, int threads) {
+  if (!s || !s->cbl) return fail(CTCD_EINVAL, "not a callback scorer");
+  if (threads < 1 || threads > 64) return fail(CTCD_EINVAL, "callback threads must be in [1, 64]");
+  std::lock_guard<std::mutex> lk(s->cb_mu);
+  s->ask_pool.start(threads, s->cbl);
+  return CTCD_OK;
+}
 long long ctcd_scorer_callback_calls(const ctcd_scorer *s) { return s && s->cbl ? (long long)s->cbl->queries : 0; }
 double ctcd_scorer_callback_seconds(const ctcd_scorer *s) { return s && s->cbl ? s->cbl->cb_seconds : 0.0; }
 
@@ -2024,8 +2104,8 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
     d->last_cb_rounds = round;
     if (round > 4 * T + 64) return fail(CTCD_EINTERNAL, "scorer hook: the decode does not make progress");
     if (live) {  // head room for the answers of a waiting launch: 8192 more slots / states before anything has to move
-      if ((cl.used + 8192) * 2 > cl.hs.ng.size()) cl.grow(std::max<size_t>(cl.hs.ng.size() * 4, (size_t)1 << 20));  // (16 MB to begin with)
-      if (cl.hist.size() + 8192 >= scorer->cb_st_cap / 2 && cl.hs.st_bo.size() <= scorer->cb_st_cap) {  // (cb_sync doubles the device arrays)
+      if ((cl.used + 8192) * 2 > cl.hs.ng.size()) cl.grow(std::max<size_t>(cl.hs.ng.size() * 4, kCbLiveSlots0));  // (64 MB to begin with)
+      if (cl.n_states() + 8192 >= scorer->cb_st_cap / 2 && cl.hs.st_bo.size() <= scorer->cb_st_cap) {  // (cb_sync doubles the device arrays)
         cl.hs.st_bo.resize(scorer->cb_st_cap + 64, 0.0f);
         cl.hs.st_fail.resize(cl.hs.st_bo.size(), 0u);
       }
@@ -2084,73 +2164,98 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
       static const bool trace = getenv("CTCD_HOOK_TIMING") != nullptr;  // (stderr: how busy this thread is while a launch waits on it)
       const auto t_begin = t_last;
       double busy = 0.0;
+      scorer->ask_pool.begin();
       for (unsigned spin = 0;; ++spin) {
         const unsigned long long s0 = seen;
         const auto t_in = trace ? std::chrono::steady_clock::now() : t_begin;
         unsigned fresh = 0;
         for (bool more = true; more && !give_up;) {
-          // the pairs that have arrived, up to 32 at a time: their table lines are requested first (a cold probe of a table of tens of MB
-          // is a DRAM access; the duplicates -- most of the list -- cost nothing else)
-          struct Pend { uint32_t st, wd, item; size_t ring; } pend[32];
-          int np = 0;
+          // The pairs that have arrived, up to 128 at a time, in three passes.  (1) classify: answered moments ago (memo), cached, or new to
+          // the cache -- the table lines were requested while the pairs were read (a cold probe of a table of tens of MB is a DRAM access),
+          // the words of a new window are looked up and the line of its next state requested; (2) ask the callback about the new windows
+          // (the scorer's helper threads take a share each when it has any); (3) in the order of the list: cache the answers, append to
+          // the log, publish per item.
+          enum { kMemo = 0, kHave = 1, kNew = 2, kDup = 3 };
+          constexpr int kBatch = 128;
+          struct Pend { uint32_t st, wd, item, at; size_t ring; int kind; } pend[kBatch];
+          ctclm::CallbackLm::Ask asks[kBatch];
+          int np = 0, na = 0;
           const uint32_t mask = (uint32_t)cl.hs.ng.size() - 1;
-          while (np < 32) {
+          while (np < kBatch) {
             const size_t at_ring = (size_t)((seen + (unsigned)np) & (kCbMissCap - 1));
             if (h_miss[4 * at_ring + 3] == 0xFFFFFFFFu) { more = false; break; }  // (the flag word: the pair's 16 bytes arrive in one piece)
             std::atomic_thread_fence(std::memory_order_acquire);
-            pend[np] = Pend{h_miss[4 * at_ring], h_miss[4 * at_ring + 1], h_miss[4 * at_ring + 2], at_ring};
+            pend[np] = Pend{h_miss[4 * at_ring], h_miss[4 * at_ring + 1], h_miss[4 * at_ring + 2], 0u, at_ring, kMemo};
             const uint32_t hh = ctclm::ng_hash(pend[np].st, pend[np].wd) & mask;
             __builtin_prefetch(&cl.hs.ng[hh]);
             __builtin_prefetch(&scorer->live_stamp[hh]);
             ++np;
           }
+          bool bad = false;
+          int usable = np;  // (the table runs out of room at this pair: the ones before it are served, then the wait ends)
           for (int q = 0; q < np; ++q) {
-            const uint32_t st = pend[q].st, wd = pend[q].wd, item = pend[q].item;
-            const size_t at_ring = pend[q].ring;
+            Pend &e = pend[q];
             // most of the list repeats pairs asked moments ago (every park queues what its pending entries need, neighbouring prefixes
             // and utterances want the same windows): a small direct-mapped memo of the pairs already in this launch's log answers
             // those without touching the table
-            const unsigned long long key = ((unsigned long long)st << 32) | wd;
-            unsigned long long &memo = scorer->live_memo[(size_t)((key * 0x9E3779B97F4A7C15ull) >> 48)];
-            if (memo == key) {
-              if (item < (uint32_t)B) {
+            const unsigned long long key = ((unsigned long long)e.st << 32) | e.wd;
+            if (scorer->live_memo[(size_t)((key * 0x9E3779B97F4A7C15ull) >> 48)] == key) continue;  // kMemo
+            const long long have = cl.find_slot(e.st, e.wd);
+            if (have >= 0) { e.kind = kHave; e.at = (uint32_t)have; continue; }
+            e.kind = kNew;
+            for (int o = 0; o < q; ++o)  // (the same new pair twice in one batch: the callback is asked once per window)
+              if (pend[o].kind == kNew && pend[o].st == e.st && pend[o].wd == e.wd) { e.kind = kDup; break; }
+            if (e.kind == kDup) continue;
+            if (!cl.room_for((size_t)na + 1, scorer->cb_st_cap)) { usable = q; give_up = true; break; }  // (the tables would have to move: between launches)
+            if (!cl.prepare(e.st, e.wd, asks[na])) { bad = true; break; }
+            cl.prefetch_next_state(e.st, e.wd);
+            ++na;
+          }
+          if (!bad && na) {
+            const auto t0 = std::chrono::steady_clock::now();
+            scorer->ask_pool.ask_all(asks, na);
+            cl.cb_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          }
+          int ia = 0;
+          bool log_full = false;
+          for (int q = 0; q < usable && !bad; ++q) {
+            Pend &e = pend[q];
+            const size_t at_ring = e.ring;
+            if (log_full && e.kind == kMemo) continue;
+            const unsigned long long key = ((unsigned long long)e.st << 32) | e.wd;
+            if (e.kind != kMemo) {
+              uint32_t at = e.at;
+              if (e.kind == kNew) {
+                if (!cl.commit(asks[ia++], &at)) { bad = true; break; }
+              } else if (e.kind == kDup) {
+                at = (uint32_t)cl.find_slot(e.st, e.wd);
+              }
+              if (log_full) continue;  // (the answers that have been paid for are cached; their pairs stay on the list for the next launch)
+              if (scorer->live_stamp[at] != launch_id) {
+                if (log_n >= kCbLogCap) { give_up = true; log_full = true; continue; }
+                scorer->live_stamp[at] = launch_id;
+                l_idx[log_n] = at;
+                l_slot[log_n] = cl.hs.ng[at];
+                ++log_n;
+                ++fresh;
                 std::atomic_thread_fence(std::memory_order_release);
-                h_ans[item] = ++ans_local[item];
+                *h_len = log_n;  // (published entry by entry: the stores of this thread arrive in order)
               }
-              h_miss[4 * at_ring] = 0xFFFFFFFFu; h_miss[4 * at_ring + 1] = 0xFFFFFFFFu; h_miss[4 * at_ring + 2] = 0xFFFFFFFFu; h_miss[4 * at_ring + 3] = 0xFFFFFFFFu;
-              ++seen;
-              continue;
+              scorer->live_memo[(size_t)((key * 0x9E3779B97F4A7C15ull) >> 48)] = key;  // (in the log from here on)
             }
-            uint32_t at = 0;
-            const long long have = cl.find_slot(st, wd);
-            if (have < 0) {
-              if (!cl.room_for(1, scorer->cb_st_cap)) { give_up = true; break; }  // (the tables would have to move: between launches)
-              if (!cl.resolve(st, wd, &at)) {
-                *h_len = 0xFFFFFFFFu;
-                (void)hipStreamSynchronize(stream);
-                scorer->live_miss_hw = kCbMissCap;
-                return fail(CTCD_EINVAL, cl.hs.error);
-              }
-            } else {
-              at = (uint32_t)have;
-            }
-            if (scorer->live_stamp[at] != launch_id) {
-              if (log_n >= kCbLogCap) { give_up = true; break; }
-              scorer->live_stamp[at] = launch_id;
-              l_idx[log_n] = at;
-              l_slot[log_n] = cl.hs.ng[at];
-              ++log_n;
-              ++fresh;
+            if (e.item < (uint32_t)B) {  // the item's workgroup goes on when every pair it queued has been dealt with
               std::atomic_thread_fence(std::memory_order_release);
-              *h_len = log_n;  // (published entry by entry: the stores of this thread arrive in order)
-            }
-            memo = key;  // (in the log from here on)
-            if (item < (uint32_t)B) {  // the item's workgroup goes on when every pair it queued has been dealt with
-              std::atomic_thread_fence(std::memory_order_release);
-              h_ans[item] = ++ans_local[item];
+              h_ans[e.item] = ++ans_local[e.item];
             }
             h_miss[4 * at_ring] = 0xFFFFFFFFu; h_miss[4 * at_ring + 1] = 0xFFFFFFFFu; h_miss[4 * at_ring + 2] = 0xFFFFFFFFu; h_miss[4 * at_ring + 3] = 0xFFFFFFFFu;
             ++seen;
+          }
+          if (bad) {
+            scorer->ask_pool.end();
+            *h_len = 0xFFFFFFFFu;
+            (void)hipStreamSynchronize(stream);
+            scorer->live_miss_hw = kCbMissCap;
+            return fail(CTCD_EINVAL, cl.hs.error);
           }
         }
         if (fresh) ++d->last_cb_waits;
@@ -2169,6 +2274,7 @@ static int cb_rounds(ctcd_decoder *d, ctcd_stream **states, const unsigned char 
         if (give_up) { *h_len = 0xFFFFFFFFu; break; }
         __builtin_ia32_pause();
       }
+      scorer->ask_pool.end();
       if (trace) fprintf(stderr, "scorer hook, waiting launch %d: %.2f ms, this thread busy %.2f ms with %llu queued pairs (%u new to the launch's log)%s\n", round,
                          1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), 1e3 * busy, seen, log_n, give_up ? "; gave up" : "");
     }

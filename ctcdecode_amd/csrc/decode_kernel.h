@@ -226,6 +226,11 @@ struct DevX {
 #else
   static constexpr bool kSpecSelect = true;
 #endif
+#if defined(CTC_EXP_SPEC_LM)  // (measured slower, round 6: beam_core.h kSpec)
+  static constexpr bool kSpecLm = true;
+#else
+  static constexpr bool kSpecLm = false;
+#endif
   static constexpr bool kQuarters = PROF == 3;  // (beam_core.h phase A1)
   // Round 6 experiments, all measured SLOWER than the kernel without them and therefore off (-DCTC_EXP_... builds them):
 #if defined(CTC_EXP_LCP_TABLE)

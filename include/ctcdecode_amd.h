@@ -147,9 +147,9 @@ double ctcd_scorer_cond_log_prob(const ctcd_scorer *scorer, const char *const *w
  *   Cost: a warm cache decodes in one launch, like the built-in tables.  Cold, an utterance misses once per frame in which a
  *   prefix completes a word under a history it has not asked about; since round 6 its workgroup WAITS for the answer (see
  *   ctcd_last_scorer_waits below) instead of ending its launch, and the call is bound by the calling thread: the callback's own
- *   time plus ~0.15 us of bookkeeping per new window (bench.py "scorer hook": 128 x 1500 frames of transcript-like rows under a
- *   5-gram model, 195 k windows, 87 ms cold in one launch -- 264 ms and 699 launches in round 5).  ctcd_last_scorer_rounds tells
- *   how many launches the last call took.
+ *   time plus ~0.12 us of bookkeeping per queued pair (bench.py "scorer hook": 128 x 1500 frames of transcript-like rows under a
+ *   5-gram model, 195 k windows, 86-88 ms cold in one launch -- 264 ms and 699 launches in round 5).  ctcd_last_scorer_rounds tells
+ *   how many launches the last call took.  The cache of such a scorer starts with room for 2 M windows (64 + 32 MB of HBM).
  * ctcd_scorer_cond_log10 evaluates any scorer in the callback's own form (so the built-in tables can sit behind one);
  * ctcd_scorer_callback_calls counts the callback invocations so far (= distinct windows cached). */
 typedef int (*ctcd_cond_log10_fn)(void *user, const char *const *words, int n, float *log10_prob);
@@ -157,8 +157,15 @@ int ctcd_scorer_create_callback(ctcd_scorer **out, double alpha, double beta, in
                                 int n_vocabulary, ctcd_cond_log10_fn fn, void *user, const char *const *labels, int V, int device_id);
 int ctcd_scorer_cond_log10(const ctcd_scorer *scorer, const char *const *words, int n, float *log10_prob);
 long long ctcd_scorer_callback_calls(const ctcd_scorer *scorer);
-/* seconds spent inside the callback so far (every 16th call is timed and counted sixteen times: an estimate) */
+/* seconds spent inside the callback so far (wall time of the asking passes of waiting launches; elsewhere every 16th call is timed
+ * and counted sixteen times) */
 double ctcd_scorer_callback_seconds(const ctcd_scorer *scorer);
+/* A callback that may be called from several threads at once (a read-only model behind it; NOT a Python callable: the interpreter
+ * lock serialises those): `threads` - 1 helper threads ask beside the calling thread while a launch waits for its answers -- the new
+ * windows of a batch of queued pairs are split among them; caching the answers stays with the calling thread, so results and the
+ * "every window is asked once" property are unchanged.  The helpers spin while a waiting launch is served and sleep otherwise.
+ * 1 (the default): the callback is only ever called from the thread that called the decoder.  threads in [1, 64]. */
+int ctcd_scorer_set_callback_threads(ctcd_scorer *scorer, int threads);
 /* launches the decoder's last call through a callback scorer took (1 = the cache held everything; one more per round of
  * misses): what a cold / lukewarm cache costs (bench.py "scorer hook") */
 int ctcd_last_scorer_rounds(ctcd_decoder *dec);

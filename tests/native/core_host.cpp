@@ -65,6 +65,11 @@ struct HostX {
   void tick() {}
   // speculative select (beam_core.h Decoder::kSpec), sequentially: the same contract as the device policy's
   static constexpr bool kSpecSelect = true;
+#if defined(CTC_EXP_SPEC_LM)  // (measured slower, round 6: beam_core.h kSpec)
+  static constexpr bool kSpecLm = true;
+#else
+  static constexpr bool kSpecLm = false;
+#endif
   static constexpr bool kQuarters = false;
   static constexpr bool kLcpTable = false;   // (a wave of its own builds it beside phase B)
   static constexpr bool kA1Overlap = false;  // (an overlap of wave roles: nothing to overlap with one thread)
@@ -510,11 +515,24 @@ static int decode_impl(const float *probs, const int32_t *seq_lens, int B, int T
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
         else st = decode_utterance<true, false, true, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+      } else if (lm && !lm->char_based && !lm->dict_wide && !getenv("CTC_HOST_GENERAL_LM") && beam <= 128 && V <= 32 && !getenv("CTC_HOST_LM_RUNTIME_LAYOUT")) {
+        // the word-model instantiation of the fixed-layout class (SMALLV = 1: what the device runs for these shapes -- with the speculative select)
+        const float *rawb = raw + (size_t)b * T * V;
+        if (pruned) st = decode_utterance<false, 1, true, false, false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+        else st = decode_utterance<true, 1, true, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
       } else if (lm && !lm->char_based && !lm->dict_wide && !getenv("CTC_HOST_GENERAL_LM")) {  // the word-model instantiation, as the product picks it
         const float *rawb = raw + (size_t)b * T * V;
         if (pruned) st = decode_utterance<false, false, true, false, false, false, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
         else st = decode_utterance<true, false, true, false, false, false, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+      } else if (lm && beam <= 128 && V <= 32 && !getenv("CTC_HOST_LM_RUNTIME_LAYOUT")) {  // any scorer, fixed-layout class
+        const float *rawb = raw + (size_t)b * T * V;
+        if (pruned) st = decode_utterance<false, 1, true>(x, w, d, blank_id, (const float *)nullptr, &pr, len, pool.data(), pool_up.data(), (int)pool.size(),
+                                  ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
+        else st = decode_utterance<true, 1, true>(x, w, d, blank_id, rows, (const PrunedRows *)nullptr, len, pool.data(), pool_up.data(), (int)pool.size(),
                                   ctcmath::host_tables().w, &outs, b, (const StreamState *)nullptr, lm, rawb, raw_log);
       } else if (lm) {
         const float *rawb = raw + (size_t)b * T * V;

@@ -530,3 +530,52 @@ def test_scorer_hook_compact_results_cold_cache_and_order_one(torch_mod):
             assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
     finally:
         inner.close()
+
+
+def test_scorer_hook_native_callback_on_several_threads(torch_mod):
+    """Round 6: a NATIVE callback that may be called from several threads at once (ctcd_scorer_set_callback_threads) -- the built-in
+    tables of test.arpa behind ctcd_scorer_cond_log10, which has the callback's signature and only reads.  The helpers split the new
+    windows of a batch of queued pairs; caching stays with the calling thread: same results as the built-in tables bit for bit, the
+    same number of callback calls as with one thread (every distinct window is asked once), and a Python callable is refused."""
+    import ctypes
+
+    import ctcdecode_amd
+    from ctcdecode_amd import _native as n
+
+    lp = ou.synth_logprobs(24, 300, 29, 9100, blank_bias=0.5)
+    lp[:, :, LABELS29.index(" ")] += np.float32(1.0)
+    m = lp.max(-1, keepdims=True)
+    lp = (lp - (m + np.log(np.exp(lp - m).sum(-1, keepdims=True)))).astype(np.float32)
+    x = torch_mod.from_numpy(lp).cuda()
+    ref = ctcdecode_amd.CTCBeamDecoder(LABELS29, model_path=TEST_ARPA, alpha=0.6, beta=1.1, beam_width=64, cutoff_top_n=29, log_probs_input=True)
+    want = ref.decode_device(x, None)
+    arr = (ctypes.c_char_p * 29)(*[s.encode("utf-8") for s in LABELS29])
+    inner = ctypes.c_void_p()
+    n.check(n.lib.ctcd_scorer_create(ctypes.byref(inner), 0.0, 0.0, TEST_ARPA.encode(), arr, 29, 0))
+    try:
+        order = int(n.lib.ctcd_scorer_max_order(inner))
+        fn_addr = ctypes.cast(n.lib.ctcd_scorer_cond_log10, ctypes.c_void_p).value
+        words = _arpa_words(TEST_ARPA)
+        calls = []
+        for threads in (1, 4, 7):
+            sc = ctcdecode_amd.CallbackScorer.from_c(fn_addr, inner.value, words, order, LABELS29, alpha=0.6, beta=1.1)
+            sc.set_callback_threads(threads)
+            dec = ctcdecode_amd.CTCBeamDecoder(LABELS29, scorer=sc, beam_width=64, cutoff_top_n=29, log_probs_input=True)
+            got = dec.decode_device(x, None)
+            for g, w in zip(got, want):
+                assert torch_mod.equal(g, w), threads
+            calls.append(sc.callback_calls())
+            got = dec.decode_device(x, None)  # (warm: nothing is asked)
+            assert sc.callback_calls() == calls[-1]
+            del dec, sc
+        assert calls[0] > 1000 and calls[1] == calls[0] and calls[2] == calls[0], calls
+    finally:
+        n.lib.ctcd_scorer_destroy(inner)
+    py = _BuiltinBehindCallback(dict(labels=LABELS29, lm_path=TEST_ARPA))
+    try:
+        sc = ctcdecode_amd.CallbackScorer(py, py.vocabulary, py.order, LABELS29, alpha=0.6, beta=1.1)
+        with pytest.raises(ValueError):
+            sc.set_callback_threads(4)
+        sc.set_callback_threads(1)
+    finally:
+        py.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The scorer hook's cost (bench.py time_scorer_hook) and the two-launches-in-flight rule (bench.py time_inflight) on their own.
-    python tools/hook_probe.py [--big] [--inflight]"""
+    python tools/hook_probe.py [--big] [--inflight] [--threads=1 --threads=4 ...]"""
 import json
 import os
 import sys
@@ -25,8 +25,10 @@ if "--inflight" in sys.argv:
     for k in (1, 2, 3):
         dt = bench.time_inflight(torch, ctcdecode_amd, dev, lp256, [str(i) for i in range(29)], 100, k, steps=20)
         print("headline batch, default build, %d in flight: %.3f ms/batch (%.0f utt/s)" % (k, dt * 1e3, 256 / dt))
-print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels), indent=1))
-print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, transcripts=True), indent=1))
+threads = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--threads=")] or [1]
+for th in threads:
+    print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, threads=th), indent=1))
+    print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, arpa, labels, transcripts=True, threads=th), indent=1))
 if "--big" in sys.argv:
     import importlib.util
     import tempfile
@@ -37,4 +39,5 @@ if "--big" in sys.argv:
     big = os.path.join(tempfile.gettempdir(), "ctcd_big_words_50k.arpa")
     if not os.path.exists(big):
         mod.make(big)
-    print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, big, labels, transcripts=True), indent=1))
+    for th in threads:
+        print(json.dumps(bench.time_scorer_hook(torch, ctcdecode_amd, dev, big, labels, transcripts=True, threads=th), indent=1))
