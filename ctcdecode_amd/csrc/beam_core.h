@@ -560,6 +560,13 @@ struct Decoder {
   static constexpr bool kLcpTable = kSpec && X::kLcpTable;
   // word models, fixed-layout class at 1024 threads, built-in tables: the n-gram query of a new entry's word runs beside phase B
   // (step(): phase A2 / phase B)
+  // Wide beams without a scorer (round 6): phase B's children loop asks FIVE per-entry arrays for every parent -- first slot, parent label,
+  // score, blank part, existing-children mask -- and in the run-time layouts each array costs an address of its own (ten VALU adds and five
+  // LDS reads of the 49 instructions one candidate takes; the loop is bound by issue: 14 000 candidates per frame at beam 500).  Phase A2,
+  // where each entry's thread computes the first slot anyway, packs {score, blank part, first slot, label} into ONE 16-byte record per entry
+  // (in the next beam's block: nothing lives there between two emissions); the children loop then makes two reads (record, mask) from two
+  // addresses.
+  static constexpr bool kParentRec = !SMALLV && LAZY && !LM && X::kParentRec && !kHotPre;  // (the pre-list experiment borrows the same block)
   static constexpr bool kLmOverlap = LM && WORDLM && SMALLV && !CB && !LAZY && X::kLmOverlap;
   static constexpr uint32_t kLmSpaceDeferred = 0x80000000u;  // high gate word of an entry whose space child the settling wave scores
   // ONE thread (X::spec_thread) turns what a frame observed -- its K-th key, the size of its hot list -- into the next frame's
@@ -1650,10 +1657,13 @@ struct Decoder {
     if (kSpec && tid == x.spec_thread()) spec_predict(in.t);
     // ---- A2: Euler-tour slot offsets; which children of in-beam parents already exist
     int npin = 0;
+    Int4v *prec = reinterpret_cast<Int4v *>(w.nxt.node);  // (kParentRec)
     for (int j = tid; j < n; j += nt) {
       const int dj = b.dep[j], q = w.e[j], P = w.anc[j], a = acnt[j];
       w.ostart[j] = 2 * j + Vnb * (j - a);
-      w.cstart[j] = 2 * q + Vnb * (q - 1 - a);
+      const int cs_j = 2 * q + Vnb * (q - 1 - a);
+      w.cstart[j] = cs_j;
+      if (kParentRec) prec[j] = Int4v{(int)ctcmath::f32_to_bits(b.score[j]), (int)ctcmath::f32_to_bits(b.bprev[j]), cs_j, b.ch[j]};
       int pr = -1, rr = -1;
       if (P >= 0) {
         if (b.dep[P] == dj - 1) {                            // parent in the beam: "hit" (path_trie.cpp:40-48)
@@ -1850,7 +1860,37 @@ struct Decoder {
       constexpr bool fixed_lp = SMALLV == 2;
       const int lp2 = fixed_lp ? kMidVc : 1 << sh;
       int ncand = 0;
-      if (small_vocab && nt2 >= lp2) {               // a group of lp2 lanes per parent, one lane per character
+      if (kParentRec && small_vocab && nt2 >= lp2) {
+        // Wide beams without a scorer: the same groups of lp2 lanes per parent, reading the packed records of phase A2 -- and a loop that
+        // every lane of a wave leaves together (the wave's first lane has its smallest parent: a scalar counter closes the loop, the lanes
+        // past the last parent are masked inside).  The general form below ends each lane's loop on its own: ten of its instructions
+        // per candidate were the bookkeeping of a divergent loop.
+        const int g0 = t2 >> sh, rn = t2 & (lp2 - 1), ng = nt2 >> sh;
+        const bool lane = rn < Vnb && g0 < ng;
+        const int r = lane ? rn + ((brank >= 0 && rn >= brank) ? 1 : 0) : 0;
+        const int c = IDENT ? r : w.cch[r];
+        const float lp = w.clp[r];
+        const int g_first = x.uni(g0);
+        const int g_last = g_first + ((x.lanes() >> sh) > 1 ? (x.lanes() >> sh) - 1 : 0);  // the wave's largest first parent
+        auto one = [&](int i) {
+          const Int4v rc = x.load4(reinterpret_cast<const int *>(prec + i));
+          const uint32_t hw = w.hit[hit_word(i, rn)];
+          const float psc = ctcmath::bits_to_f32((uint32_t)rc.x), pbp = ctcmath::bits_to_f32((uint32_t)rc.y);
+          const uint32_t live = 0u - (((hw >> (rn & 31)) & 1u) ^ 1u);  // all ones unless the child already exists
+          const float ext = lp + psc, rep = pbp > CTC_NEG_MAX ? lp + pbp : CTC_NEG_MAX;  // :110-118
+          const float logp = c == rc.w ? rep : ext;
+          const uint32_t k = ord_f32_raw(logp) & live;
+          const int sl = rc.z + rn;
+          w.skey[sl] = k;
+          hist_add(wd, k, hp, sl);
+        };
+        if (lane) {
+          int i = g0;
+          // (measured: two parents per trip, both records requested before either is used -- no gain, 38.1 against 38.0 ms)
+          for (int i0 = g_last; i0 < n; i0 += ng, i += ng) one(i);  // (every parent of the wave's lanes exists: no test per lane)
+          if (i < n) one(i);                                        // (the last pass: the wave's first groups only)
+        }
+      } else if (small_vocab && nt2 >= lp2) {        // a group of lp2 lanes per parent, one lane per character
         const int g0 = fixed_lp ? t2 / kMidVc : t2 >> sh;   // this lane's first parent
         const int rn = fixed_lp ? t2 - g0 * kMidVc : t2 & (lp2 - 1);
         const int ng = fixed_lp ? nt2 / kMidVc : nt2 >> sh;
@@ -1877,7 +1917,13 @@ struct Decoder {
           auto fetch = [&](int i) {
             Par p;
             // everything this candidate needs from its parent, requested in one go (one LDS round trip), no branches
-            p.cs = w.cstart[i]; p.hw = w.hit[hit_word(i, rn)]; p.pch = b.ch[i]; p.psc = b.score[i]; p.pbp = b.bprev[i];
+            if (kParentRec) {
+              const Int4v r = x.load4(reinterpret_cast<const int *>(prec + i));
+              p.psc = ctcmath::bits_to_f32((uint32_t)r.x); p.pbp = ctcmath::bits_to_f32((uint32_t)r.y); p.cs = r.z; p.pch = r.w;
+              p.hw = w.hit[hit_word(i, rn)];
+            } else {
+              p.cs = w.cstart[i]; p.hw = w.hit[hit_word(i, rn)]; p.pch = b.ch[i]; p.psc = b.score[i]; p.pbp = b.bprev[i];
+            }
             p.gw = (LM && WORDLM) ? (uint32_t)gate_w[i] : 0u;
             return p;
           };

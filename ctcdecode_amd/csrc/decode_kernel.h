@@ -226,6 +226,11 @@ struct DevX {
 #else
   static constexpr bool kSpecSelect = true;
 #endif
+#if defined(CTC_NO_PARENT_REC)
+  static constexpr bool kParentRec = false;
+#else
+  static constexpr bool kParentRec = true;  // (beam_core.h kParentRec: wide beams, one packed record per parent for phase B)
+#endif
 #if defined(CTC_EXP_SPEC_LM)  // (measured slower, round 6: beam_core.h kSpec)
   static constexpr bool kSpecLm = true;
 #else

@@ -65,6 +65,11 @@ struct HostX {
   void tick() {}
   // speculative select (beam_core.h Decoder::kSpec), sequentially: the same contract as the device policy's
   static constexpr bool kSpecSelect = true;
+#if defined(CTC_NO_PARENT_REC)
+  static constexpr bool kParentRec = false;
+#else
+  static constexpr bool kParentRec = true;
+#endif
 #if defined(CTC_EXP_SPEC_LM)  // (measured slower, round 6: beam_core.h kSpec)
   static constexpr bool kSpecLm = true;
 #else
