@@ -1478,6 +1478,15 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       lds = carve<2>(wtmp, nullptr, nullptr, dims, &far_bytes);
     }
   }
+  // the first wide-beam layout at its compile-time size (decode_kernel.h LAYOUT 3: beam <= 500 over <= 29 labels, no pruning, no scorer)
+  bool wide3 = false;
+#if !defined(CTC_QUICK_BUILD)
+  if (big && far_level == 1 && fits_wide_layout(dims) && !d->no_fixed_layout && !scorer && threads == 1024 && !d->profile) {
+    size_t fb3 = 0;
+    const size_t lds3 = carve<1>(wtmp, nullptr, nullptr, wide_layout_dims(), &fb3);
+    if (lds3 + 2048 <= (size_t)d->max_lds) { wide3 = true; lds = lds3; far_bytes = fb3; }
+  }
+#endif
   far_bytes = (far_bytes + 255) / 256 * 256;
   if (lds + 2048 > (size_t)d->max_lds)
     return fail(CTCD_EUNSUPPORTED, "beam_width * (candidates + 2) needs " + std::to_string(lds) + " B of LDS, more than one workgroup has");
@@ -1756,6 +1765,7 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
   }
   if (occ2) fn = pruned_mode ? (const void *)ctc_beam_decode_kernel<0, 0, 1, true, 1024, false, true> : (const void *)ctc_beam_decode_kernel<0, 0, 1, false, 1024, false, true>;
   if (fixed2 && !big) fn = (const void *)ctc_beam_decode_kernel<0, 0, 2, true, 1024>;
+  if (wide3) fn = (const void *)ctc_beam_decode_kernel<0, 1, 3, false, 1024>;
   if (d->profile && d->tl_armed) {  // the timeline build exists for the north-star class of shapes and for the first wide-beam layout
     if (threads != 1024) return fail(CTCD_EUNSUPPORTED, "barrier timeline: 1024 threads per workgroup (the product configuration)");
     if (big && far_level == 1 && !pruned_mode) {

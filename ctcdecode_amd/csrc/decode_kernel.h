@@ -906,6 +906,14 @@ __host__ __device__ inline bool fits_mid_layout(const Dims &d) {
   return d.K <= ctcbeam::kMidK && d.V <= ctcbeam::kMidV && d.Vc_max <= ctcbeam::kMidVc && d.use_rank_table && !d.lm;
 }
 
+// LAYOUT 3 (round 6): the first wide-beam layout (BIG == 1) at a compile-time size -- beam <= kWideK over <= kWideV labels, no pruning, no
+// scorer: BASELINE configs[2]'s decoder (beam 500 over the 29 labels of English characters; the largest beam whose slot keys still fit one
+// workgroup's LDS).  The algorithm is the run-time layout's (beam_core.h SMALLV = 0); what changes is that every LDS array sits at an
+// address the instructions can hold, as in LAYOUT 1.
+constexpr int kWideK = 500, kWideV = 29;
+__host__ __device__ constexpr Dims wide_layout_dims() { return Dims{kWideK, kWideV, kWideV, 0, 0}; }
+__host__ __device__ inline bool fits_wide_layout(const Dims &d) { return d.K <= kWideK && d.V <= kWideV && d.Vc_max <= kWideV && !d.use_rank_table && !d.lm; }
+
 // PRUNED: the candidates of every frame come from the vocabulary-prune pass (a.pr_*), otherwise they are the rows of a.probs.
 // OCC2 (fixed layout only): the build for two workgroups per CU -- at most 64 VGPRs (8 waves per SIMD) and the exact
 // replay's scratch in HBM (67 KB of LDS instead of 132 KB).  A lone workgroup runs ~7 % slower than in the default build
@@ -925,6 +933,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   // (every layout keeps the exact replay's scratch in per-utterance HBM scratch; the wide-beam layouts more: beam_core.h carve)
   if (LAYOUT == 1) carve<0, OCC2>(w, smem, a.far + (size_t)b * a.far_stride, fixed_layout_dims(LM != 0), nullptr);
   else if (LAYOUT == 2) carve<0, OCC2>(w, smem, a.far + (size_t)b * a.far_stride, mid_layout_dims(), nullptr);
+  else if (LAYOUT == 3) carve<BIG>(w, smem, a.far + (size_t)b * a.far_stride, wide_layout_dims(), nullptr);
   else carve<BIG>(w, smem, a.far + (size_t)b * a.far_stride, a.dims, nullptr);
   __shared__ long long prof[16];
   constexpr int kTlCap = (LM || BIG) ? kTimelineCap / 2 : kTimelineCap;  // (the LM tier's and the wide-beam layout's workspaces leave 8 KB for the stamps)
@@ -994,7 +1003,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
         prow.ch = a.pr_ch + ((size_t)b * a.T + fo) * a.pr_stride;
         prow.lp = a.pr_lp + ((size_t)b * a.T + fo) * a.pr_stride;
       }
-      st = decode_utterance<!PRUNED, LAYOUT, true, BIG != 0, BIG != 0 || OCC2, BIG == 3, false, true>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + fo) * a.V,
+      st = decode_utterance<!PRUNED, (LAYOUT == 3 ? 0 : LAYOUT), true, BIG != 0, BIG != 0 || OCC2, BIG == 3, false, true>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + fo) * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, a.raw + ((size_t)b * a.T + fo) * a.V, a.raw_log, (const int *)nullptr);
       if (st != ctcbeam::ST_NEED_HOST || a.cb_log_len == nullptr || !a.st_base) break;
@@ -1029,7 +1038,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
       len -= consumed;
     }
   } else {
-  st = decode_utterance<!PRUNED, LAYOUT, LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2, LM == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
+  st = decode_utterance<!PRUNED, (LAYOUT == 3 ? 0 : LAYOUT), LM != 0, BIG != 0, BIG != 0 || OCC2, BIG == 3, LM == 2, LM == 3>(x, w, a.dims, a.blank, PRUNED ? nullptr : a.probs + ((size_t)b * a.T + f0) * a.V,
                                   PRUNED ? &prow : (const PrunedRows *)nullptr, len, pool, pool_up, pool_cap, tbl, outs, b,
                                   a.st_base ? &ss : (const StreamState *)nullptr, lmv, LM ? a.raw + ((size_t)b * a.T + f0) * a.V : nullptr, a.raw_log,
                                   (PRUNED || kNoStreamedInput) ? (const int *)nullptr : a.frames_ready);
@@ -1069,7 +1078,7 @@ __global__ void __launch_bounds__(1024, OCC2 ? 8 : 1) ctc_beam_decode_kernel(Ker
   X(0, 1, 0, false, 0, false, false, 3) X(0, 1, 0, true, 0, false, false, 4) X(0, 2, 0, false, 0, false, false, 5) X(0, 2, 0, true, 0, false, false, 5) \
   X(0, 0, 0, false, 0, false, false, 6) X(0, 0, 0, true, 0, false, false, 6) X(0, 0, 1, false, 0, false, false, 7) X(0, 0, 1, true, 0, false, false, 7) \
   X(1, 1, 0, false, 0, false, false, 8) X(1, 1, 0, true, 0, false, false, 8) X(1, 0, 1, false, 0, false, false, 9) X(1, 0, 1, true, 0, false, false, 9) \
-  X(1, 0, 0, false, 0, false, false, 10) X(1, 0, 0, true, 0, false, false, 10)                                                       \
+  X(1, 0, 0, false, 0, false, false, 10) X(1, 0, 0, true, 0, false, false, 10) X(0, 1, 3, false, 1024, false, false, 10)                                                       \
   X(0, 0, 0, false, 0, true, false, 11) X(0, 0, 0, true, 0, true, false, 11) X(0, 0, 1, false, 1024, true, false, 2)                     \
   X(0, 0, 1, true, 1024, true, false, 3) X(2, 0, 1, false, 1024, true, false, 4)                                                       \
   X(0, 0, 1, false, 1024, 2, false, 0) X(0, 0, 1, true, 1024, 2, false, 1) X(0, 0, 1, false, 1024, 2, true, 2) X(0, 0, 1, true, 1024, 2, true, 3) X(2, 0, 1, false, 1024, 2, false, 5) \

@@ -244,6 +244,26 @@ def test_wide_beam_hbm_scratch_layout(torch_mod):
         ou.assert_same(_with_nres(got, want), want, "K=500 seed %d" % seed)
 
 
+def test_wide_beam_compile_time_layout_equals_run_time_layout(torch_mod):
+    """Round 6: beams of up to 500 over up to 29 labels (configs[2]'s decoder) run the first wide-beam layout at a compile-time size
+    (decode_kernel.h LAYOUT 3) and read one packed record per parent in phase B (beam_core.h kParentRec).  Same tensors as the run-time
+    layout's kernel bit for bit -- ragged lengths, quantised rows (ties), a small vocabulary -- and both equal the oracle; a vocabulary
+    of 30 labels stays on the run-time layout and is checked against the oracle as well."""
+    for K, V, T, seed, quant in [(200, 29, 90, 81, None), (333, 29, 70, 82, 0.5), (500, 29, 60, 83, 0.25), (500, 5, 80, 84, None), (160, 29, 50, 85, None)]:
+        lp = ou.synth_logprobs(3, T, V, seed, quant=quant)
+        sl = np.array([T, T // 2, 0], dtype=np.int32)
+        want = ou.decode(lp, sl, beam=K, which="restated")
+        got = _decode(torch_mod, lp, sl, beam=K)
+        ou.assert_same(_with_nres(got, want), want, "compile-time wide layout K=%d V=%d" % (K, V))
+        rt = _decode(torch_mod, lp, sl, beam=K, fixed_layout=False)
+        for key in ("tokens", "timesteps", "lens"):
+            assert np.array_equal(got[key], rt[key]), (K, V, key)
+        assert np.array_equal(got["scores"].view(np.uint32), rt["scores"].view(np.uint32)), (K, V)
+    lp = ou.synth_logprobs(2, 60, 30, 86)
+    want = ou.decode(lp, beam=400, which="restated")
+    ou.assert_same(_with_nres(_decode(torch_mod, lp, beam=400), want), want, "run-time wide layout K=400 V=30")
+
+
 def test_beam_width_1000(torch_mod):
     """beam_width=1000 at V=29: 31 000 candidate slots; the slot keys and the rarely read per-entry arrays live in HBM scratch
     (workspace level 2), only the beam itself and the per-frame temporaries stay in LDS."""
