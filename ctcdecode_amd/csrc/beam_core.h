@@ -1910,6 +1910,8 @@ struct Decoder {
           // (speculative select: the list space of a pass is reserved with a returning LDS atomic -- a full round trip.  The
           //  loop is pipelined by hand: the atomic is issued, then the NEXT pass's parent fields are requested, and only then
           //  is the atomic's result used -- LDS answers in order, so the append never waits on its own)
+          // (Measured and dropped, round 6: this loop under a scalar trip counter with the last, partial pass peeled off -- what gave the
+          //  wide-beam layouts 1.2 % (kParentRec) -- leaves the north-star kernel where it is: 43 -> 41 instructions, 5.129 / 5.137 ms.)
           // (Measured and dropped, round 4: two parents per trip -- both parents' fields requested together, the second's
           //  arithmetic in the first's waits: +5 % on the north-star kernel, +2 % at beam 500.  A trip is not waiting for its
           //  parent's fields.)
