@@ -560,13 +560,13 @@ struct Decoder {
   static constexpr bool kLcpTable = kSpec && X::kLcpTable;
   // word models, fixed-layout class at 1024 threads, built-in tables: the n-gram query of a new entry's word runs beside phase B
   // (step(): phase A2 / phase B)
-  // Wide beams without a scorer (round 6): phase B's children loop asks FIVE per-entry arrays for every parent -- first slot, parent label,
+  // The run-time layouts without a scorer (round 6; wide beams first): phase B's children loop asks FIVE per-entry arrays for every parent -- first slot, parent label,
   // score, blank part, existing-children mask -- and in the run-time layouts each array costs an address of its own (ten VALU adds and five
   // LDS reads of the 49 instructions one candidate takes; the loop is bound by issue: 14 000 candidates per frame at beam 500).  Phase A2,
   // where each entry's thread computes the first slot anyway, packs {score, blank part, first slot, label} into ONE 16-byte record per entry
   // (in the next beam's block: nothing lives there between two emissions); the children loop then makes two reads (record, mask) from two
   // addresses.
-  static constexpr bool kParentRec = !SMALLV && LAZY && !LM && X::kParentRec && !kHotPre;  // (the pre-list experiment borrows the same block)
+  static constexpr bool kParentRec = !SMALLV && !LM && X::kParentRec && !kHotPre;  // (the pre-list experiment borrows the same block)
   static constexpr bool kLmOverlap = LM && WORDLM && SMALLV && !CB && !LAZY && X::kLmOverlap;
   static constexpr uint32_t kLmSpaceDeferred = 0x80000000u;  // high gate word of an entry whose space child the settling wave scores
   // ONE thread (X::spec_thread) turns what a frame observed -- its K-th key, the size of its hot list -- into the next frame's
@@ -1870,6 +1870,7 @@ struct Decoder {
         const int r = lane ? rn + ((brank >= 0 && rn >= brank) ? 1 : 0) : 0;
         const int c = IDENT ? r : w.cch[r];
         const float lp = w.clp[r];
+        const uint32_t childinfo = mk_info(c, T_CHILD, 0);
         const int g_first = x.uni(g0);
         const int g_last = g_first + ((x.lanes() >> sh) > 1 ? (x.lanes() >> sh) - 1 : 0);  // the wave's largest first parent
         auto one = [&](int i) {
@@ -1882,6 +1883,7 @@ struct Decoder {
           const uint32_t k = ord_f32_raw(logp) & live;
           const int sl = rc.z + rn;
           w.skey[sl] = k;
+          if (!LAZY) w.sinfo[sl] = x.bitsel(live, childinfo + (uint32_t)i, kHoleInfo);
           hist_add(wd, k, hp, sl);
         };
         if (lane) {
