@@ -270,6 +270,11 @@ class CTCBeamDecoder(object):
         instead of the workgroup kernels / the fused logits-to-candidates pass (identical results)."""
         _native.check(_native.lib.ctcd_debug_set_fused_logits(self._handle, 1 if on else 0))
 
+    def set_prune_registers(self, on=True):
+        """Test hook: False makes the workgroup prune pass read every row twice (the form of rounds 2-5) instead of keeping it in
+        registers (identical results)."""
+        _native.check(_native.lib.ctcd_debug_set_prune_registers(self._handle, 1 if on else 0))
+
     def last_prune_rows(self, rows, stride):
         """Test hook: the vocabulary-prune pass's output of the last call as numpy arrays (counts[rows], labels and values
         [rows, stride], stride = min(cutoff_top_n, V); entries at or beyond a frame's count are unspecified)."""

@@ -19,7 +19,7 @@ RESULT_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, 
 SYMBOLS = ["ctcd_log_softmax", "ctcd_compact_label_capacity", "ctcd_beam_decode_compact", "ctcd_expand_compact", "ctcd_beam_decode_to_host", "ctcd_scorer_create", "ctcd_scorer_destroy", "ctcd_scorer_is_character_based", "ctcd_scorer_max_order", "ctcd_scorer_dict_size",
            "ctcd_scorer_reset_params", "ctcd_scorer_cond_log_prob", "ctcd_scorer_create_callback", "ctcd_scorer_cond_log10", "ctcd_scorer_callback_calls", "ctcd_scorer_callback_seconds", "ctcd_scorer_set_callback_threads", "ctcd_beam_decode_lm", "ctcd_beam_decode_lm_host", "ctcd_stream_create_lm",
            "ctcd_create", "ctcd_destroy", "ctcd_beam_decode", "ctcd_beam_decode_host", "ctcd_check_status", "ctcd_fetch_status_async", "ctcd_stream_create", "ctcd_stream_destroy", "ctcd_stream_frames", "ctcd_stream_decode", "ctcd_stream_decode_to_host", "ctcd_last_prune_host_rows", "ctcd_last_prune_flagged_rows", "ctcd_last_scorer_rounds", "ctcd_last_scorer_waits", "ctcd_set_scorer_wait",
-           "ctcd_set_threads", "ctcd_set_cu_sharing", "ctcd_set_subtree_search", "ctcd_last_subtree_search", "ctcd_debug_set_host_path", "ctcd_set_timing", "ctcd_last_kernel_ms", "ctcd_last_prune_ms", "ctcd_debug_math_check", "ctcd_debug_set_profile", "ctcd_debug_set_fixed_layout", "ctcd_debug_set_prune_resolve", "ctcd_debug_set_fused_logits", "ctcd_debug_prune_rows", "ctcd_debug_timeline", "ctcd_debug_timeline_cap", "ctcd_debug_get_profile", "ctcd_debug_beam_dump", "ctcd_workgroup_lds_bytes", "ctcd_last_error", "ctcd_version"]
+           "ctcd_set_threads", "ctcd_set_cu_sharing", "ctcd_set_subtree_search", "ctcd_last_subtree_search", "ctcd_debug_set_host_path", "ctcd_set_timing", "ctcd_last_kernel_ms", "ctcd_last_prune_ms", "ctcd_debug_math_check", "ctcd_debug_set_profile", "ctcd_debug_set_fixed_layout", "ctcd_debug_set_prune_resolve", "ctcd_debug_set_fused_logits", "ctcd_debug_set_prune_registers", "ctcd_debug_prune_rows", "ctcd_debug_timeline", "ctcd_debug_timeline_cap", "ctcd_debug_get_profile", "ctcd_debug_beam_dump", "ctcd_workgroup_lds_bytes", "ctcd_last_error", "ctcd_version"]
 
 
 def _load():
@@ -50,6 +50,7 @@ def _load():
     lib.ctcd_debug_set_fixed_layout.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.ctcd_debug_set_prune_resolve.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.ctcd_debug_set_fused_logits.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.ctcd_debug_set_prune_registers.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.ctcd_debug_prune_rows.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.ctcd_debug_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.ctcd_debug_beam_dump.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]

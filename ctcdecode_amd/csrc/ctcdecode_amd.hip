@@ -516,8 +516,14 @@ __device__ __forceinline__ int prune_cumulative_cut(const PruneArgs &a, const fl
 #ifndef CTC_PRUNE_WG_OCC
 #define CTC_PRUNE_WG_OCC 8
 #endif
-template <int F4>
-__global__ void __launch_bounds__(256, CTC_PRUNE_WG_OCC) prune_rows_wg_kernel(PruneArgs a) {
+// REG (round 6, late): the row stays in registers between the two looks at it (4 * F4 VGPRs; fewer workgroups per CU) instead of
+// being read again -- the second sweep fetched four lines in five once more (a line serves eight threads, one thread in five
+// looks again): counter traffic 1.78x the row.
+#ifndef CTC_PRUNE_REG_OCC
+#define CTC_PRUNE_REG_OCC 5
+#endif
+template <int F4, bool REG = false>
+__global__ void __launch_bounds__(256, REG ? (F4 <= 4 ? 8 : F4 <= 10 ? CTC_PRUNE_REG_OCC : 3) : CTC_PRUNE_WG_OCC) prune_rows_wg_kernel(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
   __shared__ uint32_t s_bound[4];
   __shared__ int s_cnt;
@@ -542,7 +548,26 @@ __global__ void __launch_bounds__(256, CTC_PRUNE_WG_OCC) prune_rows_wg_kernel(Pr
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     if (tid == 0) s_cnt = 0;
     uint32_t lmax = 0;
-    for (int u0 = 0; u0 < F4; u0 += kChunk) {
+    float4 vr[REG ? F4 : 1];
+    int tq = tid;
+    if (REG) {
+      asm volatile("" : "+v"(tq));  // (opaque per frame: prune_logits_wg_kernel says why)
+#pragma unroll
+      for (int u = 0; u < F4; ++u) {
+        const int i4 = tq + 256 * u;
+        vr[u] = i4 < nv4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+#pragma unroll
+      for (int u = 0; u < F4; ++u) {
+        const int i4 = tq + 256 * u;
+        if (i4 < nv4) {
+          const uint32_t k0 = prune_key(vr[u].x), k1 = prune_key(vr[u].y), k2 = prune_key(vr[u].z), k3 = prune_key(vr[u].w);
+          const uint32_t m01 = k0 > k1 ? k0 : k1, m23 = k2 > k3 ? k2 : k3, m = m01 > m23 ? m01 : m23;
+          lmax = m > lmax ? m : lmax;
+        }
+      }
+    }
+    for (int u0 = 0; !REG && u0 < F4; u0 += kChunk) {
       float4 v[kChunk];
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) {
@@ -570,7 +595,24 @@ __global__ void __launch_bounds__(256, CTC_PRUNE_WG_OCC) prune_rows_wg_kernel(Pr
     bound = s_bound[1] < bound ? s_bound[1] : bound;
     bound = s_bound[2] < bound ? s_bound[2] : bound;
     bound = s_bound[3] < bound ? s_bound[3] : bound;
-    if (lmax >= bound && lmax != 0u) {  // (only the few threads that hold a value at or above the bound sweep again)
+    if (REG) {
+      if (lmax >= bound && lmax != 0u) {
+#pragma unroll
+        for (int u = 0; u < F4; ++u) {
+          const int i4 = tq + 256 * u;
+          if (i4 < nv4) {
+            const float4 v = vr[u];
+            const uint32_t kk[4] = {prune_key(v.x), prune_key(v.y), prune_key(v.z), prune_key(v.w)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (kk[e] >= bound && kk[e] != 0u) {
+                const int p = atomicAdd(&s_cnt, 1);
+                if (p < kPruneCand) { ckey[p] = kk[e]; cidx[p] = 4 * i4 + e; cval[p] = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+              }
+          }
+        }
+      }
+    } else if (lmax >= bound && lmax != 0u) {  // (only the few threads that hold a value at or above the bound sweep again)
       for (int u = 0; u < F4; ++u) {
         const int i4 = tid + 256 * u;
         if (i4 >= nv4) break;
@@ -1086,6 +1128,7 @@ struct ctcd_decoder {
   bool timing = false;
   bool profile = false, dbg_on = false;
   bool no_fixed_layout = false;  // debugging: always use the run-time workspace layout
+  bool no_prune_reg = false;     // debugging / tests: the two-sweep form of the workgroup prune kernel
   bool no_hook_wait = false;     // tests: a callback scorer's launches end at a miss (the form of rounds 4-5) instead of waiting for the answer
   int last_cb_waits = 0;         // answer batches the last call's launches were handed while they waited
   bool no_fused_logits = false;  // tests: raw logits always through the one-wave log_softmax pass and the separate prune
@@ -1600,6 +1643,10 @@ static int decode_common(ctcd_decoder *d, const float *probs, const int32_t *seq
       pfn = V <= 1024 ? (const void *)prune_rows_wg_kernel<1> : V <= 2048 ? (const void *)prune_rows_wg_kernel<2>
           : V <= 4096 ? (const void *)prune_rows_wg_kernel<4> : V <= 10240 ? (const void *)prune_rows_wg_kernel<10>
           : (const void *)prune_rows_wg_kernel<16>;
+      static const bool reg_rows = getenv("CTCD_PRUNE_REG") ? atoi(getenv("CTCD_PRUNE_REG")) != 0 : true;
+      if (reg_rows && !d->no_prune_reg)  // the row held in registers between the two looks at it (V <= 10240: beyond, the registers run out)
+        pfn = V <= 1024 ? (const void *)prune_rows_wg_kernel<1, true> : V <= 2048 ? (const void *)prune_rows_wg_kernel<2, true>
+            : V <= 4096 ? (const void *)prune_rows_wg_kernel<4, true> : V <= 10240 ? (const void *)prune_rows_wg_kernel<10, true> : pfn;
     }
     if (fuse_logits) {  // (same shape conditions)
       pfn = V <= 1024 ? (const void *)prune_logits_wg_kernel<1> : V <= 2048 ? (const void *)prune_logits_wg_kernel<2>
@@ -2945,6 +2992,14 @@ int ctcd_debug_set_prune_resolve(ctcd_decoder *d, int on) {
 int ctcd_debug_set_fused_logits(ctcd_decoder *d, int on) {
   if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
   d->no_fused_logits = on == 0;
+  return CTCD_OK;
+}
+
+// The workgroup prune kernel: 1 (default) = the row stays in registers between the two looks at it, 0 = it is read twice (the form of
+// rounds 2-5; vocabularies beyond 10 240 labels always).  Identical results; tests compare the two.
+int ctcd_debug_set_prune_registers(ctcd_decoder *d, int on) {
+  if (!d) return fail(CTCD_EINVAL, "decoder == NULL");
+  d->no_prune_reg = on == 0;
   return CTCD_OK;
 }
 

@@ -257,6 +257,9 @@ int ctcd_debug_set_prune_resolve(ctcd_decoder *dec, int on);
  * each, and in front of a vocabulary prune not at all -- one kernel reads the logits and emits the kept candidates' normalised
  * values; 0 = always the one-wave log_softmax pass followed by the separate prune (identical results). */
 int ctcd_debug_set_fused_logits(ctcd_decoder *dec, int on);
+/* Test hook: the workgroup form of the vocabulary-prune pass (rows of 257 .. 10 240 labels, a multiple of four, cutoff_top_n <= 64) keeps
+ * the row in registers between its two looks at it (1, default) or reads it twice (0: the form of rounds 2-5).  Identical results. */
+int ctcd_debug_set_prune_registers(ctcd_decoder *dec, int on);
 /* Test hook: the vocabulary-prune pass's output of the last call (get_pruned_log_probs, decoder_utils.cpp:10-45, per frame), copied
  * to HOST memory: cnt[rows], labels / values [rows][stride], stride = min(cutoff_top_n, V); entries at or beyond a frame's count
  * are unspecified.  Waits for the launch stream. */

@@ -1027,6 +1027,51 @@ def test_fused_logits_prune_equals_log_softmax_then_prune(torch_mod, V, top_n, c
     ou.assert_same(_with_nres(got, want), want, "fused logits V=%d" % V)
 
 
+@pytest.mark.parametrize("V,top_n,cp,probs", [(260, 40, 1.0, False), (1000, 40, 0.9, True), (2048, 64, 1.0, False), (4096, 40, 0.6, False),
+                                              (10000, 40, 0.99, False), (10240, 40, 0.95, True), (10240, 3, 1.0, False)])
+def test_prune_row_in_registers_equals_two_sweeps(torch_mod, V, top_n, cp, probs):
+    """Round 6: the workgroup prune pass keeps a row in registers between its two looks at it (rows of up to 10 240 labels) instead of
+    reading it twice.  Per frame -- count, labels, values -- and the decode equal the two-sweep form of rounds 2-5 bit for bit: rows
+    with ties (flagged, settled by the std::sort replay on both sides), NaN rows, probability and log-probability input, ragged
+    lengths; the decode also equals the oracle."""
+    import ctcdecode_amd
+    import ctcdecode_amd._native as n
+
+    torch = torch_mod
+    rng = np.random.default_rng(7 * V + top_n)
+    B, T, K = 3, 27, 20
+    logits = np.stack([_logit_rows_for_prune(rng, T, V) for _ in range(B)])
+    x = ou.log_softmax_rows(logits)
+    x[1, 3, 5] = np.float32("nan")  # (defined here: a NaN sorts below every number)
+    if probs:
+        x = np.exp(x.astype(np.float64)).astype(np.float32)
+    sl = np.array([T, T - 5, 0], np.int32)
+    kw = dict(beam_width=K, cutoff_top_n=top_n, cutoff_prob=cp, log_probs_input=not probs, device="cuda:0")
+    stride = min(top_n, V)
+    res = {}
+    for reg in (True, False):
+        dec = ctcdecode_amd.CTCBeamDecoder([str(i) for i in range(V)], **kw)
+        dec.set_prune_registers(reg)
+        out, sc, ts, ln = dec.decode(torch.from_numpy(x), torch.from_numpy(sl))
+        cnt, lab, val = dec.last_prune_rows(B * T, stride)
+        res[reg] = (out.numpy(), sc.numpy(), ts.numpy(), ln.numpy(), cnt, lab, val, n.lib.ctcd_last_prune_flagged_rows(dec._handle))
+    a, b = res[True], res[False]
+    assert np.array_equal(a[4], b[4]), "counts differ in frames %s" % np.nonzero(a[4] != b[4])[0][:10]
+    for r in range(B * T):
+        c = int(a[4][r])
+        assert np.array_equal(a[5][r, :c], b[5][r, :c]), "labels of frame %d" % r
+        assert np.array_equal(a[6][r, :c].view(np.uint32), b[6][r, :c].view(np.uint32)), "values of frame %d" % r
+    for k in range(4):
+        assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k], b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), "decode output %d" % k
+    assert a[7] == b[7] and a[7] > 0  # the same frames go through the std::sort replay
+    xo = x.copy()
+    xo[1, 3, 5] = 0.0 if probs else -np.inf  # (the oracle's comparators are undefined on a NaN; below every number = what the library defines)
+    if not probs or top_n < V:
+        want = ou.decode(xo, sl, beam=K, cutoff_top_n=top_n, cutoff_prob=cp, log_input=not probs, which="restated")
+        got = dict(tokens=a[0], scores=a[1], timesteps=a[2], lens=a[3])
+        ou.assert_same(_with_nres(got, want), want, "prune in registers V=%d" % V)
+
+
 def test_fused_logits_nan_and_inf_rows(torch_mod):
     """Frames holding NaN or +inf: no order argument applies, the fused pass hands them to the replay -- same output as the
     two-pass form (whose treatment of NaN is the library's own definition: below every number)."""
