@@ -1673,7 +1673,15 @@ struct Decoder {
           if (CTC_RARE(b.viaanc[j] != b.node[P])) {
             int hops = dj - b.dep[P] - 1, xn = b.node[j];
             x.count(EV_WALK, 1); x.count(EV_WALK_HOPS, hops);
+#if !defined(CTC_NO_WALK_FROM_PARENT)
+            // (scorer instantiations -- more than one walk per frame there, each hop a dependent HBM read on the two waves the others wait
+            //  for: the first level up is the entry's own parent field, no read)
+            int h0 = 0;
+            if (LM && hops >= 1) { xn = b.par[j]; h0 = 1; }
+            for (int h = h0; h < hops; ++h) xn = pool[xn].parent;
+#else
             for (int h = 0; h < hops; ++h) xn = pool[xn].parent;
+#endif
             b.via[j] = xn;
             b.viaanc[j] = b.node[P];
             b.viach[j] = pool[xn].ch();
@@ -1754,6 +1762,14 @@ struct Decoder {
         if (has_rep) nbcur = w.clp[r] + nbp;  // :103-106 -- log_sum_exp(-FLT_MAX, y) returns y (decoder_utils.h:50)
         const int P = w.anc[j];
         const int pr = w.pinr[j];
+#if !defined(CTC_NO_LM_REVIVE_PREFETCH)
+        // (scorer instantiations: a dictionary leaves three revival candidates per frame -- tools/beam_stats.py --, so one lane of the entry
+        //  waves takes the revive path below in nearly every frame, and its read of the dead node's label probability from the pool
+        //  (HBM: ~1 k clocks) sat behind the two log_sum_exp chains.  Requested here, it arrives while they run.)
+        const int rx_pre = LM ? w.revr[j] : -1;
+        float xl_pre = 0.f;
+        if (LM && rx_pre >= 0) xl_pre = pool[b.via[j]].lpc;
+#endif
         // Pool updates (global stores) are issued after everything else of the iteration: the memory waits the compiler
         // places in the arithmetic below would otherwise also wait for their acknowledgement.  (Scorer instantiations only:
         // dozens of updates per frame there, one in ten frames on random rows.)
@@ -1788,7 +1804,11 @@ struct Decoder {
           const int cx = b.viach[j];
           const float lp = w.clp[rx];
           const int xn = b.via[j];
+#if !defined(CTC_NO_LM_REVIVE_PREFETCH)
+          float xl = LM ? xl_pre : pool[xn].lpc;
+#else
           float xl = pool[xn].lpc;
+#endif
           if (xl < lp) {
             xl = lp;
             if (LM) { upd_xn = xn; upd_xc = cx; upd_xlp = lp; }
@@ -1917,7 +1937,7 @@ struct Decoder {
           // (Measured and dropped, round 4: two parents per trip -- both parents' fields requested together, the second's
           //  arithmetic in the first's waits: +5 % on the north-star kernel, +2 % at beam 500.  A trip is not waiting for its
           //  parent's fields.)
-          struct Par { int cs; uint32_t hw; int pch; float psc, pbp; uint32_t gw; };
+          struct Par { int cs; uint32_t hw; int pch; float psc, pbp; uint32_t gw, gh; };
           auto fetch = [&](int i) {
             Par p;
             // everything this candidate needs from its parent, requested in one go (one LDS round trip), no branches
@@ -1929,6 +1949,13 @@ struct Decoder {
               p.cs = w.cstart[i]; p.hw = w.hit[hit_word(i, rn)]; p.pch = b.ch[i]; p.psc = b.score[i]; p.pbp = b.bprev[i];
             }
             p.gw = (LM && WORDLM) ? (uint32_t)gate_w[i] : 0u;
+#if !defined(CTC_NO_LM_FETCH_DEFER)
+            // (kLmOverlap: the "space child is being settled" mark travels with the parent's other fields -- asked for behind the cutoff
+            //  test it cost the space lanes' waves an LDS round trip of their own in every trip)
+            p.gh = kLmOverlap ? (uint32_t)b.dmhi[i] : 0u;
+#else
+            p.gh = 0u;
+#endif
             return p;
           };
           int i = g0;
@@ -1952,7 +1979,11 @@ struct Decoder {
                 live = 0u;
               }
               if (kLmOverlap) {
+#if !defined(CTC_NO_LM_FETCH_DEFER)
+                deferred = lm_ovl && c == lm_space && cur.gh == kLmSpaceDeferred;
+#else
                 deferred = lm_ovl && c == lm_space && (uint32_t)b.dmhi[i] == kLmSpaceDeferred;
+#endif
                 if (deferred) live = 0u;
               }
               if (live && lm_scores(c)) logp = lm_apply(logp, lm_window(b, i, c));  // :120-137
