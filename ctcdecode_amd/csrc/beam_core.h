@@ -526,7 +526,8 @@ struct Decoder {
   //  on where a candidate's score comes from, and the outputs are identical (GPU: three input kinds at the configs[4] shape; host sweeps) --
   //  but a dictionary leaves ~ 2 K live candidates per frame (206 at beam 100 with test.arpa), the K-th key lies in the bulk of them, the
   //  band "between K and 128 hot keys" is hit by 61 % of the frames only and their lists average 146 keys (the slow ranking form): kernel
-  //  10.65 -> 10.93 ms on random rows, 10.61 -> 10.83 peaky, 9.72 -> 10.01 blank-dominated.  Not behind the scorer hook in any case: a frame
+  //  10.65 -> 10.93 ms on random rows, 10.61 -> 10.83 peaky, 9.72 -> 10.01 blank-dominated.  Listing EVERY live candidate whenever the last
+  //  frame had at most 248 (84 % of the frames then settle, from lists of 156): 10.32 -> 10.53 / 10.31 -> 10.50 / 9.63 -> 9.57.  Not behind the scorer hook in any case: a frame
   //  that is abandoned and run again would have to restore the list.)
   static constexpr bool kSpec = SMALLV && (!LM || (X::kSpecLm && !CB)) && !LAZY && X::kSpecSelect;
   // Wide beams without a scorer (round 6; measured and left off: CTC_EXP_HOT_PRELIST): phase B pre-lists the candidates at or above a
