@@ -502,6 +502,11 @@ struct Decoder {
   // without bounds tests (decode_kernel.h list_bucket).  Only where the execution policy asks for it (the GPU).
   // With a scorer S can shrink (candidates are cut, the beam may not fill): the keys between the next frame's S and this
   // frame's are then cleared after the frame's closing barrier (step()).
+  // The pruned default's compile-time class (SMALLV == 2, at most 40 candidates per frame): the rank table's entries carry the frame they
+  // were written in -- (t mod 1024) << 6 | rank, 0xFFFF = never -- so that a frame's candidates need not be taken out of the table again
+  // behind the emission (a barrier and a loop per frame); the table is wiped every 1024 frames, when the tags would repeat.
+  static constexpr bool kRankEpoch = SMALLV == 2 && !IDENT && X::kRankEpoch;
+  CTC_HD static int16_t rank_tag(int t, int r) { return (int16_t)(uint16_t)((((uint32_t)t & 1023u) << 6) | (uint32_t)r); }
   static constexpr bool kTailZero = IDENT && SMALLV && !LAZY && X::kZeroKeyTail;
   CTC_HD void zero_key_tail(int from) {
     if (!kTailZero) return;
@@ -989,6 +994,10 @@ struct Decoder {
   CTC_HD int rank_of_char(const StepIn &in, int c) const {
     if (c < 0) return -1;
     if (IDENT) return c < in.Vc ? c : -1;
+    if (kRankEpoch) {
+      const uint32_t v = (uint16_t)w.rank_of[c];
+      return (v >> 6) == ((uint32_t)in.t & 1023u) ? (int)(v & 63u) : -1;
+    }
     return w.rank_of[c];
   }
 
@@ -2445,7 +2454,7 @@ struct Decoder {
     }
     // un-register this step's candidates from the rank table -- only once every wave has finished emitting (the emit
     // loop above still looks characters up in it)
-    if (!IDENT) {
+    if (!IDENT && !kRankEpoch) {
       x.sync();
       for (int r = tid; r < Vc; r += nt) w.rank_of[w.cch[r]] = -1;
     }
@@ -2848,8 +2857,12 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
       in.identity = 0;
       if (prefetch) {
         in.Vc = x.uni(pre_cnt);
+        if (Dec0::kRankEpoch && CTC_RARE((in.t & 1023) == 0 && t > 0)) {  // (the tags are about to repeat: the last frame's barrier is behind us)
+          for (int c = tid; c < d.V; c += nt) w.rank_of[c] = -1;
+          x.sync();
+        }
         if (tid < in.Vc) {
-          w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = (int16_t)tid;
+          w.cch[tid] = pre_ch; w.clp[tid] = pre_lp; w.rank_of[pre_ch] = Dec0::kRankEpoch ? Dec0::rank_tag(in.t, tid) : (int16_t)tid;
           if (t == 0) dec.note_lp(pre_lp);
           // (speculative select: the anchor of this frame's prediction -- the list is in descending order, decoder_utils.cpp:23-24)
           if ((Dec0::kSpec || Dec0::kHotPre) && tid == 0) w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(pre_lp);
@@ -2867,7 +2880,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
           const float v = pr->lp[(size_t)t * width + r];
           w.cch[r] = c;
           w.clp[r] = v;
-          w.rank_of[c] = (int16_t)r;
+          w.rank_of[c] = Dec0::kRankEpoch ? Dec0::rank_tag(in.t, r) : (int16_t)r;
           if (t == 0) dec.note_lp(v);
           if ((Dec0::kSpec || Dec0::kHotPre) && r == 0) w.vars[VAR_ROWMAX] = (int)ctcmath::f32_to_bits(v);
         }
@@ -2878,7 +2891,7 @@ CTC_HD int decode_utterance(X &x, Work &w, const Dims &d, int blank, const float
         }
       }
       x.sync();
-      in.blank_rank = x.uni((int)w.rank_of[blank]);
+      in.blank_rank = x.uni(dec.rank_of_char(in, blank));
     }
     x.tick();
     x.mark(10);

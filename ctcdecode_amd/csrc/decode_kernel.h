@@ -226,6 +226,11 @@ struct DevX {
 #else
   static constexpr bool kSpecSelect = true;
 #endif
+#if defined(CTC_NO_RANK_EPOCH)
+  static constexpr bool kRankEpoch = false;
+#else
+  static constexpr bool kRankEpoch = true;  // (beam_core.h kRankEpoch)
+#endif
 #if defined(CTC_NO_PARENT_REC)
   static constexpr bool kParentRec = false;
 #else

@@ -65,6 +65,11 @@ struct HostX {
   void tick() {}
   // speculative select (beam_core.h Decoder::kSpec), sequentially: the same contract as the device policy's
   static constexpr bool kSpecSelect = true;
+#if defined(CTC_NO_RANK_EPOCH)
+  static constexpr bool kRankEpoch = false;
+#else
+  static constexpr bool kRankEpoch = true;
+#endif
 #if defined(CTC_NO_PARENT_REC)
   static constexpr bool kParentRec = false;
 #else

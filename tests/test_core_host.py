@@ -144,6 +144,16 @@ def test_core_hbm_scratch_layout(monkeypatch, level):
     ou.assert_same(ou.decode(lp, beam=1000), ou.decode_core_host(lp, beam=1000), "beam 1000")
 
 
+def test_core_rank_table_tags_wrap():
+    """The pruned default's compile-time class tags the rank table's entries with the frame (mod 1024) instead of taking a frame's candidates
+    out of the table again; the table is wiped when the tags repeat: utterances longer than 1024 frames, against the oracle."""
+    for seed, (V, top_n, K, T) in enumerate([(300, 20, 30, 2100), (64, 40, 50, 1100)]):
+        lp = ou.synth_logprobs(1, T, V, 4400 + seed)
+        want = ou.decode(lp, beam=K, cutoff_top_n=top_n)
+        got = ou.decode_core_host(lp, None, beam=K, cutoff_top_n=top_n)
+        ou.assert_same(got, want, "rank-table tags V=%d T=%d" % (V, T))
+
+
 def test_core_streaming_equals_one_shot():
     """The stream state (beam parked between chunks) on the host build: arbitrary chunkings, empty chunks included."""
     rng = np.random.default_rng(3)

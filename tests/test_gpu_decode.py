@@ -244,6 +244,34 @@ def test_wide_beam_hbm_scratch_layout(torch_mod):
         ou.assert_same(_with_nres(got, want), want, "K=500 seed %d" % seed)
 
 
+def test_rank_table_tags_wrap_offline_and_streamed(torch_mod):
+    """Round 6: kernel <0,0,2,true,1024> tags its rank-table entries with the frame (mod 1024) and wipes the table when the tags repeat.
+    Utterances longer than 1024 frames -- in one launch, and as streams whose chunks end before, at and behind the wrap -- equal the
+    oracle and the run-time layout's kernel (which takes the candidates out of the table every frame)."""
+    import ctcdecode_amd
+
+    torch = torch_mod
+    V, top_n, K, T = 300, 20, 30, 1150
+    lp = ou.synth_logprobs(2, T, V, 4411)
+    want = ou.decode(lp, beam=K, cutoff_top_n=top_n)
+    got = _decode(torch, lp, beam=K, cutoff_top_n=top_n)
+    ou.assert_same(_with_nres(got, want), want, "rank-table tags, one launch")
+    rt = _decode(torch, lp, beam=K, cutoff_top_n=top_n, fixed_layout=False)
+    for key in ("tokens", "timesteps", "lens"):
+        assert np.array_equal(got[key], rt[key]), key
+    dec = ctcdecode_amd.OnlineCTCBeamDecoder([str(i) for i in range(V)], cutoff_top_n=top_n, beam_width=K, log_probs_input=True, device="cuda:0")
+    states = [ctcdecode_amd.DecoderState(dec) for _ in range(2)]
+    x = torch.from_numpy(lp)
+    bounds = [0, 400, 1023, 1024, 1025, T]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        out, sc, ts, ln = dec.decode(x[:, a:b], states, [b == T] * 2)
+    L = out.shape[2]
+    chunked = dict(tokens=np.zeros((2, K, T), np.int32), timesteps=np.zeros((2, K, T), np.int32), scores=sc.numpy(), lens=ln.numpy(), nres=want["nres"])
+    chunked["tokens"][:, : out.shape[1], :L] = out.numpy()
+    chunked["timesteps"][:, : out.shape[1], :L] = ts.numpy()
+    ou.assert_same(chunked, want, "rank-table tags, streamed across the wrap")
+
+
 def test_wide_beam_compile_time_layout_equals_run_time_layout(torch_mod):
     """Round 6: beams of up to 500 over up to 29 labels (configs[2]'s decoder) run the first wide-beam layout at a compile-time size
     (decode_kernel.h LAYOUT 3) and read one packed record per parent in phase B (beam_core.h kParentRec).  Same tensors as the run-time
