@@ -631,6 +631,8 @@ def main():
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
     ndev = torch.cuda.device_count()
+    if ndev == 0:  # (the hot path has no CPU form: fail loudly instead of measuring something else)
+        raise SystemExit("bench.py: no HIP device visible -- this benchmark times the MI355X kernels and has no CPU fallback")
     shared = ndev < world  # fewer devices than ranks (single-GPU dry run of the N-rank path): ranks share devices
     torch.cuda.set_device(local % ndev)
     dev = torch.device("cuda", local % ndev)
